@@ -1,0 +1,237 @@
+/*
+ * rayrs_hip.h -- C ABI of the MI355X (gfx950) build of rayrs-lib's per-pixel
+ * radiance integrator.
+ *
+ * The reference (Frojdholm/rayrs) has no FFI: its finest seam is the Rust
+ * call pair Camera::generate_primary_ray (rayrs-lib/src/lib.rs:202) +
+ * rayrs_lib::radiance (lib.rs:521) inside the rayon block loop of
+ * rayrs/src/main.rs:57-101.  A per-ray FFI is useless for a GPU, so this
+ * boundary is per image: rayrs_render replaces main.rs:57-101 wholesale, and
+ * because Scene/Object/Camera keep their fields private (lib.rs:56-67,
+ * :216-220, :302-306) the constructors are part of the boundary too.  Each
+ * entry point names the reference item it stands for; INTEGRATION.md shows
+ * the Rust `extern "C"` block a maintainer would add to rayrs-lib.
+ *
+ * Conventions: every function returns 0 (RAYRS_OK) or a negative
+ * rayrs_status; nothing unwinds or aborts across the boundary.  Parameter
+ * checks are the reference's assert!s turned into RAYRS_INVALID_ARG.  Plain
+ * pointers and sizes only; device pointers are passed as void*.
+ */
+#ifndef RAYRS_HIP_H
+#define RAYRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RAYRS_OK = 0,
+    RAYRS_INVALID_ARG = -1, /* a reference assert! would have fired */
+    RAYRS_HIP_ERROR = -2,   /* a HIP runtime call failed (see rayrs_last_error) */
+    RAYRS_OOM = -3,
+    RAYRS_NO_DEVICE = -4,   /* scene was created host-only or no GPU present */
+    RAYRS_UNSUPPORTED = -5  /* e.g. BVH deeper than the kernel's LDS stack */
+} rayrs_status;
+
+const char* rayrs_strerror(int status);
+/* Text of the last HIP error seen by the calling thread ("" if none). */
+const char* rayrs_last_error(void);
+
+/* ---- material.rs ---- */
+
+/* enum Material, material.rs:57-68 */
+enum {
+    RAYRS_MAT_LAMBERTIAN = 0,            /* LambertianDiffuse::new(color)              :608 */
+    RAYRS_MAT_REFLECT = 1,               /* Reflect::new(color)                        :629 */
+    RAYRS_MAT_REFRACT = 2,               /* Refract::new(color, ior)                   :650 */
+    RAYRS_MAT_GLASS = 3,                 /* Glass::new(color, ior)                     :673 */
+    RAYRS_MAT_COOK_TORRANCE = 4,         /* CookTorrance::new(color, alpha, fresnel)   :705 */
+    RAYRS_MAT_COOK_TORRANCE_REFRACT = 5, /* CookTorranceRefract::new(color, alpha, ior):832 */
+    RAYRS_MAT_COOK_TORRANCE_GLASS = 6,   /* CookTorranceGlass::new(color, alpha, ior)  :863 */
+    RAYRS_MAT_PLASTIC = 7,               /* Plastic::new(color, spec_color, alpha, ior):887 */
+    RAYRS_MAT_NO_REFLECT = 8             /* Material::NoReflect                            */
+};
+
+typedef struct {
+    int32_t kind;         /* RAYRS_MAT_* */
+    int32_t metallic;     /* CookTorrance: 1 = Fresnel::SchlickMetallic(r0), 0 = SchlickDielectric(ior) (:128-131) */
+    double color[3];
+    double spec_color[3]; /* Plastic only */
+    double alpha;         /* roughness; stored squared like the reference ctor (:711) */
+    double ior;
+    double r0[3];
+} rayrs_material;
+
+/* enum Emission, material.rs:1056-1075; emissive = 0 is Emission::Dark */
+typedef struct {
+    int32_t emissive;
+    int32_t pad;
+    double strength;
+    double color[3];
+} rayrs_emission;
+
+/* enum Axis, geometry.rs:161-168 */
+enum { RAYRS_AXIS_X = 0, RAYRS_AXIS_XREV = 1, RAYRS_AXIS_Y = 2, RAYRS_AXIS_YREV = 3, RAYRS_AXIS_Z = 4, RAYRS_AXIS_ZREV = 5 };
+
+/* enum BvhHeuristic, bvh.rs:187-191 */
+enum { RAYRS_BVH_MIDPOINT = 0, RAYRS_BVH_SAH = 1 };
+
+/* ---- Vec<Object>: lib.rs:302-512 ---- */
+
+typedef struct rayrs_objects rayrs_objects;
+
+int rayrs_objects_create(rayrs_objects** out);
+void rayrs_objects_destroy(rayrs_objects* objs);
+uint64_t rayrs_objects_len(const rayrs_objects* objs);
+
+/* Object::sphere(radius, origin, mat, emission)                     lib.rs:321 */
+int rayrs_object_sphere(rayrs_objects* objs, double radius, const double origin[3], const rayrs_material* mat,
+                        const rayrs_emission* emission);
+/* Object::plane(axis, umin, umax, vmin, vmax, pos, mat, emission)   lib.rs:342 */
+int rayrs_object_plane(rayrs_objects* objs, int axis, double umin, double umax, double vmin, double vmax, double pos,
+                       const rayrs_material* mat, const rayrs_emission* emission);
+/* Object::triangle(p1, p2, p3, mat, emission)                       lib.rs:380 */
+int rayrs_object_triangle(rayrs_objects* objs, const double p1[3], const double p2[3], const double p3[3],
+                          const rayrs_material* mat, const rayrs_emission* emission);
+/* Object::from_triangles(tris, mat, emission)                       lib.rs:407
+ * as an indexed mesh: verts = nverts*3 coordinates, idx = ntris*3 vertex
+ * indices (0-based, counter-clockwise).  The f32 form is what a PLY file
+ * holds; the values are widened to f64 exactly. */
+int rayrs_object_from_triangles_f32(rayrs_objects* objs, const float* verts, uint32_t nverts, const uint32_t* idx,
+                                    uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission);
+int rayrs_object_from_triangles_f64(rayrs_objects* objs, const double* verts, uint32_t nverts, const uint32_t* idx,
+                                    uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission);
+/* Object::from_spheres(spheres, mat, emission)                      lib.rs:422
+ * centers = n*3 */
+int rayrs_object_from_spheres(rayrs_objects* objs, double radius, const double* centers, uint32_t n,
+                              const rayrs_material* mat, const rayrs_emission* emission);
+/* Object::box_geom(lower_left, upper_right, mat, emission)          lib.rs:438 */
+int rayrs_object_box_geom(rayrs_objects* objs, const double lower_left[3], const double upper_right[3],
+                          const rayrs_material* mat, const rayrs_emission* emission);
+
+/* ---- Scene: lib.rs:216-296 ---- */
+
+typedef struct rayrs_scene rayrs_scene;
+
+/* Scene::new(objects, z_near, z_far, heuristic, hdri)               lib.rs:227
+ * Consumes nothing: `objs` stays owned by the caller and may be destroyed
+ * right after.  Builds the BVH exactly as Bvh::build does (bvh.rs:199-389,
+ * same splits, same child order), flattens it and uploads it to HIP device
+ * `device`.  device = -1 builds a host-only scene (no GPU needed) that can
+ * be inspected with rayrs_scene_info / rayrs_scene_export_bvh but not
+ * rendered.  hdri_rgb: hdri_w*hdri_h RGB f32 texels, row-major, image origin
+ * upper left; values are clipped to [0, 3] as main.rs:43 does. */
+int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int heuristic, uint32_t splits,
+                    uint32_t hdri_w, uint32_t hdri_h, const float* hdri_rgb, int device, rayrs_scene** out);
+void rayrs_scene_destroy(rayrs_scene* scene);
+
+typedef struct {
+    uint64_t n_objects;
+    uint32_t n_interior;   /* two-child records */
+    uint32_t n_prims;      /* leaf primitives in DFS order (== n_objects) */
+    uint32_t root_ref;
+    uint32_t depth;        /* stack entries the traversal can need */
+    uint32_t compact;      /* 1 = f32 node boxes / f32 triangle vertices (exactly representable) */
+    uint32_t n_surfaces;
+    uint32_t node_bytes;   /* bytes of one interior record on the device */
+    uint32_t prim_bytes;   /* bytes of one primitive record on the device */
+    uint64_t device_bytes; /* total scene footprint in HBM */
+    double root_box[6];    /* xmin,xmax,ymin,ymax,zmin,zmax */
+    double build_seconds;
+} rayrs_scene_info_t;
+
+int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
+/* child_box: n_interior*2*6 f64, child_ref: n_interior*2 u32, prim_object:
+ * n_prims u32 (index of the object, in insertion order, at each DFS slot).
+ * ref = kind<<30 | payload; kind 0 = interior record (payload = index),
+ * 1 = 1..4 primitives behind a box test (payload = first<<2 | count-1),
+ * 2 = one primitive with no box test (payload = prim<<2). */
+int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t* child_ref, uint32_t* prim_object);
+
+/* ---- Camera: lib.rs:54-211 ---- */
+
+typedef struct {
+    double origin[3];
+    double e_x[3];
+    double e_y[3];
+    double z[3];
+    double width, height;
+    uint32_t ppc;
+    uint32_t x_pixels; /* Camera::x_pixels lib.rs:153 */
+    uint32_t y_pixels; /* Camera::y_pixels lib.rs:175 */
+} rayrs_camera;
+
+/* Camera::new(origin, up, lookat, fov, width, height, ppi)          lib.rs:99 */
+int rayrs_camera_new(const double origin[3], const double up[3], const double lookat[3], double fov, double width,
+                     double height, uint32_t ppi, rayrs_camera* out);
+
+/* ---- render: the block loop of rayrs/src/main.rs:57-101 ---- */
+
+enum { RAYRS_OUT_F32 = 0, RAYRS_OUT_F64 = 1 };
+
+typedef struct {
+    uint32_t spp;          /* main.rs:68 */
+    uint32_t max_bounces;  /* main.rs:77 passes 50 */
+    uint64_t seed;         /* build-defined RNG, include/rayrs_numeric.h */
+    /* Pixels are summed per pixel in chunks of `sample_chunk` consecutive
+     * samples; chunk sums are added in chunk order.  0 or >= spp reproduces
+     * the reference's single sequential sum (main.rs:67-79). */
+    uint32_t sample_chunk;
+    /* Image tiles (8x8 pixels, row-major tile index t) with
+     * t % tile_ranks == tile_rank are rendered; other pixels of `out` are not
+     * written.  1-GPU: tile_rank 0, tile_ranks 1. */
+    uint32_t tile_rank, tile_ranks;
+    uint32_t out_format;   /* RAYRS_OUT_F32: f32x3 (image.rs:224-229), RAYRS_OUT_F64: f64x3 */
+    uint32_t count_work;   /* 1 = also count traversal work (slower; for the roofline figure) */
+} rayrs_render_params;
+
+typedef struct {
+    uint64_t rays;          /* BVH queries = radiance loop iterations, lib.rs:525-526 */
+    uint64_t paths;
+    uint64_t nan_pixels;    /* main.rs:81-83 */
+    uint64_t neg_pixels;    /* main.rs:85-87 */
+    uint64_t interior_visits; /* the next five only with count_work */
+    uint64_t tri_tests;
+    uint64_t sphere_tests;
+    uint64_t plane_tests;
+    uint64_t escaped_paths;
+    double kernel_ms;       /* HIP-event time of the trace kernel on its stream */
+    double total_ms;        /* trace + resolve */
+} rayrs_render_stats;
+
+/* Renders into a HOST buffer of y_pixels*x_pixels*3 elements (row-major,
+ * origin upper left, RGB).  Synchronous. */
+int rayrs_render(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params, void* out_host,
+                 rayrs_render_stats* stats);
+
+/* Enqueues the render on `hip_stream` (a hipStream_t, NULL = default stream)
+ * writing a DEVICE buffer of the same shape; returns without synchronising. */
+int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
+                        void* out_device, void* hip_stream);
+/* Waits for the last rayrs_render_launch on this scene and returns its counters. */
+int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats);
+
+/* ---- device self-test hooks (used by tests/ to check single functions
+ *      of the hot path on the GPU against the oracle) ---- */
+
+/* fn: 0 sin 1 cos 2 tan 3 log 4 exp 5 acos 6 atan2(x[i], y[i]) 7 sqrt
+ *     8 x/y 9 rng bits (x,y reinterpreted: unused) */
+int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out);
+int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
+                   uint64_t n, uint64_t* out_bits);
+/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss). */
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, double* t, int64_t* object);
+/* Material::evaluate for n (normal, view, key) tuples with one material:
+ * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */
+int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
+                        const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
+                        uint32_t* draws);
+/* Scene::background for n directions. */
+int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -141,7 +141,7 @@ RR_FN void rr_rem_pio2(double x, double* r, double* t, int* q) {
     *t = rr_fma(-k, PIO2_LO, hi - rr);
     *r = rr;
     /* k is an integer of small magnitude */
-    *q = (int)((long long)k & 3LL);
+    *q = ((int)k) & 3;
 }
 
 RR_FN double rr_sin(double x) {

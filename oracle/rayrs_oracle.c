@@ -1565,7 +1565,7 @@ static v3 radiance(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng
 typedef struct {
     const orc_scene* s;
     const orc_camera* c;
-    uint32_t spp, max_bounces, row0, row1, width, height;
+    uint32_t spp, max_bounces, row0, row1, width, height, chunk;
     uint64_t seed;
     int traversal;
     double* out;
@@ -1594,15 +1594,23 @@ static void* render_worker(void* arg) {
                 if (row < job->row0 || row >= job->row1) continue;
                 v3 pixel = V(0, 0, 0);
                 uint64_t pix_index = (uint64_t)row * job->width + col;
-                for (uint32_t sidx = 0; sidx < job->spp; sidx++) {
-                    rng_t rng;
-                    rng.key = rr_path_key(job->seed, pix_index, sidx);
-                    rng.draw = 0;
-                    /* main.rs:74-75: camera origin is lower right */
-                    ray_t r = primary_ray(job->c, job->height - i - off_y, job->width - j - off_x, &rng);
-                    v3 rad = radiance(job->s, r, job->max_bounces, &rng, job->traversal, &pc);
-                    pixel = v_add(pixel, rad);
-                    paths++;
+                /* main.rs:67-79; with chunk < spp the samples are summed per
+                 * chunk and the chunk sums added in order (build-defined
+                 * variant used for load balancing on the GPU) */
+                for (uint32_t s0 = 0; s0 < job->spp; s0 += job->chunk) {
+                    v3 part = V(0, 0, 0);
+                    uint32_t s1 = s0 + job->chunk < job->spp ? s0 + job->chunk : job->spp;
+                    for (uint32_t sidx = s0; sidx < s1; sidx++) {
+                        rng_t rng;
+                        rng.key = rr_path_key(job->seed, pix_index, sidx);
+                        rng.draw = 0;
+                        /* main.rs:74-75: camera origin is lower right */
+                        ray_t r = primary_ray(job->c, job->height - i - off_y, job->width - j - off_x, &rng);
+                        v3 rad = radiance(job->s, r, job->max_bounces, &rng, job->traversal, &pc);
+                        part = v_add(part, rad);
+                        paths++;
+                    }
+                    pixel = s0 == 0 ? part : v_add(pixel, part);
                 }
                 if (rr_isnan(pixel.x) || rr_isnan(pixel.y) || rr_isnan(pixel.z)) nan_px++;
                 if (pixel.x < 0.0 || pixel.y < 0.0 || pixel.z < 0.0) neg_px++;
@@ -1626,7 +1634,8 @@ static void* render_worker(void* arg) {
 }
 
 int orc_render(const orc_scene* s, const orc_camera* c, uint32_t spp, uint32_t max_bounces, uint64_t seed,
-               uint32_t row0, uint32_t row1, int nthreads, int traversal, double* out_rgb, orc_stats* stats) {
+               uint32_t sample_chunk, uint32_t row0, uint32_t row1, int nthreads, int traversal, double* out_rgb,
+               orc_stats* stats) {
     if (!s || !s->built || !c || !out_rgb || spp == 0) return -1;
     if (traversal == 1 && s->finfo.depth > 250) return -1;
     render_job job;
@@ -1636,6 +1645,7 @@ int orc_render(const orc_scene* s, const orc_camera* c, uint32_t spp, uint32_t m
     job.spp = spp;
     job.max_bounces = max_bounces;
     job.seed = seed;
+    job.chunk = (sample_chunk == 0 || sample_chunk >= spp) ? spp : sample_chunk;
     job.width = c->x_pixels;
     job.height = c->y_pixels;
     job.row0 = row0;

@@ -119,10 +119,13 @@ int orc_camera_new(const double origin[3], const double up[3], const double look
 /* The block loop of main.rs:57-101 with the build-defined RNG.
  * traversal: 0 = recursive reference traversal (bvh.rs:391-415),
  *            1 = ordered traversal with closest-hit culling (the kernel's).
+ * sample_chunk: 0 or >= spp = one sequential sum per pixel (main.rs:67-79);
+ * otherwise per-chunk sums added in chunk order (see include/rayrs_hip.h).
  * rows [row0,row1) of the image are rendered (whole image: 0,height); the
  * rest of out_rgb is left untouched.  out_rgb: height*width*3 f64. */
 int orc_render(const orc_scene* s, const orc_camera* c, uint32_t spp, uint32_t max_bounces, uint64_t seed,
-               uint32_t row0, uint32_t row1, int nthreads, int traversal, double* out_rgb, orc_stats* stats);
+               uint32_t sample_chunk, uint32_t row0, uint32_t row1, int nthreads, int traversal, double* out_rgb,
+               orc_stats* stats);
 
 /* ---- unit-level entry points for the known-answer and parity tests ---- */
 

@@ -1,0 +1,134 @@
+"""ctypes declarations for librayrs_hip.so (include/rayrs_hip.h).
+
+There is no fallback: if the shared library is missing this module raises, so a
+product call can never silently run on anything but the HIP build.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librayrs_hip.so")
+
+# every symbol include/rayrs_hip.h declares
+SYMBOLS = [
+    "rayrs_strerror", "rayrs_last_error",
+    "rayrs_objects_create", "rayrs_objects_destroy", "rayrs_objects_len",
+    "rayrs_object_sphere", "rayrs_object_plane", "rayrs_object_triangle",
+    "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
+    "rayrs_object_from_spheres", "rayrs_object_box_geom",
+    "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
+    "rayrs_camera_new",
+    "rayrs_render", "rayrs_render_launch", "rayrs_render_finish",
+    "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
+    "rayrs_test_background",
+]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("metallic", C.c_int32), ("color", C.c_double * 3),
+                ("spec_color", C.c_double * 3), ("alpha", C.c_double), ("ior", C.c_double),
+                ("r0", C.c_double * 3)]
+
+
+class EmissionDesc(C.Structure):
+    _fields_ = [("emissive", C.c_int32), ("pad", C.c_int32), ("strength", C.c_double),
+                ("color", C.c_double * 3)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("e_x", C.c_double * 3), ("e_y", C.c_double * 3),
+                ("z", C.c_double * 3), ("width", C.c_double), ("height", C.c_double),
+                ("ppc", C.c_uint32), ("x_pixels", C.c_uint32), ("y_pixels", C.c_uint32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_objects", C.c_uint64), ("n_interior", C.c_uint32), ("n_prims", C.c_uint32),
+                ("root_ref", C.c_uint32), ("depth", C.c_uint32), ("compact", C.c_uint32),
+                ("n_surfaces", C.c_uint32), ("node_bytes", C.c_uint32), ("prim_bytes", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
+                ("build_seconds", C.c_double)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("max_bounces", C.c_uint32), ("seed", C.c_uint64),
+                ("sample_chunk", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_ranks", C.c_uint32),
+                ("out_format", C.c_uint32), ("count_work", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("nan_pixels", C.c_uint64),
+                ("neg_pixels", C.c_uint64), ("interior_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64), ("escaped_paths", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load librayrs_hip.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C rayrs_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.rayrs_strerror.restype = C.c_char_p
+    L.rayrs_strerror.argtypes = [C.c_int]
+    L.rayrs_last_error.restype = C.c_char_p
+    L.rayrs_objects_create.argtypes = [C.POINTER(vp)]
+    L.rayrs_objects_destroy.argtypes = [vp]
+    L.rayrs_objects_destroy.restype = None
+    L.rayrs_objects_len.argtypes = [vp]
+    L.rayrs_objects_len.restype = C.c_uint64
+    mp, ep = C.POINTER(MaterialDesc), C.POINTER(EmissionDesc)
+    L.rayrs_object_sphere.argtypes = [vp, C.c_double, dp, mp, ep]
+    L.rayrs_object_plane.argtypes = [vp, C.c_int] + [C.c_double] * 5 + [mp, ep]
+    L.rayrs_object_triangle.argtypes = [vp, dp, dp, dp, mp, ep]
+    L.rayrs_object_from_triangles_f32.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, mp, ep]
+    L.rayrs_object_from_triangles_f64.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, mp, ep]
+    L.rayrs_object_from_spheres.argtypes = [vp, C.c_double, vp, C.c_uint32, mp, ep]
+    L.rayrs_object_box_geom.argtypes = [vp, dp, dp, mp, ep]
+    L.rayrs_scene_new.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                  C.c_int, C.POINTER(vp)]
+    L.rayrs_scene_destroy.argtypes = [vp]
+    L.rayrs_scene_destroy.restype = None
+    L.rayrs_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
+    L.rayrs_camera_new.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_uint32,
+                                   C.POINTER(CameraDesc)]
+    L.rayrs_render.argtypes = [vp, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp, C.POINTER(RenderStats)]
+    L.rayrs_render_launch.argtypes = [vp, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp, vp]
+    L.rayrs_render_finish.argtypes = [vp, C.POINTER(RenderStats)]
+    L.rayrs_test_math.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp]
+    L.rayrs_test_rng.argtypes = [C.c_int, C.c_uint64, vp, vp, vp, C.c_uint64, vp]
+    L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rayrs_test_material.argtypes = [C.c_int, mp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
+    L.rayrs_test_background.argtypes = [vp, vp, C.c_uint64, vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("rayrs_strerror",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+class RayrsError(RuntimeError):
+    def __init__(self, status, where):
+        L = lib()
+        msg = L.rayrs_strerror(status).decode()
+        extra = L.rayrs_last_error().decode()
+        super().__init__(f"{where}: {msg} ({status})" + (f" [{extra}]" if extra else ""))
+        self.status = status
+
+
+def check(status, where):
+    if status != 0:
+        raise RayrsError(status, where)

@@ -1,0 +1,584 @@
+// abi.cpp -- the extern "C" boundary declared in include/rayrs_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rayrs_hip.h"
+#include "kernels.h"
+#include "scene_host.hpp"
+
+using namespace rayrs;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? RAYRS_OOM : RAYRS_HIP_ERROR;
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+constexpr uint32_t MAX_STACK_DEPTH = 96;  // 4 waves * 64 lanes * 96 * 4 B = 96 KiB of LDS per workgroup
+
+}  // namespace
+
+struct rayrs_objects {
+    ObjectList list;
+};
+
+struct rayrs_scene {
+    FlatScene flat;
+    std::vector<SurfaceDev> surfaces;
+    uint64_t n_objects = 0;
+    int device = -1;
+    void* d_nodes = nullptr;
+    void* d_prims = nullptr;
+    SurfaceDev* d_surfaces = nullptr;
+    float* d_hdri = nullptr;
+    Counters* d_counters = nullptr;
+    double* d_partial = nullptr;
+    size_t partial_items = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    bool last_count = false;
+    int cu_count = 0;
+    int blocks_per_cu = 0;
+    uint64_t device_bytes = 0;
+};
+
+static void push_triangle(ObjectList& l, Vec3 p1, Vec3 p2, Vec3 p3, uint32_t surf) {
+    Object o;
+    std::memset(&o, 0, sizeof(o));
+    o.geom.kind = PRIM_TRIANGLE;
+    o.geom.p1 = p1, o.geom.p2 = p2, o.geom.p3 = p3;
+    o.surface = surf;
+    l.objs.push_back(o);
+}
+
+template <typename T>
+static int from_triangles(rayrs_objects* objs, const T* verts, uint32_t nverts, const uint32_t* idx, uint32_t ntris,
+                          const rayrs_material* mat, const rayrs_emission* emission) {
+    if (!objs || (!verts && nverts) || (!idx && ntris)) return RAYRS_INVALID_ARG;
+    for (size_t i = 0; i < (size_t)ntris * 3; i++)
+        if (idx[i] >= nverts) return RAYRS_INVALID_ARG;
+    const int surf = objs->list.add_surface(mat, emission);
+    if (surf < 0) return surf;
+    objs->list.objs.reserve(objs->list.objs.size() + ntris);
+    for (uint32_t t = 0; t < ntris; t++) {
+        const T* a = verts + 3 * (size_t)idx[3 * t];
+        const T* b = verts + 3 * (size_t)idx[3 * t + 1];
+        const T* c = verts + 3 * (size_t)idx[3 * t + 2];
+        push_triangle(objs->list, {(double)a[0], (double)a[1], (double)a[2]},
+                      {(double)b[0], (double)b[1], (double)b[2]}, {(double)c[0], (double)c[1], (double)c[2]},
+                      (uint32_t)surf);
+    }
+    return RAYRS_OK;
+}
+
+extern "C" {
+
+const char* rayrs_strerror(int status) {
+    switch (status) {
+        case RAYRS_OK: return "ok";
+        case RAYRS_INVALID_ARG: return "invalid argument (a reference assert! would have fired)";
+        case RAYRS_HIP_ERROR: return "HIP runtime error";
+        case RAYRS_OOM: return "out of memory";
+        case RAYRS_NO_DEVICE: return "no HIP device for this scene";
+        case RAYRS_UNSUPPORTED: return "unsupported (size or depth limit)";
+        default: return "unknown status";
+    }
+}
+
+const char* rayrs_last_error(void) { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------- Vec<Object>
+
+int rayrs_objects_create(rayrs_objects** out) {
+    if (!out) return RAYRS_INVALID_ARG;
+    *out = new (std::nothrow) rayrs_objects();
+    return *out ? RAYRS_OK : RAYRS_OOM;
+}
+
+void rayrs_objects_destroy(rayrs_objects* objs) { delete objs; }
+
+uint64_t rayrs_objects_len(const rayrs_objects* objs) { return objs ? objs->list.objs.size() : 0; }
+
+int rayrs_object_sphere(rayrs_objects* objs, double radius, const double origin[3], const rayrs_material* mat,
+                        const rayrs_emission* emission) {
+    if (!objs || !origin) return RAYRS_INVALID_ARG;
+    if (!(radius > 0.)) return RAYRS_INVALID_ARG;  // geometry.rs:97
+    const int surf = objs->list.add_surface(mat, emission);
+    if (surf < 0) return surf;
+    Object o;
+    std::memset(&o, 0, sizeof(o));
+    o.geom.kind = PRIM_SPHERE;
+    o.geom.radius2 = radius * radius;  // geometry.rs:99
+    o.geom.origin = {origin[0], origin[1], origin[2]};
+    o.surface = (uint32_t)surf;
+    objs->list.objs.push_back(o);
+    return RAYRS_OK;
+}
+
+int rayrs_object_plane(rayrs_objects* objs, int axis, double umin, double umax, double vmin, double vmax, double pos,
+                       const rayrs_material* mat, const rayrs_emission* emission) {
+    if (!objs) return RAYRS_INVALID_ARG;
+    if (!(umin < umax && vmin < vmax)) return RAYRS_INVALID_ARG;  // geometry.rs:205-212
+    if (axis < 0 || axis > 5) return RAYRS_INVALID_ARG;
+    const int surf = objs->list.add_surface(mat, emission);
+    if (surf < 0) return surf;
+    Object o;
+    std::memset(&o, 0, sizeof(o));
+    o.geom.kind = PRIM_PLANE;
+    o.geom.axis = (uint32_t)axis;
+    o.geom.u0 = umin, o.geom.u1 = umax, o.geom.v0 = vmin, o.geom.v1 = vmax, o.geom.pos = pos;
+    o.surface = (uint32_t)surf;
+    objs->list.objs.push_back(o);
+    return RAYRS_OK;
+}
+
+int rayrs_object_triangle(rayrs_objects* objs, const double p1[3], const double p2[3], const double p3[3],
+                          const rayrs_material* mat, const rayrs_emission* emission) {
+    if (!objs || !p1 || !p2 || !p3) return RAYRS_INVALID_ARG;
+    const int surf = objs->list.add_surface(mat, emission);
+    if (surf < 0) return surf;
+    push_triangle(objs->list, {p1[0], p1[1], p1[2]}, {p2[0], p2[1], p2[2]}, {p3[0], p3[1], p3[2]}, (uint32_t)surf);
+    return RAYRS_OK;
+}
+
+int rayrs_object_from_triangles_f32(rayrs_objects* objs, const float* verts, uint32_t nverts, const uint32_t* idx,
+                                    uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission) {
+    return from_triangles<float>(objs, verts, nverts, idx, ntris, mat, emission);
+}
+
+int rayrs_object_from_triangles_f64(rayrs_objects* objs, const double* verts, uint32_t nverts, const uint32_t* idx,
+                                    uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission) {
+    return from_triangles<double>(objs, verts, nverts, idx, ntris, mat, emission);
+}
+
+int rayrs_object_from_spheres(rayrs_objects* objs, double radius, const double* centers, uint32_t n,
+                              const rayrs_material* mat, const rayrs_emission* emission) {
+    if (!objs || (!centers && n)) return RAYRS_INVALID_ARG;
+    for (uint32_t i = 0; i < n; i++) {
+        const int st = rayrs_object_sphere(objs, radius, centers + 3 * (size_t)i, mat, emission);
+        if (st != RAYRS_OK) return st;
+    }
+    return RAYRS_OK;
+}
+
+int rayrs_object_box_geom(rayrs_objects* objs, const double ll[3], const double ur[3], const rayrs_material* mat,
+                          const rayrs_emission* emission) {
+    if (!objs || !ll || !ur) return RAYRS_INVALID_ARG;
+    // lib.rs:444-505, same order (note: both Y faces sit at lower_left.y, as in the reference)
+    const struct {
+        int axis;
+        double u0, u1, v0, v1, pos;
+    } faces[6] = {
+        {RAYRS_AXIS_X, ll[1], ur[1], ll[2], ur[2], ll[0]},    {RAYRS_AXIS_XREV, ll[1], ur[1], ll[2], ur[2], ur[0]},
+        {RAYRS_AXIS_ZREV, ll[0], ur[0], ll[1], ur[1], ll[2]}, {RAYRS_AXIS_Z, ll[0], ur[0], ll[1], ur[1], ur[2]},
+        {RAYRS_AXIS_YREV, ll[0], ur[0], ll[2], ur[2], ll[1]}, {RAYRS_AXIS_Y, ll[0], ur[0], ll[2], ur[2], ll[1]},
+    };
+    for (const auto& f : faces) {
+        const int st = rayrs_object_plane(objs, f.axis, f.u0, f.u1, f.v0, f.v1, f.pos, mat, emission);
+        if (st != RAYRS_OK) return st;
+    }
+    return RAYRS_OK;
+}
+
+// ------------------------------------------------------------------- Scene
+
+static void scene_free_device(rayrs_scene* s) {
+    if (s->device < 0) return;
+    (void)hipSetDevice(s->device);
+    if (s->pending && s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_prims) (void)hipFree(s->d_prims);
+    if (s->d_surfaces) (void)hipFree(s->d_surfaces);
+    if (s->d_hdri) (void)hipFree(s->d_hdri);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_partial) (void)hipFree(s->d_partial);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+}
+
+void rayrs_scene_destroy(rayrs_scene* scene) {
+    if (!scene) return;
+    scene_free_device(scene);
+    delete scene;
+}
+
+static int scene_upload(rayrs_scene* s) {
+    HIP_TRY(hipSetDevice(s->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    s->cu_count = prop.multiProcessorCount;
+    const FlatScene& f = s->flat;
+    HIP_TRY(hipMalloc(&s->d_nodes, f.node_bytes.size()));
+    HIP_TRY(hipMemcpy(s->d_nodes, f.node_bytes.data(), f.node_bytes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
+    HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
+    HIP_TRY(hipMemcpy(s->d_surfaces, s->surfaces.data(), s->surfaces.size() * sizeof(SurfaceDev),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&s->d_hdri, f.hdri_rgba.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_rgba.data(), f.hdri_rgba.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
+    for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+                      f.hdri_rgba.size() * sizeof(float);
+    const uint32_t depth = f.depth ? f.depth : 1;
+    HIP_TRY(trace_occupancy(f.compact, depth, &s->blocks_per_cu));
+    if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    return RAYRS_OK;
+}
+
+int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int heuristic, uint32_t splits,
+                    uint32_t hdri_w, uint32_t hdri_h, const float* hdri_rgb, int device, rayrs_scene** out) {
+    if (!objs || !out) return RAYRS_INVALID_ARG;
+    *out = nullptr;
+    rayrs_scene* s = new (std::nothrow) rayrs_scene();
+    if (!s) return RAYRS_OOM;
+    int st = build_flat_scene(objs->list, z_near, z_far, heuristic, splits, hdri_w, hdri_h, hdri_rgb, &s->flat);
+    if (st != RAYRS_OK) {
+        delete s;
+        return st;
+    }
+    s->surfaces = objs->list.surfaces;
+    s->n_objects = objs->list.objs.size();
+    s->device = device;
+    if (device >= 0) {
+        if (s->flat.depth > MAX_STACK_DEPTH) {
+            delete s;
+            return RAYRS_UNSUPPORTED;
+        }
+        st = scene_upload(s);
+        if (st != RAYRS_OK) {
+            scene_free_device(s);
+            delete s;
+            return st;
+        }
+    }
+    *out = s;
+    return RAYRS_OK;
+}
+
+int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
+    if (!scene || !info) return RAYRS_INVALID_ARG;
+    const FlatScene& f = scene->flat;
+    std::memset(info, 0, sizeof(*info));
+    info->n_objects = scene->n_objects;
+    info->n_interior = f.n_interior();
+    info->n_prims = f.n_prims();
+    info->root_ref = f.root_ref;
+    info->depth = f.depth;
+    info->compact = f.compact ? 1u : 0u;
+    info->n_surfaces = (uint32_t)scene->surfaces.size();
+    info->node_bytes = f.compact ? (uint32_t)sizeof(NodeF32) : (uint32_t)sizeof(NodeF64);
+    info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
+    info->device_bytes = scene->device_bytes;
+    for (int i = 0; i < 6; i++) info->root_box[i] = f.root_box[i];
+    info->build_seconds = f.build_seconds;
+    return RAYRS_OK;
+}
+
+int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t* child_ref, uint32_t* prim_object) {
+    if (!scene) return RAYRS_INVALID_ARG;
+    const FlatScene& f = scene->flat;
+    if (child_box && !f.child_box.empty()) std::memcpy(child_box, f.child_box.data(), f.child_box.size() * 8);
+    if (child_ref && !f.child_ref.empty()) std::memcpy(child_ref, f.child_ref.data(), f.child_ref.size() * 4);
+    if (prim_object && !f.prim_object.empty())
+        std::memcpy(prim_object, f.prim_object.data(), f.prim_object.size() * 4);
+    return RAYRS_OK;
+}
+
+// ------------------------------------------------------------------ Camera
+
+int rayrs_camera_new(const double origin[3], const double up[3], const double lookat[3], double fov, double width,
+                     double height, uint32_t ppi, rayrs_camera* out) {
+    return camera_new(origin, up, lookat, fov, width, height, ppi, out);
+}
+
+// ------------------------------------------------------------------ render
+
+static SceneDev make_scene_dev(const rayrs_scene* s) {
+    SceneDev sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.nodes = s->d_nodes;
+    sc.prims = s->d_prims;
+    sc.surfaces = s->d_surfaces;
+    sc.hdri = s->d_hdri;
+    sc.hdri_w = s->flat.hdri_w;
+    sc.hdri_h = s->flat.hdri_h;
+    sc.root_ref = s->flat.root_ref;
+    sc.stack_depth = s->flat.depth ? s->flat.depth : 1;
+    for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
+    sc.t0 = s->flat.t0;
+    sc.t1 = s->flat.t1;
+    return sc;
+}
+
+static CameraDev make_camera_dev(const rayrs_camera* c) {
+    CameraDev cam;
+    std::memset(&cam, 0, sizeof(cam));
+    for (int i = 0; i < 3; i++) {
+        cam.origin[i] = c->origin[i];
+        cam.e_x[i] = c->e_x[i];
+        cam.e_y[i] = c->e_y[i];
+        cam.z[i] = c->z[i];
+    }
+    cam.width = c->width;
+    cam.height = c->height;
+    cam.ppc = (double)c->ppc;  // `self.ppc as f64`, lib.rs:206
+    cam.W = c->x_pixels;
+    cam.H = c->y_pixels;
+    return cam;
+}
+
+int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
+                        void* out_device, void* hip_stream) {
+    if (!scene || !camera || !params || !out_device) return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
+    if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
+    if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (scene->pending) {  // one render in flight per scene: its counters and partial sums are shared
+        HIP_TRY(hipStreamSynchronize(scene->last_stream));
+        scene->pending = false;
+    }
+
+    RenderDev rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.spp = params->spp;
+    rp.max_bounces = params->max_bounces;
+    rp.seed = params->seed;
+    rp.chunk = (params->sample_chunk == 0 || params->sample_chunk >= params->spp) ? params->spp : params->sample_chunk;
+    rp.nchunks = (rp.spp + rp.chunk - 1) / rp.chunk;
+    rp.tile_rank = params->tile_rank;
+    rp.tile_ranks = params->tile_ranks;
+    rp.tiles_x = (camera->x_pixels + 7) / 8;
+    rp.tiles_y = (camera->y_pixels + 7) / 8;
+    const uint64_t n_tiles = (uint64_t)rp.tiles_x * rp.tiles_y;
+    const uint64_t n_local = n_tiles > rp.tile_rank ? (n_tiles - rp.tile_rank + rp.tile_ranks - 1) / rp.tile_ranks : 0;
+    rp.n_local_tiles = (uint32_t)n_local;
+    rp.total_items = n_local * rp.nchunks * 64ull;
+    if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
+    rp.out_format = params->out_format;
+    rp.out = out_device;
+    rp.counters = scene->d_counters;
+
+    if (rp.total_items > scene->partial_items) {
+        if (scene->d_partial) HIP_TRY(hipFree(scene->d_partial));
+        scene->d_partial = nullptr;
+        scene->partial_items = 0;
+        HIP_TRY(hipMalloc((void**)&scene->d_partial, (size_t)rp.total_items * 3 * sizeof(double)));
+        scene->partial_items = (size_t)rp.total_items;
+    }
+    rp.partial = scene->d_partial;
+
+    const SceneDev sc = make_scene_dev(scene);
+    const CameraDev cam = make_camera_dev(camera);
+
+    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
+    HIP_TRY(hipEventRecord(scene->ev[0], stream));
+    if (rp.total_items > 0) {
+        const uint64_t wanted = (rp.total_items / 64 + 3) / 4;
+        uint64_t resident = (uint64_t)scene->cu_count * (uint64_t)scene->blocks_per_cu;
+        if (resident < 1) resident = 1;
+        const uint32_t blocks = (uint32_t)(wanted < resident ? wanted : resident);
+        HIP_TRY(launch_trace(scene->flat.compact, params->count_work != 0, sc, cam, rp, blocks, stream));
+    }
+    HIP_TRY(hipEventRecord(scene->ev[1], stream));
+    HIP_TRY(launch_resolve(cam, rp, stream));
+    HIP_TRY(hipEventRecord(scene->ev[2], stream));
+    scene->last_stream = stream;
+    scene->pending = true;
+    scene->last_count = params->count_work != 0;
+    return RAYRS_OK;
+}
+
+int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
+    if (!scene) return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    if (!scene->pending) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipEventSynchronize(scene->ev[2]));
+    scene->pending = false;
+    if (stats) {
+        Counters c;
+        HIP_TRY(hipMemcpy(&c, scene->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays = c.rays;
+        stats->paths = c.paths;
+        stats->nan_pixels = c.nan_pixels;
+        stats->neg_pixels = c.neg_pixels;
+        stats->interior_visits = c.interior_visits;
+        stats->tri_tests = c.tri_tests;
+        stats->sphere_tests = c.sphere_tests;
+        stats->plane_tests = c.plane_tests;
+        stats->escaped_paths = c.escaped_paths;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
+        stats->kernel_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[2]));
+        stats->total_ms = ms;
+    }
+    return RAYRS_OK;
+}
+
+int rayrs_render(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params, void* out_host,
+                 rayrs_render_stats* stats) {
+    if (!scene || !camera || !params || !out_host) return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t elem = params->out_format == RAYRS_OUT_F64 ? 8 : 4;
+    const size_t bytes = (size_t)camera->x_pixels * camera->y_pixels * 3 * elem;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, bytes));
+    // pixels of other ranks' tiles keep the caller's values
+    hipError_t e = hipMemcpy(d_out, out_host, bytes, hipMemcpyHostToDevice);
+    int st = e == hipSuccess ? RAYRS_OK : hip_fail(e, "hipMemcpy(out H2D)");
+    if (st == RAYRS_OK) st = rayrs_render_launch(scene, camera, params, d_out, nullptr);
+    if (st == RAYRS_OK) st = rayrs_render_finish(scene, stats);
+    if (st == RAYRS_OK) {
+        e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = hip_fail(e, "hipMemcpy(out D2H)");
+    }
+    (void)hipFree(d_out);
+    return st;
+}
+
+// ------------------------------------------------------------- self tests
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        return e == hipSuccess ? RAYRS_OK : hip_fail(e, "hipMalloc");
+    }
+    int upload(const void* src, size_t bytes) {
+        int st = alloc(bytes);
+        if (st != RAYRS_OK) return st;
+        if (!bytes) return RAYRS_OK;
+        hipError_t e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+        return e == hipSuccess ? RAYRS_OK : hip_fail(e, "hipMemcpy H2D");
+    }
+    int download(void* dst, size_t bytes) {
+        if (!bytes) return RAYRS_OK;
+        hipError_t e = hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost);
+        return e == hipSuccess ? RAYRS_OK : hip_fail(e, "hipMemcpy D2H");
+    }
+};
+#define ST_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != RAYRS_OK) return _s; \
+    } while (0)
+}  // namespace
+
+int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out) {
+    if (!x || !out) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dx, dy, dout;
+    ST_TRY(dx.upload(x, n * 8));
+    if (y) ST_TRY(dy.upload(y, n * 8));
+    ST_TRY(dout.alloc(n * 8));
+    if (n) HIP_TRY(launch_test_math(fn, (const double*)dx.p, y ? (const double*)dy.p : nullptr, n, (double*)dout.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.download(out, n * 8);
+}
+
+int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
+                   uint64_t n, uint64_t* out_bits) {
+    if (!pixel || !sample || !draw || !out_bits) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dp, ds, dd, dout;
+    ST_TRY(dp.upload(pixel, n * 8));
+    ST_TRY(ds.upload(sample, n * 8));
+    ST_TRY(dd.upload(draw, n * 4));
+    ST_TRY(dout.alloc(n * 8));
+    if (n)
+        HIP_TRY(launch_test_rng(seed, (const uint64_t*)dp.p, (const uint64_t*)ds.p, (const uint32_t*)dd.p, n,
+                                (uint64_t*)dout.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.download(out_bits, n * 8);
+}
+
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, double* t, int64_t* object) {
+    if (!scene || !o || !d || !t || !object) return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    HIP_TRY(hipSetDevice(scene->device));
+    DevBuf dorg, ddir, dt, dprim;
+    ST_TRY(dorg.upload(o, n * 24));
+    ST_TRY(ddir.upload(d, n * 24));
+    ST_TRY(dt.alloc(n * 8));
+    ST_TRY(dprim.alloc(n * 8));
+    const SceneDev sc = make_scene_dev(scene);
+    if (n)
+        HIP_TRY(launch_test_intersect(scene->flat.compact, sc, (const double*)dorg.p, (const double*)ddir.p, n,
+                                      (double*)dt.p, (long long*)dprim.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    ST_TRY(dt.download(t, n * 8));
+    ST_TRY(dprim.download(object, n * 8));
+    for (uint64_t i = 0; i < n; i++)  // DFS slot -> object index in insertion order
+        if (object[i] >= 0) object[i] = (int64_t)scene->flat.prim_object[(size_t)object[i]];
+    return RAYRS_OK;
+}
+
+int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
+                        const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
+                        uint32_t* draws) {
+    if (!mat || !normal || !view || !key || !scattered || !color || !dir || !draws) return RAYRS_INVALID_ARG;
+    ObjectList tmp;
+    const int surf = tmp.add_surface(mat, nullptr);
+    if (surf < 0) return surf;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf ds, dn, dv, dk, dsc, dc, dd, ddr;
+    ST_TRY(ds.upload(&tmp.surfaces[0], sizeof(SurfaceDev)));
+    ST_TRY(dn.upload(normal, n * 24));
+    ST_TRY(dv.upload(view, n * 24));
+    ST_TRY(dk.upload(key, n * 8));
+    ST_TRY(dsc.alloc(n * 4));
+    ST_TRY(dc.alloc(n * 24));
+    ST_TRY(dd.alloc(n * 24));
+    ST_TRY(ddr.alloc(n * 4));
+    if (n)
+        HIP_TRY(launch_test_material((const SurfaceDev*)ds.p, (const double*)dn.p, (const double*)dv.p,
+                                     (const uint64_t*)dk.p, n, (int32_t*)dsc.p, (double*)dc.p, (double*)dd.p,
+                                     (uint32_t*)ddr.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    ST_TRY(dsc.download(scattered, n * 4));
+    ST_TRY(dc.download(color, n * 24));
+    ST_TRY(dd.download(dir, n * 24));
+    return ddr.download(draws, n * 4);
+}
+
+int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb) {
+    if (!scene || !dir || !rgb) return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    HIP_TRY(hipSetDevice(scene->device));
+    DevBuf dd, dout;
+    ST_TRY(dd.upload(dir, n * 24));
+    ST_TRY(dout.alloc(n * 24));
+    const SceneDev sc = make_scene_dev(scene);
+    if (n) HIP_TRY(launch_test_background(sc, (const double*)dd.p, n, (double*)dout.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.download(rgb, n * 24);
+}
+
+}  // extern "C"

@@ -1,0 +1,676 @@
+// device_path.h -- gfx950 device functions of the radiance integrator.
+//
+// One lane traces one path.  All arithmetic is f64 in the reference's operator
+// order (no contraction: the translation unit is built with -ffp-contract=off);
+// elementary functions and the RNG come from include/rayrs_numeric.h so that the
+// CPU checker, which compiles the same header, sees the same bits.
+//
+// Reference items restated here (paths relative to rayrs-lib/src):
+//   vecmath.rs:341-352, :513-806   vector helpers
+//   geometry.rs:106-136, :229-282, :359-379, :458-513   shapes, AABB slab test
+//   bvh.rs:40-73, :391-415         closest hit (first leaf in DFS order wins ties)
+//   material.rs:91-109, :259-593, :721-812, :903-1046, :1132-1161, :1189-1231,
+//               :1233-1518         materials
+//   lib.rs:202-210, :254-285, :521-560   primary ray, background, radiance
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rayrs_hip.h"
+#include "../../include/rayrs_numeric.h"
+#include "layout.h"
+
+namespace rayrs {
+
+#define RR_DEV __device__ __forceinline__
+
+struct V3 {
+    double x, y, z;
+};
+
+RR_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+RR_DEV V3 v_add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RR_DEV V3 v_sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RR_DEV V3 v_mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RR_DEV V3 v_scale(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+RR_DEV V3 v_div(V3 a, double s) {  // Div<f64>: multiply by the reciprocal, vecmath.rs:690-698
+    const double inv = 1.0 / s;
+    return v_scale(a, inv);
+}
+RR_DEV double v_dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RR_DEV V3 v_cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RR_DEV double v_mag2(V3 a) { return v_dot(a, a); }
+RR_DEV V3 v_unit(V3 a) { return v_div(a, rr_sqrt(v_mag2(a))); }
+RR_DEV bool v_is_zeros(V3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
+
+RR_DEV void v_onb(V3 n, V3& e1, V3& e2) {  // vecmath.rs:341-352
+    if (rr_fabs(n.x) > rr_fabs(n.y))
+        e1 = v_unit(mk(n.z, 0.0, -n.x));
+    else
+        e1 = v_unit(mk(0.0, n.z, -n.y));
+    e2 = v_unit(v_cross(n, e1));
+}
+
+// powi(4) / powi(5) as LLVM expands them for a constant exponent
+RR_DEV double pow4(double x) {
+    const double x2 = x * x;
+    return x2 * x2;
+}
+RR_DEV double pow5(double x) {
+    const double x2 = x * x;
+    return x * (x2 * x2);
+}
+
+struct Rng {
+    uint64_t key;
+    uint32_t draw;
+    RR_DEV double next() { return rr_uniform(key, draw++); }
+};
+
+// ------------------------------------------------------------------ records
+
+RR_DEV double f64_from(uint32_t lo, uint32_t hi) { return rr_bits_f64(((uint64_t)hi << 32) | lo); }
+
+template <bool COMPACT>
+struct PrimRec {
+    // enough dwords for either layout; only the first 12 (compact) or 20 (full) are loaded
+    uint4 q[COMPACT ? 3 : 5];
+    RR_DEV uint32_t tag() const { return COMPACT ? q[2].w : q[4].w; }
+    RR_DEV uint32_t dw(int i) const {
+        const uint4& v = q[i >> 2];
+        switch (i & 3) {
+            case 0: return v.x;
+            case 1: return v.y;
+            case 2: return v.z;
+            default: return v.w;
+        }
+    }
+    RR_DEV double f64_at(int i) const { return f64_from(dw(2 * i), dw(2 * i + 1)); }  // i-th double of the payload
+    RR_DEV double tri_coord(int i) const {  // i-th of p1.xyz p2.xyz p3.xyz
+        if (COMPACT) return (double)__uint_as_float(dw(i));
+        return f64_at(i);
+    }
+};
+
+template <bool COMPACT>
+RR_DEV PrimRec<COMPACT> load_prim(const void* prims, uint32_t p) {
+    PrimRec<COMPACT> r;
+    const uint4* src = reinterpret_cast<const uint4*>(prims) + (size_t)p * (COMPACT ? 3 : 5);
+#pragma unroll
+    for (int i = 0; i < (COMPACT ? 3 : 5); i++) r.q[i] = src[i];
+    return r;
+}
+
+// --------------------------------------------------------------- primitives
+
+// Sphere::intersect, geometry.rs:106-132
+RR_DEV bool sphere_intersect(double radius2, V3 c, V3 o, V3 d, double& t) {
+    const V3 odiff = v_sub(o, c);
+    const double a = v_mag2(d);
+    const double b = 2.0 * v_dot(d, odiff);
+    const double cc = v_mag2(odiff) - radius2;
+    const double desc = b * b - 4.0 * a * cc;
+    if (desc > 0.0) {
+        const double sq = rr_sqrt(desc);
+        const double t1 = (-b - sq) / (2.0 * a);
+        const double t2 = (-b + sq) / (2.0 * a);
+        if (t1 < 0.0) {
+            if (t2 < 0.0) return false;
+            t = t2;
+            return true;
+        }
+        t = t1;
+        return true;
+    }
+    return false;
+}
+
+RR_DEV bool range_contains(double start, double end, double x) { return start <= x && x < end; }
+
+// Plane::intersect, geometry.rs:229-271
+RR_DEV bool plane_intersect(uint32_t axis, double u0, double u1, double v0, double v1, double pos, V3 o, V3 d,
+                            double& t) {
+    const uint32_t ax = axis >> 1;  // 0 X, 1 Y, 2 Z
+    const double dn = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+    const double on = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+    if (dn != 0.0) {
+        const double tt = (pos - on) / dn;
+        const V3 p = v_add(o, v_scale(d, tt));
+        const double pu = ax == 0 ? p.y : p.x;
+        const double pv = ax == 2 ? p.y : p.z;
+        if (range_contains(u0, u1, pu) && range_contains(v0, v1, pv)) {
+            t = tt;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Triangle::intersect, geometry.rs:359-375, with e1/e2 formed as Triangle::new does (:342-343)
+RR_DEV bool triangle_intersect(V3 p1, V3 p2, V3 p3, V3 o, V3 d, double& t) {
+    const V3 e1 = v_sub(p2, p1);
+    const V3 e2 = v_sub(p3, p1);
+    const V3 tt = v_sub(o, p1);
+    const V3 p = v_cross(d, e2);
+    const V3 q = v_cross(tt, e1);
+    const double den = v_dot(p, e1);
+    const double dd = v_dot(q, e2) / den;
+    const double u = v_dot(p, tt) / den;
+    const double v = v_dot(q, d) / den;
+    if (dd < 0.0 || u < 0.0 || v < 0.0 || u + v > 1.0) return false;
+    t = dd;
+    return true;
+}
+
+template <bool COMPACT>
+RR_DEV bool prim_intersect(const PrimRec<COMPACT>& r, V3 o, V3 d, double& t) {
+    const uint32_t tag = r.tag();
+    const uint32_t kind = tag & 3u;
+    if (kind == PRIM_TRIANGLE) {
+        const V3 p1 = mk(r.tri_coord(0), r.tri_coord(1), r.tri_coord(2));
+        const V3 p2 = mk(r.tri_coord(3), r.tri_coord(4), r.tri_coord(5));
+        const V3 p3 = mk(r.tri_coord(6), r.tri_coord(7), r.tri_coord(8));
+        return triangle_intersect(p1, p2, p3, o, d, t);
+    } else if (kind == PRIM_SPHERE) {
+        return sphere_intersect(r.f64_at(0), mk(r.f64_at(1), r.f64_at(2), r.f64_at(3)), o, d, t);
+    } else {
+        return plane_intersect((tag >> 2) & 7u, r.f64_at(0), r.f64_at(1), r.f64_at(2), r.f64_at(3), r.f64_at(4), o, d,
+                               t);
+    }
+}
+
+// Hittable::normal: geometry.rs:134-136, :273-282, :377-379 (+ Triangle::new :344-351)
+template <bool COMPACT>
+RR_DEV V3 prim_normal(const PrimRec<COMPACT>& r, V3 position) {
+    const uint32_t tag = r.tag();
+    const uint32_t kind = tag & 3u;
+    if (kind == PRIM_TRIANGLE) {
+        const V3 p1 = mk(r.tri_coord(0), r.tri_coord(1), r.tri_coord(2));
+        const V3 p2 = mk(r.tri_coord(3), r.tri_coord(4), r.tri_coord(5));
+        const V3 p3 = mk(r.tri_coord(6), r.tri_coord(7), r.tri_coord(8));
+        return v_unit(v_cross(v_sub(p2, p1), v_sub(p3, p1)));
+    } else if (kind == PRIM_SPHERE) {
+        return v_unit(v_sub(position, mk(r.f64_at(1), r.f64_at(2), r.f64_at(3))));
+    } else {
+        const uint32_t axis = (tag >> 2) & 7u;
+        const double s = (axis & 1u) ? -1.0 : 1.0;
+        const uint32_t ax = axis >> 1;
+        return mk(ax == 0 ? s : 0.0, ax == 1 ? s : 0.0, ax == 2 ? s : 0.0);
+    }
+}
+
+// ---------------------------------------------------------------- traversal
+
+// AxisAlignedBoundingBox::intersect (geometry.rs:458-513) with 1/dir hoisted
+// (the reference recomputes the same quotient at every node).  tmin only grows
+// and tmax only shrinks, so the single final compare equals the three
+// early-outs.  `entry` is the slab entry parameter used for ordering/culling.
+RR_DEV bool slab(double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, V3 o, V3 inv,
+                 double tmin, double tmax, double& entry) {
+    double lo = xmin - o.x, hi = xmax - o.x;
+    double t0 = inv.x < 0.0 ? hi * inv.x : lo * inv.x;
+    double t1 = inv.x < 0.0 ? lo * inv.x : hi * inv.x;
+    tmin = rr_max(tmin, t0);
+    tmax = rr_min(tmax, t1);
+    lo = ymin - o.y, hi = ymax - o.y;
+    t0 = inv.y < 0.0 ? hi * inv.y : lo * inv.y;
+    t1 = inv.y < 0.0 ? lo * inv.y : hi * inv.y;
+    tmin = rr_max(tmin, t0);
+    tmax = rr_min(tmax, t1);
+    lo = zmin - o.z, hi = zmax - o.z;
+    t0 = inv.z < 0.0 ? hi * inv.z : lo * inv.z;
+    t1 = inv.z < 0.0 ? lo * inv.z : hi * inv.z;
+    tmin = rr_max(tmin, t0);
+    tmax = rr_min(tmax, t1);
+    entry = tmin;
+    return !(tmax <= tmin);
+}
+
+struct WorkCount {
+    uint32_t interior, tri, sphere, plane;
+};
+
+// Bvh::intersect (bvh.rs:212-214, :391-415).  Children are tested at the parent,
+// the nearer one is entered first and the farther one pushed on the lane's LDS
+// stack (entry k of lane l lives at stack[k * 64]); boxes entered beyond the
+// closest hit so far are skipped.  The answer is the reference's: smallest
+// accepted t, lowest DFS index on exact ties.
+template <bool COMPACT, bool COUNT>
+RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, double& t_hit, uint32_t& prim_hit,
+                          WorkCount& wc) {
+    const double tmin = sc.t0, tmax = sc.t1;
+    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double entry;
+    if (!slab(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, inv,
+              tmin, tmax, entry))
+        return false;
+    bool found = false;
+    double best_t = tmax;
+    uint32_t best_prim = 0xffffffffu;
+    int sp = 0;
+    uint32_t cur = sc.root_ref;
+    for (;;) {
+        if ((cur >> 30) == REF_INTERIOR) {
+            const uint32_t rec = cur & 0x3fffffffu;
+            if (COUNT) wc.interior++;
+            double b0[6], b1[6];
+            uint32_t r0, r1;
+            if (COMPACT) {
+                const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 4;
+                const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
+                b0[0] = (double)__uint_as_float(a.x), b0[1] = (double)__uint_as_float(a.y);
+                b0[2] = (double)__uint_as_float(a.z), b0[3] = (double)__uint_as_float(a.w);
+                b0[4] = (double)__uint_as_float(b.x), b0[5] = (double)__uint_as_float(b.y);
+                b1[0] = (double)__uint_as_float(b.z), b1[1] = (double)__uint_as_float(b.w);
+                b1[2] = (double)__uint_as_float(c.x), b1[3] = (double)__uint_as_float(c.y);
+                b1[4] = (double)__uint_as_float(c.z), b1[5] = (double)__uint_as_float(c.w);
+                r0 = e.x, r1 = e.y;
+            } else {
+                const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
+                const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6];
+                b0[0] = f64_from(q0.x, q0.y), b0[1] = f64_from(q0.z, q0.w);
+                b0[2] = f64_from(q1.x, q1.y), b0[3] = f64_from(q1.z, q1.w);
+                b0[4] = f64_from(q2.x, q2.y), b0[5] = f64_from(q2.z, q2.w);
+                b1[0] = f64_from(q3.x, q3.y), b1[1] = f64_from(q3.z, q3.w);
+                b1[2] = f64_from(q4.x, q4.y), b1[3] = f64_from(q4.z, q4.w);
+                b1[4] = f64_from(q5.x, q5.y), b1[5] = f64_from(q5.z, q5.w);
+                r0 = q6.x, r1 = q6.y;
+            }
+            double e0 = tmin, e1 = tmin;
+            bool h0 = true, h1 = true;
+            if ((r0 >> 30) != REF_SINGLE) {
+                h0 = slab(b0[0], b0[1], b0[2], b0[3], b0[4], b0[5], o, inv, tmin, tmax, e0);
+                if (e0 > best_t) h0 = false;
+            }
+            if ((r1 >> 30) != REF_SINGLE) {
+                h1 = slab(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5], o, inv, tmin, tmax, e1);
+                if (e1 > best_t) h1 = false;
+            }
+            if (h0 && h1) {
+                const bool swap = e1 < e0;
+                stack[sp * 64] = swap ? r0 : r1;
+                sp++;
+                cur = swap ? r1 : r0;
+                continue;
+            } else if (h0) {
+                cur = r0;
+                continue;
+            } else if (h1) {
+                cur = r1;
+                continue;
+            }
+        } else {
+            const uint32_t first = (cur & 0x3fffffffu) >> 2;
+            const uint32_t count = (cur & 3u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const uint32_t p = first + k;
+                const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
+                if (COUNT) {
+                    const uint32_t kind = r.tag() & 3u;
+                    if (kind == PRIM_TRIANGLE) wc.tri++;
+                    else if (kind == PRIM_SPHERE) wc.sphere++;
+                    else wc.plane++;
+                }
+                double t;
+                if (prim_intersect<COMPACT>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
+                    if (!found || t < best_t || (t == best_t && p < best_prim)) {  // bvh.rs:62
+                        found = true;
+                        best_t = t;
+                        best_prim = p;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * 64];
+    }
+    t_hit = best_t;
+    prim_hit = best_prim;
+    return found;
+}
+
+// ---------------------------------------------------------------- materials
+
+struct CtLayer {  // struct CookTorrance, material.rs:194-200
+    double alpha2;
+    int metallic;
+    double ior;
+    V3 r0;
+    V3 color;
+};
+
+RR_DEV CtLayer load_ct(const SurfaceDev* s) {
+    CtLayer ct;
+    ct.alpha2 = s->ct_alpha2;
+    ct.metallic = s->metallic;
+    ct.ior = s->ct_ior;
+    ct.r0 = mk(s->ct_r0[0], s->ct_r0[1], s->ct_r0[2]);
+    ct.color = mk(s->ct_color[0], s->ct_color[1], s->ct_color[2]);
+    return ct;
+}
+
+RR_DEV double dir_ior_ratio(bool entering, double ior) { return entering ? 1.0 / ior : ior; }  // :1200-1205
+RR_DEV V3 dir_normal(bool entering, V3 n) { return entering ? n : v_scale(n, -1.0); }          // :1215-1220
+
+RR_DEV double schlick_scalar(double ior_curr, double ior_new, V3 n, V3 v) {  // :1472-1479
+    double r0 = (ior_curr - ior_new) / (ior_curr + ior_new);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * pow5(1.0 - v_dot(n, v));
+}
+RR_DEV V3 schlick_vec(V3 r0, V3 n, V3 v) {  // :1484-1489
+    const double p = pow5(1.0 - v_dot(n, v));
+    return v_add(r0, v_scale(v_sub(mk(1.0, 1.0, 1.0), r0), p));
+}
+RR_DEV V3 reflect(V3 n, V3 v) { return v_sub(v_scale(n, 2.0 * v_dot(v, n)), v); }  // :1492-1496
+RR_DEV bool refract(V3 n, V3 v, double ior_ratio, V3& out) {                         // :1502-1518
+    const double cos_theta = v_dot(v, n);
+    const double sin_theta = rr_sqrt(1.0 - cos_theta * cos_theta);
+    if (ior_ratio * sin_theta > 1.0) return false;
+    const V3 par = v_scale(v_sub(v_scale(n, cos_theta), v), ior_ratio);
+    const V3 perp = v_scale(n, -rr_sqrt(1.0 - v_mag2(par)));
+    out = v_add(perp, par);
+    return true;
+}
+
+RR_DEV V3 fresnel_value(const CtLayer& ct, V3 n, V3 v, bool entering) {  // :1457-1469
+    if (!ct.metallic) {
+        const double f = entering ? schlick_scalar(1.0, ct.ior, n, v) : schlick_scalar(ct.ior, 1.0, n, v);
+        return mk(f, f, f);
+    }
+    return schlick_vec(ct.r0, n, v);
+}
+
+RR_DEV double beckmann_from_tan(double tan_theta_h, double alpha2, double nh) {  // :940, :1310, :1414
+    return rr_exp(-tan_theta_h * tan_theta_h / alpha2) / (RR_PI * alpha2 * pow4(nh));
+}
+
+RR_DEV V3 ct_brdf(const CtLayer& ct, V3 n, V3 l, V3 v) {  // :1276-1322
+    const double nv = rr_fabs(v_dot(n, v));
+    const double nl = rr_fabs(v_dot(n, l));
+    V3 h = v_add(v, l);
+    if (nv == 0.0 || nl == 0.0) return mk(0, 0, 0);
+    if (v_is_zeros(h)) return mk(0, 0, 0);
+    h = v_unit(h);
+    const double nh = v_dot(n, h);
+    const double tan_theta_h = rr_tan(rr_acos(nh));
+    if (__builtin_isinf(tan_theta_h)) return mk(0, 0, 0);
+    const double beckmann = beckmann_from_tan(tan_theta_h, ct.alpha2, nh);
+    const double hv = v_dot(h, v);
+    const double g = rr_min(2.0 * nh * nv / hv, rr_min(2.0 * nh * nl / hv, 1.0));
+    const V3 f = fresnel_value(ct, h, v, true);
+    V3 r = v_mul(ct.color, f);
+    r = v_scale(r, beckmann);
+    r = v_scale(r, g);
+    return v_div(r, 4.0 * nv * nl);
+}
+
+RR_DEV V3 ct_btdf(const CtLayer& ct, V3 n, V3 l, V3 v, bool entering) {  // :1362-1442
+    const double nv = rr_fabs(v_dot(n, v));
+    const double nl = rr_fabs(v_dot(n, l));
+    const double ior_ratio = dir_ior_ratio(entering, ct.ior);
+    V3 h;
+    if (ior_ratio > 1.0)
+        h = v_add(l, v_scale(v, ior_ratio));
+    else
+        h = v_sub(v_scale(v, -ior_ratio), l);
+    if (nv == 0.0 || nl == 0.0) return mk(0, 0, 0);
+    if (v_is_zeros(h)) return mk(0, 0, 0);
+    h = v_unit(h);
+    const double nh = v_dot(n, h);
+    const double tan_theta_h = rr_tan(rr_acos(nh));
+    if (__builtin_isinf(tan_theta_h)) return mk(0, 0, 0);
+    const double beckmann = beckmann_from_tan(tan_theta_h, ct.alpha2, nh);
+    const double hl = rr_fabs(v_dot(h, l));
+    const double hv = rr_fabs(v_dot(h, v));
+    const double g = rr_min(2.0 * nh * nv / hv, rr_min(2.0 * nh * nl / hv, 1.0));
+    double denom = ior_ratio * hv + hl;
+    denom = denom * denom;
+    const double norm_fac = hv * hl / (nv * nl);
+    const V3 f = fresnel_value(ct, h, v, entering);
+    V3 r = v_mul(ct.color, v_sub(mk(1.0, 1.0, 1.0), f));
+    r = v_scale(r, beckmann);
+    r = v_scale(r, g);
+    r = v_scale(r, norm_fac);
+    r = v_scale(r, ior_ratio);
+    r = v_scale(r, ior_ratio);
+    return v_div(r, denom);
+}
+
+RR_DEV double pdf_beckmann_reflect_value(double alpha2, V3 n, V3 l, V3 v) {  // :915-941
+    V3 h = v_add(l, v);
+    if (v_is_zeros(h)) return 1.0;
+    h = v_unit(h);
+    const double nh = rr_fabs(v_dot(n, h));
+    const double tan_theta_h = rr_tan(rr_acos(nh));
+    if (__builtin_isinf(tan_theta_h)) return 1.0;
+    return beckmann_from_tan(tan_theta_h, alpha2, nh);
+}
+
+// Pdf::Beckmann.generate (:1006-1020) / MicrofacetDistribution::generate (:1139-1161)
+template <bool WITH_VALUE>
+RR_DEV V3 beckmann_generate(double alpha2, V3 n, Rng& rng, double& value) {
+    V3 e1, e2;
+    v_onb(n, e1, e2);
+    const double phi = 2.0 * RR_PI * rng.next();
+    const double tan2theta = -alpha2 * rr_log(1.0 - rng.next());
+    const double costheta = 1.0 / rr_sqrt(1.0 + tan2theta);
+    const double sintheta = rr_sqrt(1.0 - costheta * costheta);
+    double sp, cp;
+    rr_sincos(phi, &sp, &cp);
+    const double x = cp * sintheta;
+    const double y = sp * sintheta;
+    const V3 h = v_add(v_add(v_scale(e1, x), v_scale(e2, y)), v_scale(n, costheta));
+    if (WITH_VALUE) {
+        const double nh = v_dot(n, h);
+        value = rr_exp(-tan2theta / alpha2) / (RR_PI * alpha2 * pow4(nh));
+    }
+    return h;
+}
+
+struct Scatter {
+    bool scatter;
+    V3 color;
+    V3 dir;
+};
+
+RR_DEV Scatter no_scatter() { return Scatter{false, mk(0, 0, 0), mk(0, 0, 0)}; }
+
+RR_DEV Scatter ct_evaluate_reflection(const CtLayer& ct, V3 n, V3 h, V3 v, V3 l, double pdf) {  // :721-758
+    if (v_dot(h, v) < 0.0) return no_scatter();
+    const double nl = v_dot(n, l);
+    if (nl < 0.0) return no_scatter();
+    const double frac_dwh_dwi = 4.0 * v_dot(h, l);
+    V3 color = v_scale(ct_brdf(ct, n, l, v), nl);
+    color = v_scale(v_div(color, pdf), frac_dwh_dwi);
+    if (v_is_zeros(color)) return no_scatter();
+    return Scatter{true, color, l};
+}
+
+RR_DEV Scatter ct_evaluate_refraction(const CtLayer& ct, V3 n, V3 h, V3 v, V3 l, double pdf, bool entering,
+                                      double ior_ratio) {  // :764-812
+    if (v_dot(h, v) < 0.0) return no_scatter();
+    const double nl = v_dot(n, l);
+    if (nl > 0.0) return no_scatter();
+    const double hl = rr_fabs(v_dot(h, l));
+    const double hv = rr_fabs(v_dot(h, v));
+    double denom = ior_ratio * hv + hl;
+    denom = denom * denom;
+    const double dwh_dwi = hl / denom;
+    V3 color = v_div(v_scale(ct_btdf(ct, n, l, v, entering), rr_fabs(nl)), ior_ratio * ior_ratio);
+    color = v_div(color, pdf * dwh_dwi);
+    if (v_is_zeros(color)) return no_scatter();
+    return Scatter{true, color, l};
+}
+
+RR_DEV Scatter lambertian_scatter(V3 color_in, V3 n, Rng& rng) {  // :259-281, :982-993, :1233-1243
+    V3 e1, e2;
+    v_onb(n, e1, e2);
+    const double u = rng.next();
+    const double phi = 2.0 * RR_PI * rng.next();
+    const double su = rr_sqrt(u);
+    double sp, cp;
+    rr_sincos(phi, &sp, &cp);
+    const double x = cp * su;
+    const double y = sp * su;
+    const double z = rr_sqrt(1.0 - u);
+    const V3 l = v_add(v_add(v_scale(e1, x), v_scale(e2, y)), v_scale(n, z));
+    const double ndl = v_dot(n, l);
+    const V3 brdf = v_scale(color_in, RR_FRAC_1_PI);
+    const V3 color = v_div(v_scale(brdf, ndl), ndl * RR_FRAC_1_PI);
+    return Scatter{true, color, l};
+}
+
+RR_DEV Scatter ct_scatter(const CtLayer& ct, V3 n, V3 v, Rng& rng) {  // :403-424
+    double unused;
+    const V3 h = beckmann_generate<false>(ct.alpha2, n, rng, unused);
+    const V3 l = reflect(h, v);
+    return ct_evaluate_reflection(ct, n, h, v, l, pdf_beckmann_reflect_value(ct.alpha2, n, l, v));
+}
+
+RR_DEV V3 reflect_brdf(V3 color, V3 n, V3 l) { return v_div(color, rr_fabs(v_dot(n, l))); }  // :1254-1265
+RR_DEV V3 refract_btdf(V3 color, V3 n, V3 l, V3 v) {                                          // :1333-1351
+    if (v_dot(l, v) > 0.0) return mk(0, 0, 0);
+    return v_div(color, rr_fabs(v_dot(n, l)));
+}
+
+// Material::evaluate, material.rs:91-109
+RR_DEV Scatter material_evaluate(const SurfaceDev* s, V3 n, V3 v, Rng& rng) {
+    const int kind = s->kind;
+    const V3 color = mk(s->color[0], s->color[1], s->color[2]);
+    switch (kind) {
+        case RAYRS_MAT_LAMBERTIAN: return lambertian_scatter(color, n, rng);
+        case RAYRS_MAT_REFLECT: {  // :283-301 (pdf.value == 1: x / 1. is exact)
+            const V3 l = reflect(n, v);
+            return Scatter{true, v_scale(reflect_brdf(color, n, l), v_dot(n, l)), l};
+        }
+        case RAYRS_MAT_REFRACT: {  // :303-337
+            const bool entering = v_dot(n, v) > 0.0;
+            const V3 nf = dir_normal(entering, n);
+            V3 l;
+            if (!refract(nf, v, dir_ior_ratio(entering, s->ior), l)) return no_scatter();
+            return Scatter{true, v_scale(refract_btdf(color, nf, l, v), rr_fabs(v_dot(nf, l))), l};
+        }
+        case RAYRS_MAT_GLASS: {  // :339-401
+            const double cos_theta = v_dot(n, v);
+            const bool entering = cos_theta > 0.0;
+            const V3 nf = dir_normal(entering, n);
+            const double sin2theta = 1.0 - cos_theta * cos_theta;
+            const double ior_ratio = dir_ior_ratio(entering, s->ior);
+            bool do_reflect = ior_ratio * ior_ratio * sin2theta >= 1.0;
+            if (!do_reflect) {
+                const double fresnel =
+                    entering ? schlick_scalar(1.0, s->ior, nf, v) : schlick_scalar(s->ior, 1.0, nf, v);
+                do_reflect = rng.next() < fresnel;
+            }
+            if (do_reflect) {
+                const V3 l = reflect(nf, v);
+                return Scatter{true, v_scale(reflect_brdf(color, nf, l), v_dot(nf, l)), l};
+            }
+            V3 l;
+            if (!refract(nf, v, ior_ratio, l)) return no_scatter();  // .unwrap()
+            return Scatter{true, v_scale(refract_btdf(color, nf, l, v), rr_fabs(v_dot(nf, l))), l};
+        }
+        case RAYRS_MAT_COOK_TORRANCE: return ct_scatter(load_ct(s), n, v, rng);
+        case RAYRS_MAT_COOK_TORRANCE_REFRACT: {  // :426-467
+            const CtLayer ct = load_ct(s);
+            const bool entering = v_dot(n, v) > 0.0;
+            const V3 nf = dir_normal(entering, n);
+            const double ior_ratio = dir_ior_ratio(entering, s->ior);
+            double value;
+            V3 h = beckmann_generate<true>(ct.alpha2, nf, rng, value);
+            h = dir_normal(entering, h);
+            V3 l;
+            if (!refract(h, v, ior_ratio, l)) return no_scatter();
+            return ct_evaluate_refraction(ct, nf, h, v, l, value, entering, ior_ratio);
+        }
+        case RAYRS_MAT_COOK_TORRANCE_GLASS: {  // :469-565
+            const CtLayer ct = load_ct(s);
+            double value;
+            V3 h = beckmann_generate<true>(ct.alpha2, n, rng, value);
+            const bool entering = v_dot(n, v) > 0.0;
+            h = dir_normal(entering, h);
+            const V3 nf = dir_normal(entering, n);
+            const double cos_theta = v_dot(h, v);
+            const double ior_ratio = dir_ior_ratio(entering, s->ior);
+            const double sin2_theta = 1.0 - cos_theta * cos_theta;
+            if (ior_ratio * ior_ratio * sin2_theta >= 1.0) {
+                const V3 l = reflect(h, v);
+                return ct_evaluate_reflection(ct, nf, h, v, l, value);
+            }
+            const double fresnel = entering ? schlick_scalar(1.0, s->ior, h, v) : schlick_scalar(s->ior, 1.0, h, v);
+            if (rng.next() < fresnel) {
+                const V3 l = reflect(h, v);
+                Scatter ev = ct_evaluate_reflection(ct, nf, h, v, l, value);
+                if (ev.scatter) ev.color = v_div(ev.color, fresnel);
+                return ev;
+            }
+            V3 l;
+            if (!refract(h, v, ior_ratio, l)) return no_scatter();  // .expect()
+            Scatter ev = ct_evaluate_refraction(ct, nf, h, v, l, value, entering, ior_ratio);
+            if (ev.scatter) ev.color = v_div(ev.color, 1.0 - fresnel);
+            return ev;
+        }
+        case RAYRS_MAT_PLASTIC: {  // :567-593
+            const double fresnel = schlick_scalar(1.0, s->ior, n, v);
+            if (rng.next() < fresnel) {
+                Scatter ev = ct_scatter(load_ct(s), n, v, rng);
+                if (ev.scatter) ev.color = v_div(ev.color, fresnel);
+                return ev;
+            }
+            return lambertian_scatter(color, n, rng);
+        }
+        default: return no_scatter();  // NoReflect
+    }
+}
+
+// --------------------------------------------------------------- background
+
+RR_DEV uint32_t f64_as_index(double x) {  // Rust `as usize`: NaN and negatives -> 0, saturating
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 0xffffffffu;
+    return (uint32_t)x;
+}
+
+RR_DEV V3 hdri_texel(const SceneDev& sc, uint32_t i, uint32_t j) {
+    // Image::pixel would panic out of range (image.rs:183-186); that only
+    // happens for phi == 2*pi or theta == pi, where the weights of the
+    // out-of-range texels are zero.  Clamp.
+    if (i >= sc.hdri_h) i = sc.hdri_h - 1;
+    if (j >= sc.hdri_w) j = sc.hdri_w - 1;
+    const float4 t = reinterpret_cast<const float4*>(sc.hdri)[(size_t)i * sc.hdri_w + j];
+    return mk((double)t.x, (double)t.y, (double)t.z);
+}
+
+// Scene::background, lib.rs:254-285
+RR_DEV V3 background(const SceneDev& sc, V3 dir) {
+    dir = v_unit(dir);
+    const double phi = rr_atan2(dir.z, dir.x) + RR_PI;
+    const double theta = rr_acos(dir.y);
+    const double x = phi / (2.0 * RR_PI) * (double)(sc.hdri_w - 1);
+    const double y = theta / RR_PI * (double)(sc.hdri_h - 1);
+    const double x_f = rr_floor(x), x_c = rr_ceil(x), y_f = rr_floor(y), y_c = rr_ceil(y);
+    const uint32_t i = f64_as_index(y_f);
+    const uint32_t j = f64_as_index(x_f);
+    const V3 f0 = hdri_texel(sc, i, j), f1 = hdri_texel(sc, i + 1, j), f2 = hdri_texel(sc, i, j + 1),
+             f3 = hdri_texel(sc, i + 1, j + 1);
+    const V3 a = v_scale(v_scale(f0, x_c - x), y_c - y);
+    const V3 b = v_scale(v_scale(f1, x_c - x), y - y_f);
+    const V3 c = v_scale(v_scale(f2, x - x_f), y_c - y);
+    const V3 e = v_scale(v_scale(f3, x - x_f), y - y_f);
+    return v_add(v_add(v_add(a, b), c), e);
+}
+
+// Camera::generate_primary_ray, lib.rs:202-210
+RR_DEV void primary_ray(const CameraDev& cam, uint32_t i, uint32_t j, Rng& rng, V3& o, V3& d) {
+    const double fi = (double)i, fj = (double)j;
+    const double x = (fj + rng.next()) / cam.ppc - cam.width / 2.0;
+    const double y = (fi + rng.next()) / cam.ppc - cam.height / 2.0;
+    o = mk(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const V3 ex = mk(cam.e_x[0], cam.e_x[1], cam.e_x[2]);
+    const V3 ey = mk(cam.e_y[0], cam.e_y[1], cam.e_y[2]);
+    d = v_add(v_add(mk(cam.z[0], cam.z[1], cam.z[2]), v_scale(ex, x)), v_scale(ey, y));
+}
+
+}  // namespace rayrs

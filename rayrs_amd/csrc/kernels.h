@@ -1,0 +1,25 @@
+// kernels.h -- host-callable launch wrappers of kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace rayrs {
+
+hipError_t launch_trace(bool compact, bool count, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
+                        uint32_t blocks, hipStream_t stream);
+hipError_t trace_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu);
+uint32_t trace_lds_bytes(uint32_t stack_depth);
+hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream);
+
+hipError_t launch_test_math(int fn, const double* x, const double* y, uint64_t n, double* out, hipStream_t stream);
+hipError_t launch_test_rng(uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
+                           uint64_t n, uint64_t* out, hipStream_t stream);
+hipError_t launch_test_intersect(bool compact, const SceneDev& sc, const double* o, const double* d, uint64_t n,
+                                 double* t_out, long long* prim_out, hipStream_t stream);
+hipError_t launch_test_material(const SurfaceDev* surf, const double* normal, const double* view, const uint64_t* key,
+                                uint64_t n, int32_t* scattered, double* color, double* dir, uint32_t* draws,
+                                hipStream_t stream);
+hipError_t launch_test_background(const SceneDev& sc, const double* dir, uint64_t n, double* rgb, hipStream_t stream);
+
+}  // namespace rayrs

@@ -1,0 +1,104 @@
+// layout.h -- HBM data layout shared by the host flattener and the gfx950 kernels.
+//
+// Everything the traversal touches is one of two record arrays, each record a
+// whole number of 16-byte words so that a lane fetches it with global_load_dwordx4:
+//
+//   interior record  two child boxes + two child refs          64 B (compact) / 128 B (full)
+//   primitive record triangle | sphere | plane + tag, DFS order  48 B (compact) /  80 B (full)
+//
+// "compact" = every node bound and every triangle vertex is exactly
+// representable in f32 (true for PLY meshes, whose vertices are f32), so the
+// f32 storage widens back to the very f64 values the reference computes with.
+// Spheres and planes always keep f64 parameters inside their record.
+#pragma once
+#include <stdint.h>
+
+namespace rayrs {
+
+// child reference: kind << 30 | payload
+constexpr uint32_t REF_INTERIOR = 0u;  // payload = interior record index
+constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1); box tested by the parent
+constexpr uint32_t REF_SINGLE = 2u;    // payload = prim << 2; no box test (bvh.rs:297, :302)
+constexpr uint32_t REF_NONE = 3u;
+
+// primitive tag: kind | axis << 2 | surface << 8
+constexpr uint32_t PRIM_SPHERE = 0u;
+constexpr uint32_t PRIM_PLANE = 1u;
+constexpr uint32_t PRIM_TRIANGLE = 2u;
+
+struct NodeF32 {  // 64 B
+    float box[2][6];  // xmin,xmax,ymin,ymax,zmin,zmax per child
+    uint32_t ref[2];
+    uint32_t pad[2];
+};
+struct NodeF64 {  // 128 B
+    double box[2][6];
+    uint32_t ref[2];
+    uint32_t pad[6];
+};
+static_assert(sizeof(NodeF32) == 64, "NodeF32");
+static_assert(sizeof(NodeF64) == 128, "NodeF64");
+
+// Primitive records are raw dwords: the payload starts at dword 0 and the tag
+// is the last dword.
+//   triangle: p1,p2,p3 as 9 f32 (compact) or 9 f64 (full)
+//   sphere  : radius2, cx, cy, cz as 4 f64
+//   plane   : umin, umax, vmin, vmax, pos as 5 f64 (axis in the tag)
+constexpr uint32_t PRIM_DWORDS_COMPACT = 12;  // 48 B
+constexpr uint32_t PRIM_DWORDS_FULL = 20;     // 80 B
+
+// One row per distinct (Material, Emission) pair; material.rs:148-238, :1056-1060.
+struct SurfaceDev {
+    int32_t kind;      // RAYRS_MAT_*
+    int32_t metallic;  // CookTorrance layer: Fresnel::SchlickMetallic
+    double color[3];   // Lambertian / Reflect / Refract / Glass colour; Plastic diffuse colour
+    double ior;
+    double ct_alpha2;  // alpha * alpha, material.rs:711
+    double ct_ior;
+    double ct_r0[3];
+    double ct_color[3];
+    double emit[3];    // Emission::emit(): strength * color, or zeros
+    int32_t emissive;
+    int32_t pad;
+};
+
+struct SceneDev {
+    const void* nodes;
+    const void* prims;
+    const SurfaceDev* surfaces;
+    const float* hdri;  // RGBA f32 texels (A unused), clipped to [0,3]
+    uint32_t hdri_w, hdri_h;
+    uint32_t root_ref;
+    uint32_t stack_depth;
+    double root_box[6];
+    double t0, t1;  // Scene::t_range, lib.rs:218
+};
+
+struct CameraDev {
+    double origin[3], e_x[3], e_y[3], z[3];
+    double width, height, ppc;
+    uint32_t W, H;
+};
+
+struct Counters {
+    unsigned long long rays, paths, nan_pixels, neg_pixels;
+    unsigned long long interior_visits, tri_tests, sphere_tests, plane_tests, escaped_paths;
+    unsigned long long queue_head;  // work queue (items)
+    unsigned long long pad[6];
+};
+
+struct RenderDev {
+    uint32_t spp, max_bounces;
+    uint64_t seed;
+    uint32_t chunk, nchunks;
+    uint32_t tile_rank, tile_ranks;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_local_tiles;
+    uint32_t out_format;
+    uint64_t total_items;  // n_local_tiles * nchunks * 64
+    double* partial;       // total_items * 3
+    Counters* counters;
+    void* out;
+};
+
+}  // namespace rayrs

@@ -1,0 +1,444 @@
+// scene_host.cpp -- Object/Scene/Camera constructors and the BVH builder + flattener.
+//
+// The builder takes the same decisions as the reference's BvhTree::build_sah /
+// build_midpoint (rayrs-lib/src/bvh.rs:227-389) -- same longest-axis rule, same
+// stable sort by bbox centre, same 1..=splits candidate planes, same strict "<"
+// on the SAH cost, same median fallback, same leaf threshold of 4, same child
+// order -- but evaluates all candidate planes of a node from one prefix and one
+// suffix sweep of surface areas instead of 2*splits from_object_list folds.
+// min/max are exact, so the swept boxes are bit-identical to the folded ones and
+// the chosen split is the same (tests/test_bvh_builder.py checks the exported
+// tree against the oracle's literal restatement).
+#include "scene_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <limits>
+
+#include "../../include/rayrs_numeric.h"
+
+namespace rayrs {
+
+// ---------------------------------------------------------------- surfaces
+
+static bool in01(const double* c) {
+    return c[0] >= 0.0 && c[0] <= 1.0 && c[1] >= 0.0 && c[1] <= 1.0 && c[2] >= 0.0 && c[2] <= 1.0;
+}
+
+// ctor asserts: material.rs:609, :630, :651-653, :674-676, :706-708, :833-837,
+// :864-868, :888-893, :1068-1072
+int ObjectList::add_surface(const rayrs_material* m, const rayrs_emission* e) {
+    if (!m) return RAYRS_INVALID_ARG;
+    SurfaceDev s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = m->kind;
+    if (m->kind < 0 || m->kind > RAYRS_MAT_NO_REFLECT) return RAYRS_INVALID_ARG;
+    if (m->kind != RAYRS_MAT_NO_REFLECT) {
+        if (!in01(m->color)) return RAYRS_INVALID_ARG;
+        for (int i = 0; i < 3; i++) s.color[i] = m->color[i];
+        const bool needs_ior = m->kind == RAYRS_MAT_REFRACT || m->kind == RAYRS_MAT_GLASS ||
+                               m->kind == RAYRS_MAT_COOK_TORRANCE_REFRACT ||
+                               m->kind == RAYRS_MAT_COOK_TORRANCE_GLASS || m->kind == RAYRS_MAT_PLASTIC;
+        if (needs_ior && !(m->ior > 0.0 && std::isfinite(m->ior))) return RAYRS_INVALID_ARG;
+        s.ior = m->ior;
+        if (m->kind >= RAYRS_MAT_COOK_TORRANCE && m->kind <= RAYRS_MAT_PLASTIC) {
+            if (!(m->alpha > 0.0 && std::isfinite(m->alpha))) return RAYRS_INVALID_ARG;
+            s.ct_alpha2 = m->alpha * m->alpha;
+            for (int i = 0; i < 3; i++) s.ct_color[i] = m->color[i];
+            if (m->kind == RAYRS_MAT_COOK_TORRANCE) {
+                s.metallic = m->metallic ? 1 : 0;
+                if (s.metallic) {
+                    for (int i = 0; i < 3; i++) s.ct_r0[i] = m->r0[i];
+                } else {
+                    s.ct_ior = m->ior;
+                }
+            } else {
+                s.metallic = 0;
+                s.ct_ior = m->ior;
+                if (m->kind == RAYRS_MAT_PLASTIC) {
+                    if (!in01(m->spec_color)) return RAYRS_INVALID_ARG;
+                    for (int i = 0; i < 3; i++) s.ct_color[i] = m->spec_color[i];
+                }
+            }
+        }
+    }
+    if (e && e->emissive) {
+        if (!(e->strength >= 0.0) || !in01(e->color)) return RAYRS_INVALID_ARG;
+        s.emissive = 1;
+        for (int i = 0; i < 3; i++) s.emit[i] = e->strength * e->color[i];  // material.rs:1080
+    }
+    // share identical rows (Object::from_triangles clones one pair per triangle)
+    for (size_t i = 0; i < surfaces.size(); i++)
+        if (std::memcmp(&surfaces[i], &s, sizeof(s)) == 0) return (int)i;
+    surfaces.push_back(s);
+    return (int)surfaces.size() - 1;
+}
+
+// ------------------------------------------------------------------- boxes
+
+// From<&Sphere/&Plane/&Triangle> for AxisAlignedBoundingBox, geometry.rs:686-733
+Aabb shape_bbox(const Shape& s) {
+    Aabb b;
+    if (s.kind == PRIM_SPHERE) {
+        const double radius = rr_sqrt(s.radius2);
+        b.xmin = s.origin.x - radius;
+        b.xmax = s.origin.x + radius;
+        b.ymin = s.origin.y - radius;
+        b.ymax = s.origin.y + radius;
+        b.zmin = s.origin.z - radius;
+        b.zmax = s.origin.z + radius;
+    } else if (s.kind == PRIM_PLANE) {
+        if (s.axis == RAYRS_AXIS_X || s.axis == RAYRS_AXIS_XREV) {
+            b = {s.pos, s.pos, s.u0, s.u1, s.v0, s.v1};
+        } else if (s.axis == RAYRS_AXIS_Y || s.axis == RAYRS_AXIS_YREV) {
+            b = {s.u0, s.u1, s.pos, s.pos, s.v0, s.v1};
+        } else {
+            b = {s.u0, s.u1, s.v0, s.v1, s.pos, s.pos};
+        }
+    } else {
+        b.xmin = rr_min(s.p1.x, rr_min(s.p2.x, s.p3.x));
+        b.ymin = rr_min(s.p1.y, rr_min(s.p2.y, s.p3.y));
+        b.zmin = rr_min(s.p1.z, rr_min(s.p2.z, s.p3.z));
+        b.xmax = rr_max(s.p1.x, rr_max(s.p2.x, s.p3.x));
+        b.ymax = rr_max(s.p1.y, rr_max(s.p2.y, s.p3.y));
+        b.zmax = rr_max(s.p1.z, rr_max(s.p2.z, s.p3.z));
+    }
+    return b;
+}
+
+static inline Aabb merge(const Aabb& a, const Aabb& o) {  // expand, geometry.rs:674-683
+    return {rr_min(a.xmin, o.xmin), rr_max(a.xmax, o.xmax), rr_min(a.ymin, o.ymin),
+            rr_max(a.ymax, o.ymax), rr_min(a.zmin, o.zmin), rr_max(a.zmax, o.zmax)};
+}
+static inline double area(const Aabb& b) {  // surface_area, geometry.rs:640-645
+    const double x = b.xmax - b.xmin, y = b.ymax - b.ymin, z = b.zmax - b.zmin;
+    return 2. * x * y + 2. * y * z + 2. * x * z;
+}
+static inline double centre_of(double lo, double hi) { return (hi - lo) / 2. + lo; }  // geometry.rs:577-582
+
+// ----------------------------------------------------------------- builder
+
+namespace {
+
+struct Builder {
+    const ObjectList& list;
+    FlatScene& flat;
+    const bool sah;
+    const uint32_t splits;
+    std::vector<Aabb> boxes;
+    std::vector<double> centre[3];
+    std::vector<uint32_t> order;  // objects in their current (sorted) order
+    std::vector<std::pair<double, uint32_t>> keyed;
+    std::vector<double> area_left, area_right;
+    uint32_t next_prim = 0;
+
+    Builder(const ObjectList& l, FlatScene& f, bool use_sah, uint32_t n_splits)
+        : list(l), flat(f), sah(use_sah), splits(n_splits) {
+        const size_t n = l.objs.size();
+        boxes.resize(n);
+        for (auto& c : centre) c.resize(n);
+        order.resize(n);
+        keyed.resize(n);
+        area_left.resize(n);
+        area_right.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            boxes[i] = shape_bbox(l.objs[i].geom);
+            centre[0][i] = centre_of(boxes[i].xmin, boxes[i].xmax);
+            centre[1][i] = centre_of(boxes[i].ymin, boxes[i].ymax);
+            centre[2][i] = centre_of(boxes[i].zmin, boxes[i].zmax);
+            order[i] = (uint32_t)i;
+        }
+        flat.prim_object.assign(n, 0);
+    }
+
+    Aabb bounds(size_t lo, size_t hi) const {
+        Aabb b = boxes[order[lo]];
+        for (size_t i = lo + 1; i < hi; i++) b = merge(b, boxes[order[i]]);
+        return b;
+    }
+
+    // BvhData::sort: a stable sort of the node's objects by centre on `axis`
+    void sort_range(size_t lo, size_t hi, int axis) {
+        const std::vector<double>& c = centre[axis];
+        bool sorted = true;
+        for (size_t i = lo + 1; i < hi; i++) {
+            if (c[order[i - 1]] > c[order[i]]) {
+                sorted = false;
+                break;
+            }
+        }
+        if (sorted) return;
+        for (size_t i = lo; i < hi; i++) keyed[i] = {c[order[i]], order[i]};
+        std::stable_sort(keyed.begin() + (std::ptrdiff_t)lo, keyed.begin() + (std::ptrdiff_t)hi,
+                         [](const std::pair<double, uint32_t>& a, const std::pair<double, uint32_t>& b) {
+                             return a.first < b.first;
+                         });
+        for (size_t i = lo; i < hi; i++) order[i] = keyed[i].second;
+    }
+
+    uint32_t emit_single(uint32_t obj) {
+        const uint32_t p = next_prim++;
+        flat.prim_object[p] = obj;
+        return (REF_SINGLE << 30) | (p << 2);
+    }
+
+    // Node over order[lo, hi), hi - lo >= 1 handled by the caller for singles.
+    // Returns the child reference and the node's box.
+    uint32_t build(size_t lo, size_t hi, uint32_t level, Aabb* box_out) {
+        const size_t len = hi - lo;
+        const Aabb box = bounds(lo, hi);
+        *box_out = box;
+        if (len <= 4) {  // bvh.rs:306-316 / :378-387
+            const uint32_t first = next_prim;
+            for (size_t i = lo; i < hi; i++) flat.prim_object[next_prim++] = order[i];
+            return (REF_RANGE << 30) | (first << 2) | (uint32_t)(len - 1);
+        }
+        const double ex = box.xmax - box.xmin, ey = box.ymax - box.ymin, ez = box.zmax - box.zmin;
+        int axis;
+        double lo_edge, extent;
+        if (ex >= ey && ex >= ez) {  // bvh.rs:248-257
+            axis = 0, lo_edge = box.xmin, extent = ex;
+        } else if (ey >= ez) {
+            axis = 1, lo_edge = box.ymin, extent = ey;
+        } else {
+            axis = 2, lo_edge = box.zmin, extent = ez;
+        }
+        sort_range(lo, hi, axis);
+        const std::vector<double>& c = centre[axis];
+
+        bool found = false;
+        size_t ind = 0;
+        if (sah) {
+            const double total_area = area(box);
+            // area_left[k]  = SA(objects lo .. lo+k-1), k >= 1
+            // area_right[k] = SA(objects lo+k .. hi-1)
+            Aabb acc = boxes[order[lo]];
+            for (size_t k = 1; k < len; k++) {
+                area_left[lo + k] = area(acc);
+                acc = merge(acc, boxes[order[lo + k]]);
+            }
+            acc = boxes[order[hi - 1]];
+            area_right[lo + len - 1] = area(acc);
+            for (size_t k = len - 1; k-- > 0;) {
+                acc = merge(boxes[order[lo + k]], acc);
+                area_right[lo + k] = area(acc);
+            }
+            const double step = extent / (double)(splits - 1u);  // bvh.rs:259
+            double best = std::numeric_limits<double>::infinity();
+            size_t k = 0;
+            for (uint32_t i = 1; i < splits + 1u; i++) {  // bvh.rs:262
+                const double plane = lo_edge + (double)i * step;
+                while (k < len && !(c[order[lo + k]] > plane)) k++;  // split_ind, bvh.rs:7-13
+                if (k == len) break;                                 // None for this and all later planes
+                const double p_left = k > 0 ? area_left[lo + k] / total_area : 0.;
+                const double p_right = area_right[lo + k] / total_area;
+                const double cost = 0.3 + 1. * (p_left * (double)k + p_right * (double)(len - k));  // bvh.rs:36-37
+                if (cost < best) {
+                    best = cost;
+                    ind = k;
+                    found = true;
+                }
+            }
+        } else {
+            const double plane = axis == 0 ? centre_of(box.xmin, box.xmax)
+                                           : (axis == 1 ? centre_of(box.ymin, box.ymax) : centre_of(box.zmin, box.zmax));
+            size_t k = 0;
+            while (k < len && !(c[order[lo + k]] > plane)) k++;
+            found = k < len;
+            ind = k;
+        }
+        if (!found || ind == 0 || ind == len - 1) ind = len / 2;  // bvh.rs:279-287
+
+        const uint32_t rec = (uint32_t)(flat.child_ref.size() / 2);
+        flat.child_ref.resize(flat.child_ref.size() + 2);
+        flat.child_box.resize(flat.child_box.size() + 12);
+        if (level + 1 > flat.depth) flat.depth = level + 1;
+
+        const size_t mid = lo + ind;
+        const size_t range[2][2] = {{lo, mid}, {mid, hi}};
+        for (int ch = 0; ch < 2; ch++) {
+            Aabb cb;
+            uint32_t ref;
+            if (range[ch][1] - range[ch][0] > 1) {  // bvh.rs:294-303
+                ref = build(range[ch][0], range[ch][1], level + 1, &cb);
+            } else {
+                const uint32_t obj = order[range[ch][0]];
+                cb = boxes[obj];
+                ref = emit_single(obj);
+            }
+            flat.child_ref[(size_t)rec * 2 + ch] = ref;
+            double* bx = &flat.child_box[((size_t)rec * 2 + ch) * 6];
+            bx[0] = cb.xmin, bx[1] = cb.xmax, bx[2] = cb.ymin, bx[3] = cb.ymax, bx[4] = cb.zmin, bx[5] = cb.zmax;
+        }
+        return (REF_INTERIOR << 30) | rec;
+    }
+};
+
+inline bool f32_exact(double v) { return (double)(float)v == v; }
+
+void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
+void put_f32(uint32_t* dst, float v) { std::memcpy(dst, &v, 4); }
+
+}  // namespace
+
+int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int heuristic, uint32_t splits,
+                     uint32_t hdri_w, uint32_t hdri_h, const float* hdri_rgb, FlatScene* out) {
+    if (!(z_near >= 0.0) || !(z_far > z_near)) return RAYRS_INVALID_ARG;  // lib.rs:234-235
+    if (objs.objs.empty()) return RAYRS_INVALID_ARG;                      // bvh.rs:229
+    if (heuristic != RAYRS_BVH_MIDPOINT && heuristic != RAYRS_BVH_SAH) return RAYRS_INVALID_ARG;
+    if (heuristic == RAYRS_BVH_SAH && splits < 2) return RAYRS_INVALID_ARG;
+    if (hdri_w < 2 || hdri_h < 2 || !hdri_rgb) return RAYRS_INVALID_ARG;
+    if (objs.objs.size() >= (1u << 28)) return RAYRS_UNSUPPORTED;
+
+    const auto t_begin = std::chrono::steady_clock::now();
+    FlatScene& f = *out;
+    f = FlatScene();
+    f.t0 = z_near;
+    f.t1 = z_far;
+
+    Builder b(objs, f, heuristic == RAYRS_BVH_SAH, splits);
+    Aabb root;
+    const size_t n = objs.objs.size();
+    if (n == 1) {
+        // Node(bbox, [Leaf]) -- bvh.rs:306-316 with one object
+        root = b.boxes[0];
+        f.prim_object[0] = 0;
+        b.next_prim = 1;
+        f.root_ref = (REF_RANGE << 30) | 0u;
+    } else {
+        f.root_ref = b.build(0, n, 0, &root);
+    }
+    f.root_box[0] = root.xmin, f.root_box[1] = root.xmax, f.root_box[2] = root.ymin;
+    f.root_box[3] = root.ymax, f.root_box[4] = root.zmin, f.root_box[5] = root.zmax;
+
+    // ---- choose the layout
+    bool compact = true;
+    for (size_t r = 0; r < f.child_ref.size() && compact; r++) {
+        if ((f.child_ref[r] >> 30) == REF_SINGLE) continue;  // box never read
+        for (int k = 0; k < 6; k++)
+            if (!f32_exact(f.child_box[r * 6 + k])) {
+                compact = false;
+                break;
+            }
+    }
+    for (size_t i = 0; i < n && compact; i++) {
+        const Shape& s = objs.objs[i].geom;
+        if (s.kind != PRIM_TRIANGLE) continue;
+        const double v[9] = {s.p1.x, s.p1.y, s.p1.z, s.p2.x, s.p2.y, s.p2.z, s.p3.x, s.p3.y, s.p3.z};
+        for (double c : v)
+            if (!f32_exact(c)) {
+                compact = false;
+                break;
+            }
+    }
+    f.compact = compact;
+
+    // ---- interior records
+    const uint32_t n_int = f.n_interior();
+    if (compact) {
+        f.node_bytes.assign((size_t)std::max(n_int, 1u) * sizeof(NodeF32), 0);
+        NodeF32* nodes = reinterpret_cast<NodeF32*>(f.node_bytes.data());
+        for (uint32_t r = 0; r < n_int; r++)
+            for (int ch = 0; ch < 2; ch++) {
+                nodes[r].ref[ch] = f.child_ref[(size_t)r * 2 + ch];
+                const bool unused = (nodes[r].ref[ch] >> 30) == REF_SINGLE;
+                for (int k = 0; k < 6; k++)
+                    nodes[r].box[ch][k] = unused ? 0.f : (float)f.child_box[((size_t)r * 2 + ch) * 6 + k];
+            }
+    } else {
+        f.node_bytes.assign((size_t)std::max(n_int, 1u) * sizeof(NodeF64), 0);
+        NodeF64* nodes = reinterpret_cast<NodeF64*>(f.node_bytes.data());
+        for (uint32_t r = 0; r < n_int; r++)
+            for (int ch = 0; ch < 2; ch++) {
+                nodes[r].ref[ch] = f.child_ref[(size_t)r * 2 + ch];
+                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = f.child_box[((size_t)r * 2 + ch) * 6 + k];
+            }
+    }
+
+    // ---- primitive records in DFS order
+    const uint32_t dw = compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL;
+    f.prim_bytes.assign((size_t)n * dw * 4, 0);
+    uint32_t* prims = reinterpret_cast<uint32_t*>(f.prim_bytes.data());
+    for (size_t p = 0; p < n; p++) {
+        const Object& o = objs.objs[f.prim_object[p]];
+        const Shape& s = o.geom;
+        uint32_t* rec = prims + p * dw;
+        if (s.kind == PRIM_SPHERE) {
+            put_f64(rec + 0, s.radius2);
+            put_f64(rec + 2, s.origin.x);
+            put_f64(rec + 4, s.origin.y);
+            put_f64(rec + 6, s.origin.z);
+        } else if (s.kind == PRIM_PLANE) {
+            put_f64(rec + 0, s.u0);
+            put_f64(rec + 2, s.u1);
+            put_f64(rec + 4, s.v0);
+            put_f64(rec + 6, s.v1);
+            put_f64(rec + 8, s.pos);
+        } else {
+            const double v[9] = {s.p1.x, s.p1.y, s.p1.z, s.p2.x, s.p2.y, s.p2.z, s.p3.x, s.p3.y, s.p3.z};
+            for (int k = 0; k < 9; k++) {
+                if (compact)
+                    put_f32(rec + k, (float)v[k]);
+                else
+                    put_f64(rec + 2 * k, v[k]);
+            }
+        }
+        rec[dw - 1] = s.kind | (s.axis << 2) | (o.surface << 8);
+    }
+
+    // ---- HDRI: clip(0, 3) (main.rs:43; clip = min(max).max(min), vecmath.rs:388-396), RGBA
+    f.hdri_w = hdri_w;
+    f.hdri_h = hdri_h;
+    f.hdri_rgba.resize((size_t)hdri_w * hdri_h * 4);
+    for (size_t t = 0; t < (size_t)hdri_w * hdri_h; t++) {
+        for (int k = 0; k < 3; k++) {
+            const double v = rr_max(rr_min((double)hdri_rgb[t * 3 + k], 3.0), 0.0);
+            f.hdri_rgba[t * 4 + k] = (float)v;  // v is an f32 value or 0 or 3: exact
+        }
+        f.hdri_rgba[t * 4 + 3] = 0.f;
+    }
+
+    f.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return RAYRS_OK;
+}
+
+// ------------------------------------------------------------------ camera
+
+static inline Vec3 sub(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline Vec3 cross(Vec3 a, Vec3 b) {  // vecmath.rs:565-577
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+static inline Vec3 unit(Vec3 a) {  // vecmath.rs:525-527 with Div<f64> :690-698
+    const double inv = 1.0 / rr_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+int camera_new(const double origin[3], const double up[3], const double lookat[3], double fov, double width,
+               double height, uint32_t ppi, rayrs_camera* out) {
+    if (!origin || !up || !lookat || !out) return RAYRS_INVALID_ARG;
+    if (!(fov > 0. && fov < 180.)) return RAYRS_INVALID_ARG;  // lib.rs:108
+    if (!(width > 0.) || !(height > 0.)) return RAYRS_INVALID_ARG;
+    const Vec3 o{origin[0], origin[1], origin[2]}, u{up[0], up[1], up[2]}, la{lookat[0], lookat[1], lookat[2]};
+    if (o.x == la.x && o.y == la.y && o.z == la.z) return RAYRS_INVALID_ARG;  // lib.rs:111
+    const uint32_t ppc = (uint32_t)std::round((double)ppi * 2.54);            // lib.rs:113
+    const Vec3 z = unit(sub(la, o));
+    const Vec3 x = unit(cross(u, z));
+    const Vec3 y = unit(cross(z, x));
+    const double rad = fov * (RR_PI / 180.0);  // f64::to_radians
+    const double focal = width / rr_tan(rad / 2.);  // lib.rs:131
+    out->origin[0] = o.x, out->origin[1] = o.y, out->origin[2] = o.z;
+    out->e_x[0] = x.x, out->e_x[1] = x.y, out->e_x[2] = x.z;
+    out->e_y[0] = y.x, out->e_y[1] = y.y, out->e_y[2] = y.z;
+    out->z[0] = focal * z.x, out->z[1] = focal * z.y, out->z[2] = focal * z.z;
+    out->width = width;
+    out->height = height;
+    out->ppc = ppc;
+    out->x_pixels = (uint32_t)std::round(width * (double)ppc);   // lib.rs:153-155
+    out->y_pixels = (uint32_t)std::round(height * (double)ppc);  // lib.rs:175-177
+    return RAYRS_OK;
+}
+
+}  // namespace rayrs
