@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- Mray/s of the MI355X radiance integrator on BASELINE.json's headline
+configuration (configs[4]: floor + 1,310,720-triangle mesh, 2048x2048, 1024 spp,
+50 bounces), on N GPUs of one node.
+
+One step = one full frame: every 8x8 image tile of this rank traced by the
+persistent gfx950 kernel, the per-pixel resolve, and (N > 1) one RCCL reduce of
+the f32x3 framebuffer to rank 0.  Tiles are interleaved over ranks (tile t ->
+rank t % N), the scene is replicated, total work is fixed: strong scaling.
+`value` = BVH queries of all ranks / max-over-ranks wall time (scene build,
+upload and file I/O excluded -- the region the reference times, main.rs:59-100).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+  roofline     -- algorithmic bytes of the trace kernel per launch (from the
+                  kernel's own traversal counters on the flattened layout)
+                  / its HIP-event duration, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed
+                  traversal over a pointer tree, rayrs-lib's algorithm) timed on
+                  this box's host cores on a bounded band of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(stats, info, n_pixels, n_items):
+    """bytes the traversal must fetch on the flattened layout
+    (one record per interior visit / primitive test), 4 texels per escaped
+    path, the per-item partial sums (written by the trace kernel, read by the
+    resolve) and the framebuffer write."""
+    return (stats["interior_visits"] * info["node_bytes"]
+            + (stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"]) * info["prim_bytes"]
+            + stats["escaped_paths"] * 4 * 16
+            + n_items * 24)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=5, help="BASELINE.json configs[n-1]; 5 is the headline")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only)")
+    ap.add_argument("--res", type=int, default=0, help="override resolution (development only)")
+    ap.add_argument("--sample-chunk", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as graft
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rank == 0:
+        graft.build()
+
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import rayrs_amd
+    from rayrs_amd import procedural, scenes
+
+    cam_args, objs, heur, spp, max_bounces = scenes.config(args.config)
+    reduced = False
+    if args.spp:
+        spp, reduced = args.spp, True
+    if args.res:
+        cam_args, reduced = scenes.camera_for_resolution(cam_args, args.res, args.res), True
+    hdri = procedural.make_hdri(1024, 512)
+    t0 = time.time()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=local_rank)
+    build_s = time.time() - t0
+    cam = rayrs_amd.Camera(*cam_args)
+    info = scene.info()
+    H, W = cam.y_pixels(), cam.x_pixels()
+
+    dev = torch.device("cuda", local_rank)
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    params = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=args.sample_chunk, tile_rank=rank,
+                                   tile_ranks=world)
+
+    def step():
+        fb.zero_()
+        rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
+        if use_dist:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        return rayrs_amd.render_finish(scene)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t_begin = time.perf_counter()
+    rays = 0
+    kernel_ms = []
+    for _ in range(args.steps):
+        st = step()
+        rays += st["rays"]
+        kernel_ms.append(st["kernel_ms"])
+    fence()
+    elapsed = time.perf_counter() - t_begin
+
+    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        r = tot[:1].clone()
+        e = tot[1:].clone()
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        total_rays, max_elapsed = float(r.item()), float(e.item())
+    else:
+        total_rays, max_elapsed = float(rays), elapsed
+    checksum = float(fb.double().sum().item()) if rank == 0 else 0.0
+
+    roofline = None
+    if not args.no_roofline:
+        # same launch once more with the traversal counters compiled in (untimed):
+        # the work of a launch is a pure function of (scene, seed), so the counts
+        # apply to the timed launches exactly
+        pc = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=args.sample_chunk, tile_rank=rank,
+                                   tile_ranks=world, count_work=True)
+        fb2 = torch.zeros_like(fb)
+        rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
+        cst = rayrs_amd.render_finish(scene)
+        assert cst["rays"] == st["rays"], "counting launch traced a different frame"
+        n_tiles = ((W + 7) // 8) * ((H + 7) // 8)
+        n_local = (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
+        chunk = spp if (args.sample_chunk == 0 or args.sample_chunk >= spp) else args.sample_chunk
+        n_items = n_local * ((spp + chunk - 1) // chunk) * 64
+        abytes = algorithmic_bytes(cst, info, H * W, n_items)
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "trace_kernel", "kernel_ms": round(avg_ms, 3),
+                    "algorithmic_bytes_per_launch": int(abytes),
+                    "bytes_per_ray": round(abytes / max(cst["rays"], 1), 1),
+                    "interior_visits_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
+                    "prim_tests_per_ray": round((cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"])
+                                                / max(cst["rays"], 1), 2)}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle
+        ncores = os.cpu_count() or 1
+        t0 = time.time()
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, hdri, builder=1)
+        ocam = _oracle.OracleCamera(*cam_args)
+        obuild = time.time() - t0
+        mid = H // 2
+        # calibrate on a thin band, then size the sample for ~cpu-seconds of wall time
+        band = max(16, H // 64)
+        _, cal = osc.render(ocam, 1, max_bounces, seed=0x5EED, rows=(mid - band // 2, mid + band // 2),
+                            nthreads=ncores, traversal=0)
+        rate = cal["rays"] / max(cal["seconds"], 1e-6)
+        rays_per_row_spp = cal["rays"] / band
+        rows = min(H, max(band, 16 * (int(H // 8) // 16)))
+        want = rate * args.cpu_seconds
+        cspp = int(max(1, min(spp, want / max(rays_per_row_spp * rows, 1.0))))
+        _, cst2 = osc.render(ocam, cspp, max_bounces, seed=0x5EED, rows=(mid - rows // 2, mid + rows // 2),
+                             nthreads=ncores, traversal=0)
+        cpu_baseline = {"value": round(cst2["rays"] / cst2["seconds"] / 1e6, 4), "unit": "Mray/s", "cores": ncores,
+                        "kind": "port",
+                        "sample": f"C restatement of rayrs-lib's CPU path (recursive un-narrowed BVH traversal, "
+                                  f"f64, 16x16 blocks on {ncores} threads), same scene/camera/seed, image rows "
+                                  f"{mid - rows // 2}..{mid + rows // 2} of {H} at {cspp} spp: {cst2['rays']} rays in "
+                                  f"{cst2['seconds']:.2f} s (oracle BVH build {obuild:.1f} s not timed)"}
+
+    if rank == 0:
+        value = total_rays / max_elapsed / 1e6
+        n_tri = info["n_prims"]
+        line = {
+            "metric": "Mray/s (primary+secondary) on 1M-tri scene @1024spp",
+            "value": round(value, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(max_elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[{args.config - 1}]: floor + {n_tri - 1 if args.config == 5 else n_tri}-primitive "
+                            f"procedural mesh scene, {W}x{H}, {spp} spp, max {max_bounces} bounces, SAH(1000) BVH, "
+                            f"1024x512 procedural HDRI" + (" [REDUCED: development run]" if reduced else ""),
+                "resolution": [W, H], "spp": spp, "max_bounces": max_bounces, "primitives": n_tri,
+                "sample_chunk": args.sample_chunk, "parallelism": f"8x8 image tiles interleaved over {world} GPU(s), "
+                                                                 f"scene replicated, one RCCL reduce of the f32x3 framebuffer",
+                "layout": "compact f32 records" if info["compact"] else "f64 records",
+                "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"], "scene_build_s": round(build_s, 2),
+            },
+            "rays_per_step": int(total_rays / args.steps),
+            "framebuffer_checksum": checksum,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

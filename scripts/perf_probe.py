@@ -1,0 +1,40 @@
+"""Quick GPU throughput probe (development aid, not the benchmark)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rayrs_amd
+from rayrs_amd import scenes, procedural
+
+def run(cfg, w, h, spp, chunk=0, level=None, count=False):
+    if level is not None:
+        cam_args, objs, heur = scenes.mesh_scene(level)
+        cam_args = scenes.camera_for_resolution(cam_args, w, h); mb = 50
+    else:
+        cam_args, objs, heur, _, mb = scenes.config(cfg)
+        cam_args = scenes.camera_for_resolution(cam_args, w, h)
+    hdri = procedural.make_hdri(1024, 512)
+    t = time.time()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=0)
+    tb = time.time() - t
+    cam = rayrs_amd.Camera(*cam_args)
+    info = scene.info()
+    img, st = rayrs_amd.render(scene, cam, min(spp, 4), mb, sample_chunk=chunk)  # warm
+    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, count_work=count)
+    mr = st['rays'] / st['kernel_ms'] / 1e3
+    print(f"cfg={cfg} level={level} {w}x{h}x{spp} chunk={chunk} build={tb:.1f}s prims={info['n_prims']} depth={info['depth']} compact={info['compact']} "
+          f"rays={st['rays']} kernel={st['kernel_ms']:.1f}ms total={st['total_ms']:.1f}ms Mray/s={mr:.1f} rays/path={st['rays']/st['paths']:.2f}", flush=True)
+    if count:
+        print({k: st[k] for k in ('interior_visits','tri_tests','sphere_tests','plane_tests','escaped_paths')})
+    return st
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "c2"):
+        run(2, 1024, 1024, 16)
+        run(2, 1024, 1024, 64, chunk=16)
+    if what in ("all", "c4"):
+        run(4, 1024, 1024, 16)
+    if what in ("all", "c3"):
+        run(3, 1024, 1024, 16, count=True)
+    if what in ("all", "c5"):
+        run(5, 1024, 1024, 8, count=True)
