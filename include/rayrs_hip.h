@@ -197,6 +197,9 @@ typedef struct {
     uint64_t sphere_tests;
     uint64_t plane_tests;
     uint64_t escaped_paths;
+    /* lane-utilisation diagnostics (count_work only); each *_wave value is summed over
+     * all 64 lanes of the waves that executed the phase, *_lane over the active lanes */
+    uint64_t step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
     double kernel_ms;       /* HIP-event time of the trace kernel on its stream */
     double total_ms;        /* trace + resolve */
 } rayrs_render_stats;

@@ -27,10 +27,20 @@
 
 #include <stdint.h>
 
+/* RR_FN: small helpers, always inlined.  RR_BIG: the elementary functions; in
+ * device code they are real functions (not inlined into every call site), which
+ * keeps the kernel's register allocation low enough for three waves per SIMD.
+ * Inlining does not change any arithmetic. */
 #if defined(__HIPCC__)
 #define RR_FN __host__ __device__ static inline
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RR_BIG __device__ static __attribute__((noinline))
+#else
+#define RR_BIG __host__ __device__ static inline
+#endif
 #else
 #define RR_FN static inline
+#define RR_BIG static inline
 #endif
 
 /* ------------------------------------------------------------------ bits */
@@ -144,7 +154,7 @@ RR_FN void rr_rem_pio2(double x, double* r, double* t, int* q) {
     *q = ((int)k) & 3;
 }
 
-RR_FN double rr_sin(double x) {
+RR_BIG double rr_sin(double x) {
     double r, t;
     int q;
     rr_rem_pio2(x, &r, &t, &q);
@@ -156,7 +166,7 @@ RR_FN double rr_sin(double x) {
     }
 }
 
-RR_FN double rr_cos(double x) {
+RR_BIG double rr_cos(double x) {
     double r, t;
     int q;
     rr_rem_pio2(x, &r, &t, &q);
@@ -169,7 +179,7 @@ RR_FN double rr_cos(double x) {
 }
 
 /* sin and cos of the same argument (one reduction). */
-RR_FN void rr_sincos(double x, double* s, double* c) {
+RR_BIG void rr_sincos(double x, double* s, double* c) {
     double r, t;
     int q;
     rr_rem_pio2(x, &r, &t, &q);
@@ -185,7 +195,7 @@ RR_FN void rr_sincos(double x, double* s, double* c) {
 
 /* tan as a quotient of the two kernels.  tan(acos(0)) = tan(0x1.921fb54442d18p+0)
  * is finite (1.633e16), as it is for the reference's libm. */
-RR_FN double rr_tan(double x) {
+RR_BIG double rr_tan(double x) {
     double r, t;
     int q;
     rr_rem_pio2(x, &r, &t, &q);
@@ -196,7 +206,7 @@ RR_FN double rr_tan(double x) {
 
 /* ------------------------------------------------------------------- log */
 
-RR_FN double rr_log(double x) {
+RR_BIG double rr_log(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
@@ -237,7 +247,7 @@ RR_FN double rr_log(double x) {
 
 /* ------------------------------------------------------------------- exp */
 
-RR_FN double rr_exp(double x) {
+RR_BIG double rr_exp(double x) {
     const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
                  P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
@@ -297,7 +307,7 @@ RR_FN double rr_acos_R(double z) {
     return p / q;
 }
 
-RR_FN double rr_acos(double x) {
+RR_BIG double rr_acos(double x) {
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
     uint64_t u = rr_f64_bits(x);
     uint32_t hx = (uint32_t)(u >> 32);
@@ -331,7 +341,7 @@ RR_FN double rr_acos(double x) {
 
 /* ----------------------------------------------------------- atan / atan2 */
 
-RR_FN double rr_atan(double x) {
+RR_BIG double rr_atan(double x) {
     const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
                  atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
     const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
@@ -385,7 +395,7 @@ RR_FN double rr_atan(double x) {
     return sign ? -z : z;
 }
 
-RR_FN double rr_atan2(double y, double x) {
+RR_BIG double rr_atan2(double y, double x) {
     const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
     if (rr_isnan(x) || rr_isnan(y)) return x + y;
     uint64_t ux = rr_f64_bits(x), uy = rr_f64_bits(y);

@@ -59,6 +59,8 @@ class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("nan_pixels", C.c_uint64),
                 ("neg_pixels", C.c_uint64), ("interior_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64), ("escaped_paths", C.c_uint64),
+                ("step_wave", C.c_uint64), ("step_lane", C.c_uint64), ("inner_wave", C.c_uint64),
+                ("leaf_wave", C.c_uint64), ("shade_wave", C.c_uint64), ("shade_lane", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
     def as_dict(self):

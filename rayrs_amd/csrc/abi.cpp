@@ -428,6 +428,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->sphere_tests = c.sphere_tests;
         stats->plane_tests = c.plane_tests;
         stats->escaped_paths = c.escaped_paths;
+        stats->step_wave = c.step_wave, stats->step_lane = c.step_lane, stats->inner_wave = c.inner_wave;
+        stats->leaf_wave = c.leaf_wave, stats->shade_wave = c.shade_wave, stats->shade_lane = c.shade_lane;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->kernel_ms = ms;

@@ -203,132 +203,172 @@ RR_DEV V3 prim_normal(const PrimRec<COMPACT>& r, V3 position) {
 // ---------------------------------------------------------------- traversal
 
 // AxisAlignedBoundingBox::intersect (geometry.rs:458-513) with 1/dir hoisted
-// (the reference recomputes the same quotient at every node).  tmin only grows
-// and tmax only shrinks, so the single final compare equals the three
-// early-outs.  `entry` is the slab entry parameter used for ordering/culling.
-RR_DEV bool slab(double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, V3 o, V3 inv,
-                 double tmin, double tmax, double& entry) {
-    double lo = xmin - o.x, hi = xmax - o.x;
-    double t0 = inv.x < 0.0 ? hi * inv.x : lo * inv.x;
-    double t1 = inv.x < 0.0 ? lo * inv.x : hi * inv.x;
-    tmin = rr_max(tmin, t0);
-    tmax = rr_min(tmax, t1);
-    lo = ymin - o.y, hi = ymax - o.y;
-    t0 = inv.y < 0.0 ? hi * inv.y : lo * inv.y;
-    t1 = inv.y < 0.0 ? lo * inv.y : hi * inv.y;
-    tmin = rr_max(tmin, t0);
-    tmax = rr_min(tmax, t1);
-    lo = zmin - o.z, hi = zmax - o.z;
-    t0 = inv.z < 0.0 ? hi * inv.z : lo * inv.z;
-    t1 = inv.z < 0.0 ? lo * inv.z : hi * inv.z;
-    tmin = rr_max(tmin, t0);
-    tmax = rr_min(tmax, t1);
+// (the reference recomputes the same quotient at every node) and the
+// `if inv < 0 { (hi*inv, lo*inv) } else { (lo*inv, hi*inv) }` swap applied to the
+// bounds before the subtraction: (near - o) * inv and (far - o) * inv are the
+// same two products.  tmin only grows and tmax only shrinks, so the single final
+// compare equals the reference's three early-outs.  `entry` is the slab entry
+// parameter used for ordering/culling.
+RR_DEV bool slab(double xn, double xf, double yn, double yf, double zn, double zf, V3 o, V3 inv, double tmin,
+                 double tmax, double& entry) {
+    tmin = rr_max(tmin, (xn - o.x) * inv.x);
+    tmax = rr_min(tmax, (xf - o.x) * inv.x);
+    tmin = rr_max(tmin, (yn - o.y) * inv.y);
+    tmax = rr_min(tmax, (yf - o.y) * inv.y);
+    tmin = rr_max(tmin, (zn - o.z) * inv.z);
+    tmax = rr_min(tmax, (zf - o.z) * inv.z);
     entry = tmin;
     return !(tmax <= tmin);
 }
 
 struct WorkCount {
     uint32_t interior, tri, sphere, plane;
+    uint32_t leaf_prims;  // primitives of the last leaf visited in a macro step
 };
 
-// Bvh::intersect (bvh.rs:212-214, :391-415).  Children are tested at the parent,
-// the nearer one is entered first and the farther one pushed on the lane's LDS
-// stack (entry k of lane l lives at stack[k * 64]); boxes entered beyond the
-// closest hit so far are skipped.  The answer is the reference's: smallest
-// accepted t, lowest DFS index on exact ties.
+RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
+
+// Bvh::intersect (bvh.rs:212-214, :391-415) as a resumable per-lane state
+// machine.  Children are tested at the parent, the nearer one is entered first
+// and the farther one pushed on the lane's LDS stack (entry k of lane l lives at
+// stack[k * 64]); boxes entered beyond the closest hit so far are skipped.  The
+// answer is the reference's: smallest accepted t, lowest DFS index on exact ties.
+//
+// A query advances by interior steps (one record) and leaf steps (one leaf
+// reference); the kernel decides per wave which kind to run next.  A record is
+// fetched whole, with loads that do not depend on its contents, before anything
+// is decided from it.
+constexpr uint32_t TRAV_DONE = 0xffffffffu;
+
+struct Trav {
+    V3 inv;
+    double best_t;
+    uint32_t best_prim;  // 0xffffffff = no hit yet
+    uint32_t cur;        // reference to visit next, TRAV_DONE when finished
+    int sp;
+};
+
+RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
+    tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const bool nx = tv.inv.x < 0.0, ny = tv.inv.y < 0.0, nz = tv.inv.z < 0.0;
+    tv.best_t = sc.t1;
+    tv.best_prim = 0xffffffffu;
+    tv.sp = 0;
+    double entry;
+    const bool hit = slab(nx ? sc.root_box[1] : sc.root_box[0], nx ? sc.root_box[0] : sc.root_box[1],
+                          ny ? sc.root_box[3] : sc.root_box[2], ny ? sc.root_box[2] : sc.root_box[3],
+                          nz ? sc.root_box[5] : sc.root_box[4], nz ? sc.root_box[4] : sc.root_box[5], o, tv.inv, sc.t0,
+                          sc.t1, entry);
+    tv.cur = hit ? sc.root_ref : TRAV_DONE;
+}
+
+RR_DEV void trav_pop(uint32_t* stack, Trav& tv) {
+    if (tv.sp > 0) {
+        tv.sp--;
+        tv.cur = stack[tv.sp * 64];
+    } else {
+        tv.cur = TRAV_DONE;
+    }
+}
+
+// One interior record: both child boxes tested, nearer child entered, farther pushed.
+template <bool COMPACT, bool COUNT>
+RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, uint32_t* stack, Trav& tv, WorkCount& wc) {
+    const double tmin = sc.t0, tmax = sc.t1;
+    const V3 inv = tv.inv;
+    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+    const uint32_t rec = tv.cur & 0x3fffffffu;
+    if (COUNT) wc.interior++;
+    double e0, e1;
+    bool h0, h1;
+    uint32_t r0, r1;
+    if (COMPACT) {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 4;
+        const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
+        r0 = e.x, r1 = e.y;
+        // box0 = a.x a.y a.z a.w b.x b.y ; box1 = b.z b.w c.x c.y c.z c.w  (xmin xmax ymin ymax zmin zmax)
+        h0 = slab(f32bits_to_f64(nx ? a.y : a.x), f32bits_to_f64(nx ? a.x : a.y), f32bits_to_f64(ny ? a.w : a.z),
+                  f32bits_to_f64(ny ? a.z : a.w), f32bits_to_f64(nz ? b.y : b.x), f32bits_to_f64(nz ? b.x : b.y), o,
+                  inv, tmin, tmax, e0);
+        h1 = slab(f32bits_to_f64(nx ? b.w : b.z), f32bits_to_f64(nx ? b.z : b.w), f32bits_to_f64(ny ? c.y : c.x),
+                  f32bits_to_f64(ny ? c.x : c.y), f32bits_to_f64(nz ? c.w : c.z), f32bits_to_f64(nz ? c.z : c.w), o,
+                  inv, tmin, tmax, e1);
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6];
+        r0 = q6.x, r1 = q6.y;
+        const double x0 = f64_from(q0.x, q0.y), x1 = f64_from(q0.z, q0.w);
+        const double y0 = f64_from(q1.x, q1.y), y1 = f64_from(q1.z, q1.w);
+        const double z0 = f64_from(q2.x, q2.y), z1 = f64_from(q2.z, q2.w);
+        h0 = slab(nx ? x1 : x0, nx ? x0 : x1, ny ? y1 : y0, ny ? y0 : y1, nz ? z1 : z0, nz ? z0 : z1, o, inv, tmin,
+                  tmax, e0);
+        const double u0 = f64_from(q3.x, q3.y), u1 = f64_from(q3.z, q3.w);
+        const double v0 = f64_from(q4.x, q4.y), v1 = f64_from(q4.z, q4.w);
+        const double w0 = f64_from(q5.x, q5.y), w1 = f64_from(q5.z, q5.w);
+        h1 = slab(nx ? u1 : u0, nx ? u0 : u1, ny ? v1 : v0, ny ? v0 : v1, nz ? w1 : w0, nz ? w0 : w1, o, inv, tmin,
+                  tmax, e1);
+    }
+    // a direct leaf child is not box-tested by the reference (bvh.rs:297, :302)
+    const bool s0 = (r0 >> 30) == REF_SINGLE, s1 = (r1 >> 30) == REF_SINGLE;
+    h0 = s0 || (h0 && !(e0 > tv.best_t));
+    h1 = s1 || (h1 && !(e1 > tv.best_t));
+    e0 = s0 ? tmin : e0;
+    e1 = s1 ? tmin : e1;
+    if (h0 && h1) {
+        const bool swap = e1 < e0;
+        stack[tv.sp * 64] = swap ? r0 : r1;
+        tv.sp++;
+        tv.cur = swap ? r1 : r0;
+    } else if (h0 || h1) {
+        tv.cur = h0 ? r0 : r1;
+    } else {
+        trav_pop(stack, tv);
+    }
+}
+
+// One leaf reference: its 1..4 primitives in DFS order, then pop.
+template <bool COMPACT, bool COUNT>
+RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, Trav& tv, WorkCount& wc) {
+    const double tmin = sc.t0, tmax = sc.t1;
+    const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
+    const uint32_t count = (tv.cur & 3u) + 1u;
+    if (COUNT) wc.leaf_prims = count;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t p = first + k;
+        const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
+        if (COUNT) {
+            const uint32_t kind = r.tag() & 3u;
+            if (kind == PRIM_TRIANGLE) wc.tri++;
+            else if (kind == PRIM_SPHERE) wc.sphere++;
+            else wc.plane++;
+        }
+        double t;
+        if (prim_intersect<COMPACT>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
+            if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {    // bvh.rs:62
+                tv.best_t = t;
+                tv.best_prim = p;
+            }
+        }
+    }
+    trav_pop(stack, tv);
+}
+
+RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
+
 template <bool COMPACT, bool COUNT>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
-    const double tmin = sc.t0, tmax = sc.t1;
-    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    double entry;
-    if (!slab(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, inv,
-              tmin, tmax, entry))
-        return false;
-    bool found = false;
-    double best_t = tmax;
-    uint32_t best_prim = 0xffffffffu;
-    int sp = 0;
-    uint32_t cur = sc.root_ref;
-    for (;;) {
-        if ((cur >> 30) == REF_INTERIOR) {
-            const uint32_t rec = cur & 0x3fffffffu;
-            if (COUNT) wc.interior++;
-            double b0[6], b1[6];
-            uint32_t r0, r1;
-            if (COMPACT) {
-                const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 4;
-                const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
-                b0[0] = (double)__uint_as_float(a.x), b0[1] = (double)__uint_as_float(a.y);
-                b0[2] = (double)__uint_as_float(a.z), b0[3] = (double)__uint_as_float(a.w);
-                b0[4] = (double)__uint_as_float(b.x), b0[5] = (double)__uint_as_float(b.y);
-                b1[0] = (double)__uint_as_float(b.z), b1[1] = (double)__uint_as_float(b.w);
-                b1[2] = (double)__uint_as_float(c.x), b1[3] = (double)__uint_as_float(c.y);
-                b1[4] = (double)__uint_as_float(c.z), b1[5] = (double)__uint_as_float(c.w);
-                r0 = e.x, r1 = e.y;
-            } else {
-                const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
-                const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6];
-                b0[0] = f64_from(q0.x, q0.y), b0[1] = f64_from(q0.z, q0.w);
-                b0[2] = f64_from(q1.x, q1.y), b0[3] = f64_from(q1.z, q1.w);
-                b0[4] = f64_from(q2.x, q2.y), b0[5] = f64_from(q2.z, q2.w);
-                b1[0] = f64_from(q3.x, q3.y), b1[1] = f64_from(q3.z, q3.w);
-                b1[2] = f64_from(q4.x, q4.y), b1[3] = f64_from(q4.z, q4.w);
-                b1[4] = f64_from(q5.x, q5.y), b1[5] = f64_from(q5.z, q5.w);
-                r0 = q6.x, r1 = q6.y;
-            }
-            double e0 = tmin, e1 = tmin;
-            bool h0 = true, h1 = true;
-            if ((r0 >> 30) != REF_SINGLE) {
-                h0 = slab(b0[0], b0[1], b0[2], b0[3], b0[4], b0[5], o, inv, tmin, tmax, e0);
-                if (e0 > best_t) h0 = false;
-            }
-            if ((r1 >> 30) != REF_SINGLE) {
-                h1 = slab(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5], o, inv, tmin, tmax, e1);
-                if (e1 > best_t) h1 = false;
-            }
-            if (h0 && h1) {
-                const bool swap = e1 < e0;
-                stack[sp * 64] = swap ? r0 : r1;
-                sp++;
-                cur = swap ? r1 : r0;
-                continue;
-            } else if (h0) {
-                cur = r0;
-                continue;
-            } else if (h1) {
-                cur = r1;
-                continue;
-            }
-        } else {
-            const uint32_t first = (cur & 0x3fffffffu) >> 2;
-            const uint32_t count = (cur & 3u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                const uint32_t p = first + k;
-                const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
-                if (COUNT) {
-                    const uint32_t kind = r.tag() & 3u;
-                    if (kind == PRIM_TRIANGLE) wc.tri++;
-                    else if (kind == PRIM_SPHERE) wc.sphere++;
-                    else wc.plane++;
-                }
-                double t;
-                if (prim_intersect<COMPACT>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
-                    if (!found || t < best_t || (t == best_t && p < best_prim)) {  // bvh.rs:62
-                        found = true;
-                        best_t = t;
-                        best_prim = p;
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * 64];
+    Trav tv;
+    trav_init(sc, o, d, tv);
+    while (tv.cur != TRAV_DONE) {
+        if (trav_at_interior(tv))
+            trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
+        else
+            trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }
-    t_hit = best_t;
-    prim_hit = best_prim;
-    return found;
+    t_hit = tv.best_t;
+    prim_hit = tv.best_prim;
+    return tv.best_prim != 0xffffffffu;
 }
 
 // ---------------------------------------------------------------- materials

@@ -84,7 +84,9 @@ struct Counters {
     unsigned long long rays, paths, nan_pixels, neg_pixels;
     unsigned long long interior_visits, tri_tests, sphere_tests, plane_tests, escaped_paths;
     unsigned long long queue_head;  // work queue (items)
-    unsigned long long pad[6];
+    // lane-utilisation diagnostics (count_work only): *_wave counts executions of a
+    // phase by a wave x 64, *_lane the lanes that were active in it
+    unsigned long long step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
 };
 
 struct RenderDev {

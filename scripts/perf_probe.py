@@ -21,10 +21,12 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False):
     img, st = rayrs_amd.render(scene, cam, min(spp, 4), mb, sample_chunk=chunk)  # warm
     img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, count_work=count)
     mr = st['rays'] / st['kernel_ms'] / 1e3
-    print(f"cfg={cfg} level={level} {w}x{h}x{spp} chunk={chunk} build={tb:.1f}s prims={info['n_prims']} depth={info['depth']} compact={info['compact']} "
-          f"rays={st['rays']} kernel={st['kernel_ms']:.1f}ms total={st['total_ms']:.1f}ms Mray/s={mr:.1f} rays/path={st['rays']/st['paths']:.2f}", flush=True)
+    print(f"cfg={cfg} {w}x{h}x{spp} chunk={chunk} Mray/s={mr:.1f} kernel={st['kernel_ms']:.1f}ms rays={st['rays']}", flush=True)
     if count:
-        print({k: st[k] for k in ('interior_visits','tri_tests','sphere_tests','plane_tests','escaped_paths')})
+        prims = st['tri_tests'] + st['sphere_tests'] + st['plane_tests']
+        print(f"  visits/ray={st['interior_visits']/st['rays']:.1f} prims/ray={prims/st['rays']:.2f} | lane utilisation: "
+              f"interior {st['step_lane']/max(st['step_wave'],1)/1:.2f} leaf {st['inner_wave']/max(st['leaf_wave'],1):.2f} "
+              f"shade {st['shade_lane']/max(st['shade_wave'],1):.2f} | wave-phases/ray*64: int {st['step_wave']/st['rays']:.2f} leaf {st['leaf_wave']/st['rays']:.2f} shade {st['shade_wave']/st['rays']:.2f}", flush=True)
     return st
 
 if __name__ == "__main__":
@@ -35,6 +37,10 @@ if __name__ == "__main__":
     if what in ("all", "c4"):
         run(4, 1024, 1024, 16)
     if what in ("all", "c3"):
-        run(3, 1024, 1024, 16, count=True)
+        run(3, 1024, 1024, 16)
     if what in ("all", "c5"):
-        run(5, 1024, 1024, 8, count=True)
+        run(5, 1024, 1024, 64)
+    if what == "u5":
+        run(5, 1024, 1024, 16, count=True)
+    if what == "u2":
+        run(2, 1024, 1024, 16, count=True)
