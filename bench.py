@@ -3,17 +3,18 @@
 configuration (configs[4]: floor + 1,310,720-triangle mesh, 2048x2048, 1024 spp,
 50 bounces), on N GPUs of one node.
 
-One step = one full frame: every 8x8 image tile of this rank traced by the
-persistent gfx950 kernel, the per-pixel resolve, and (N > 1) one RCCL reduce of
-the f32x3 framebuffer to rank 0.  Tiles are interleaved over ranks (tile t ->
+One step = one full frame: every 8x8 image tile of this rank pushed through the
+gfx950 path pipeline (persistent traversal kernel + hit/miss kernels, one round
+per bounce), the per-pixel resolve, and (N > 1) one RCCL reduce of the f32x3
+framebuffer to rank 0.  Tiles are interleaved over ranks (tile t ->
 rank t % N), the scene is replicated, total work is fixed: strong scaling.
 `value` = BVH queries of all ranks / max-over-ranks wall time (scene build,
 upload and file I/O excluded -- the region the reference times, main.rs:59-100).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline     -- algorithmic bytes of the trace kernel per launch (from the
-                  kernel's own traversal counters on the flattened layout)
-                  / its HIP-event duration, against the 8 TB/s HBM peak;
+  roofline     -- algorithmic bytes of the traversal kernel per launch (from the
+                  kernel's own counters on the flattened layout) / its average
+                  HIP-event duration, against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed
                   traversal over a pointer tree, rayrs-lib's algorithm) timed on
                   this box's host cores on a bounded band of the same frame.
@@ -30,15 +31,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def algorithmic_bytes(stats, info, n_pixels, n_items):
-    """bytes the traversal must fetch on the flattened layout
-    (one record per interior visit / primitive test), 4 texels per escaped
-    path, the per-item partial sums (written by the trace kernel, read by the
-    resolve) and the framebuffer write."""
+def algorithmic_bytes(stats, info):
+    """bytes the traversal kernel must move on the flattened layout:
+    one record per interior visit and per primitive test, plus, per BVH query, the
+    ray it reads from the path pool (origin + direction, 48 B), the result it
+    writes back (t + primitive, 12 B) and the slot's state byte (read + write)."""
     return (stats["interior_visits"] * info["node_bytes"]
             + (stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"]) * info["prim_bytes"]
-            + stats["escaped_paths"] * 4 * 16
-            + n_items * 24)
+            + stats["rays"] * (48 + 12 + 2))
+
+
+def effective_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def main():
@@ -52,7 +64,7 @@ def main():
     ap.add_argument("--sample-chunk", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -147,18 +159,17 @@ def main():
         rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
         cst = rayrs_amd.render_finish(scene)
         assert cst["rays"] == st["rays"], "counting launch traced a different frame"
-        n_tiles = ((W + 7) // 8) * ((H + 7) // 8)
-        n_local = (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
-        chunk = spp if (args.sample_chunk == 0 or args.sample_chunk >= spp) else args.sample_chunk
-        n_items = n_local * ((spp + chunk - 1) // chunk) * 64
-        abytes = algorithmic_bytes(cst, info, H * W, n_items)
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        # the dominant kernel is the traversal kernel, launched once per path round
+        launches = st["kernel_launches"]
+        abytes = algorithmic_bytes(cst, info) / launches          # per launch
+        avg_ms = sum(kernel_ms) / len(kernel_ms) / launches       # per launch, HIP events on the render stream
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "trace_kernel", "kernel_ms": round(avg_ms, 3),
+                    "kernel": "wf_trav_kernel", "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
+                    "kernel_share_of_step": round(sum(kernel_ms) / len(kernel_ms) / (max_elapsed / args.steps * 1e3), 3),
                     "algorithmic_bytes_per_launch": int(abytes),
-                    "bytes_per_ray": round(abytes / max(cst["rays"], 1), 1),
+                    "bytes_per_ray": round(abytes * launches / max(cst["rays"], 1), 1),
                     "interior_visits_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
                     "prim_tests_per_ray": round((cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"])
                                                 / max(cst["rays"], 1), 2)}
@@ -167,7 +178,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle
-        ncores = os.cpu_count() or 1
+        ncores = effective_cores()
         t0 = time.time()
         osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, hdri, builder=1)
         ocam = _oracle.OracleCamera(*cam_args)

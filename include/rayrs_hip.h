@@ -200,8 +200,10 @@ typedef struct {
     /* lane-utilisation diagnostics (count_work only); each *_wave value is summed over
      * all 64 lanes of the waves that executed the phase, *_lane over the active lanes */
     uint64_t step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
-    double kernel_ms;       /* HIP-event time of the trace kernel on its stream */
-    double total_ms;        /* trace + resolve */
+    double kernel_ms;       /* summed HIP-event time of the traversal kernel's launches on its stream */
+    double total_ms;        /* all kernels of the render: path rounds + resolve */
+    uint64_t kernel_launches; /* launches of the traversal kernel (= path rounds) */
+    double trace_ms;        /* all path rounds (gen + traversal + hit + miss kernels) */
 } rayrs_render_stats;
 
 /* Renders into a HOST buffer of y_pixels*x_pixels*3 elements (row-major,

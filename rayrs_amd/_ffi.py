@@ -61,7 +61,8 @@ class RenderStats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64), ("escaped_paths", C.c_uint64),
                 ("step_wave", C.c_uint64), ("step_lane", C.c_uint64), ("inner_wave", C.c_uint64),
                 ("leaf_wave", C.c_uint64), ("shade_wave", C.c_uint64), ("shade_lane", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
+                ("trace_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -10,6 +11,7 @@
 #include "../../include/rayrs_hip.h"
 #include "kernels.h"
 #include "scene_host.hpp"
+#include "wavefront.h"
 
 using namespace rayrs;
 
@@ -53,8 +55,16 @@ struct rayrs_scene {
     bool pending = false;
     bool last_count = false;
     int cu_count = 0;
-    int blocks_per_cu = 0;
+    int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
     uint64_t device_bytes = 0;
+    // path pool and queues of the wavefront pipeline
+    WfDev wf = {};
+    void* wf_block = nullptr;    // one allocation holding rays, paths and the six queues
+    uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
+    uint32_t rounds = 0;
+    uint32_t timed_rounds = 0;
 };
 
 static void push_triangle(ObjectList& l, Vec3 p1, Vec3 p2, Vec3 p3, uint32_t surf) {
@@ -207,7 +217,14 @@ static void scene_free_device(rayrs_scene* s) {
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->wf_block) (void)hipFree(s->wf_block);
+    if (s->wf.ctl) (void)hipFree(s->wf.ctl);
+    if (s->h_live) (void)hipHostFree(s->h_live);
     for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->ev_batch)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->ev_trav)
         if (e) (void)hipEventDestroy(e);
 }
 
@@ -237,8 +254,11 @@ static int scene_upload(rayrs_scene* s) {
     s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_rgba.size() * sizeof(float);
     const uint32_t depth = f.depth ? f.depth : 1;
-    HIP_TRY(trace_occupancy(f.compact, depth, &s->blocks_per_cu));
+    HIP_TRY(wf_trav_occupancy(f.compact, depth, &s->blocks_per_cu));
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    HIP_TRY(hipMalloc((void**)&s->wf.ctl, sizeof(WfCtl)));
+    HIP_TRY(hipHostMalloc((void**)&s->h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    for (auto& e : s->ev_batch) HIP_TRY(hipEventCreate(&e));
     return RAYRS_OK;
 }
 
@@ -390,21 +410,96 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const SceneDev sc = make_scene_dev(scene);
     const CameraDev cam = make_camera_dev(camera);
 
+    // ---- path pool: enough slots to fill the chip, few enough that every slot
+    // works through many items (the tail of a render is one item long)
+    uint64_t np64 = rp.total_items / 8;
+    const uint64_t np_min = 8ull * 256ull * (uint64_t)scene->cu_count * (uint64_t)scene->blocks_per_cu;
+    if (np64 < np_min) np64 = np_min;
+    if (np64 > (1ull << 23)) np64 = 1ull << 23;
+    if (const char* env = getenv("RAYRS_POOL_SLOTS")) {
+        const long long v = atoll(env);
+        if (v > 0) np64 = (uint64_t)v;
+    }
+    if (np64 > rp.total_items) np64 = rp.total_items;
+    const uint32_t live = (uint32_t)np64;
+    np64 = (np64 + 1023ull) & ~1023ull;  // whole windows
+    const uint32_t np = (uint32_t)np64;
+    if (np > scene->wf.np || !scene->wf_block) {
+        if (scene->wf_block) HIP_TRY(hipFree(scene->wf_block));
+        scene->wf_block = nullptr;
+        scene->wf.np = 0;
+        const size_t bytes = (size_t)np * (sizeof(RaySlot) + sizeof(PathSlot) + 1);
+        HIP_TRY(hipMalloc(&scene->wf_block, bytes));
+        uint8_t* p = static_cast<uint8_t*>(scene->wf_block);
+        scene->wf.paths = reinterpret_cast<PathSlot*>(p);
+        p += (size_t)np * sizeof(PathSlot);
+        scene->wf.rays = reinterpret_cast<RaySlot*>(p);
+        p += (size_t)np * sizeof(RaySlot);
+        scene->wf.state = p;
+        scene->wf.np = np;
+    }
+    WfDev wf = scene->wf;
+    wf.np = np;
+
+    const bool compact = scene->flat.compact;
+    const bool count = params->count_work != 0;
+    const uint32_t trav_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->blocks_per_cu;
+    uint32_t flat_blocks = (np / 1024u + 3u) / 4u;  // one wave per window
+    const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
+    if (flat_blocks > flat_cap) flat_blocks = flat_cap;
+
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
+    scene->rounds = 0;
+    scene->timed_rounds = 0;
     if (rp.total_items > 0) {
-        const uint64_t wanted = (rp.total_items / 64 + 3) / 4;
-        uint64_t resident = (uint64_t)scene->cu_count * (uint64_t)scene->blocks_per_cu;
-        if (resident < 1) resident = 1;
-        const uint32_t blocks = (uint32_t)(wanted < resident ? wanted : resident);
-        HIP_TRY(launch_trace(scene->flat.compact, params->count_work != 0, sc, cam, rp, blocks, stream));
+        HIP_TRY(wf_launch_init(wf, live, stream));
+        HIP_TRY(wf_launch_gen(cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
+        // Rounds are enqueued in batches; the live-slot count of batch b is read
+        // back while batch b+1 is already queued, so the GPU never waits for the host.
+        constexpr uint32_t BATCH = 16;
+        constexpr uint32_t MAX_TIMED = 8192;
+        scene->h_live[0] = scene->h_live[1] = 1;
+        uint32_t it = 0;
+        for (uint32_t b = 0;; b++) {
+            for (uint32_t k = 0; k < BATCH; k++, it++) {
+                const bool timed = it < MAX_TIMED;
+                if (timed) {
+                    while (scene->ev_trav.size() < 2 * (size_t)(it + 1)) {
+                        hipEvent_t e;
+                        HIP_TRY(hipEventCreate(&e));
+                        scene->ev_trav.push_back(e);
+                    }
+                    HIP_TRY(hipEventRecord(scene->ev_trav[2 * it], stream));
+                }
+                HIP_TRY(wf_launch_trav(compact, count, sc, rp, wf, trav_blocks, stream));
+                if (timed) {
+                    HIP_TRY(hipEventRecord(scene->ev_trav[2 * it + 1], stream));
+                    scene->timed_rounds = it + 1;
+                }
+                HIP_TRY(wf_launch_hit(compact, sc, cam, rp, wf, flat_blocks, stream));
+                HIP_TRY(wf_launch_miss(sc, cam, rp, wf, flat_blocks, stream));
+            }
+            HIP_TRY(hipMemcpyAsync(&scene->h_live[b & 1u], &wf.ctl->live_slots, sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(scene->ev_batch[b & 1u], stream));
+            if (b > 0) {
+                HIP_TRY(hipEventSynchronize(scene->ev_batch[(b - 1u) & 1u]));
+                if (scene->h_live[(b - 1u) & 1u] == 0u) break;
+            }
+            if (it > (1u << 26)) {
+                g_last_error = "path rounds did not terminate";
+                return RAYRS_HIP_ERROR;
+            }
+        }
+        scene->rounds = it;
     }
     HIP_TRY(hipEventRecord(scene->ev[1], stream));
     HIP_TRY(launch_resolve(cam, rp, stream));
     HIP_TRY(hipEventRecord(scene->ev[2], stream));
     scene->last_stream = stream;
     scene->pending = true;
-    scene->last_count = params->count_work != 0;
+    scene->last_count = count;
     return RAYRS_OK;
 }
 
@@ -432,9 +527,19 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->leaf_wave = c.leaf_wave, stats->shade_wave = c.shade_wave, stats->shade_lane = c.shade_lane;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
-        stats->kernel_ms = ms;
+        stats->trace_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[2]));
         stats->total_ms = ms;
+        double trav = 0.0;
+        for (uint32_t r = 0; r < scene->timed_rounds; r++) {
+            HIP_TRY(hipEventElapsedTime(&ms, scene->ev_trav[2 * r], scene->ev_trav[2 * r + 1]));
+            trav += ms;
+        }
+        // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
+        if (scene->timed_rounds && scene->rounds > scene->timed_rounds)
+            trav *= (double)scene->rounds / (double)scene->timed_rounds;
+        stats->kernel_ms = trav;
+        stats->kernel_launches = scene->rounds;
     }
     return RAYRS_OK;
 }

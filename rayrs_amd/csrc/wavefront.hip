@@ -1,0 +1,488 @@
+// wavefront.hip -- the radiance integrator as a stream of paths through three
+// gfx950 kernels per round:
+//
+//   trav_kernel   persistent waves, one BVH query per lane, lanes refilled from the
+//                 pool as queries finish; per-lane stack in LDS   (bvh.rs:391-415)
+//   hit_kernel    Material::evaluate + emission + Russian roulette (lib.rs:528-547)
+//   miss_kernel   Scene::background                               (lib.rs:555)
+// When a path ends in the hit or miss kernel the same lane adds the sample to the
+// item's sum and starts the item's next sample (or takes the next item from the
+// device-wide counter) and emits its primary ray (main.rs:67-79, lib.rs:202-210);
+// gen_kernel does that once for the initial fill of the pool.
+//
+// A slot is one (pixel, sample-chunk) item with at most one path in flight, so the
+// samples of an item are summed in order, exactly as the reference's per-pixel loop
+// does.  Every slot carries a one-byte state; a kernel takes a window of 1024
+// consecutive slots, compacts the slots that are in its state into a list in LDS
+// (__ballot + popcount rank) and works through the list 64 at a time, so its waves
+// run with all lanes on the same code.  There are no global queues and no atomics
+// on the data path (a single-word atomic counter saturates near 90 updates/us on
+// this chip; the first version of this file, which pushed every slot through global
+// queues, spent most of its time there).  Kernel boundaries on one stream order the
+// state changes; no in-kernel cross-CU hand-off is needed.
+#include <hip/hip_runtime.h>
+
+#include "device_path.h"
+#include "kernels.h"
+#include "wavefront.h"
+
+namespace rayrs {
+
+constexpr uint32_t WINDOW = 1024;  // slots per window = 64 lanes x 16 state bytes
+
+// Builds, in LDS, the list of slots of window `win` whose state is `want`.
+// Returns the list length (wave-uniform).  list entries are offsets inside the window.
+RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint16_t* list) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    const uint32_t base = win * WINDOW;
+    // np is a multiple of WINDOW (the host rounds the pool up), so the 16-byte load is in range
+    const uint4 st = reinterpret_cast<const uint4*>(wf.state + base)[lane];
+    const uint32_t words[4] = {st.x, st.y, st.z, st.w};
+    uint32_t count = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t s = (words[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+        const bool m = s == (uint32_t)want;
+        const unsigned long long mask = __ballot(m);
+        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = (uint16_t)(lane * 16u + (uint32_t)j);
+        count += (uint32_t)__popcll(mask);
+    }
+    return count;
+}
+
+RR_DEV void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
+                          uint32_t& s_end) {
+    const uint32_t pit = item & 63u;
+    const uint32_t tc = item >> 6;
+    const uint32_t chunk = tc % rp.nchunks;
+    const uint32_t tile = (tc / rp.nchunks) * rp.tile_ranks + rp.tile_rank;
+    row = (tile / rp.tiles_x) * 8u + (pit >> 3);
+    col = (tile % rp.tiles_x) * 8u + (pit & 7u);
+    s_begin = chunk * rp.chunk;
+    s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
+}
+
+// ------------------------------------------------------------------- init
+
+__global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        WfCtl* c = wf.ctl;
+        c->next_window = 0;
+        c->live_slots = live;
+        c->next_item = 0ull;
+    }
+    if (i >= wf.np) return;
+    wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
+    wf.paths[i].has_item = 0;
+}
+
+// -------------------------------------------------------------------- gen
+
+// For every lane with `want`: the slot's path has ended (or it never had one).
+// Write out the item if its samples are all done, take the next sample -- or the
+// next item from the device-wide counter -- and emit its primary ray; the slot
+// becomes READY, or DEAD when the counter has run out.  Called by all 64 lanes
+// (it uses wave ballots); lanes without `want` only take part in those.
+RR_DEV void next_sample(bool want, uint32_t slot, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+                        unsigned long long& n_paths, uint32_t& retired) {
+    WfCtl* ctl = wf.ctl;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    PathSlot* ps = wf.paths + slot;
+    bool has_item = false;
+    uint32_t item = 0, s_cur = 0, s_end = 0, row = 0, col = 0;
+    if (want) {
+        has_item = ps->has_item != 0u;
+        item = ps->item;
+        s_cur = ps->s_cur;
+        s_end = ps->s_end;
+    }
+    // an item whose samples are all done is written out (its sum goes to the resolve kernel)
+    if (want && has_item && s_cur >= s_end) {
+        double* dst = rp.partial + (size_t)item * 3;
+        dst[0] = ps->acc[0];
+        dst[1] = ps->acc[1];
+        dst[2] = ps->acc[2];
+        has_item = false;
+    }
+    // slots without an item take the next ones from the device-wide item counter
+    bool need = want && !has_item;
+    bool fresh = false;
+    bool dead = false;
+    unsigned long long need_mask = __ballot(need);
+    while (need_mask != 0ull) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)need_mask) - 1u;
+        unsigned long long first = 0;
+        if (lane == leader) first = atomicAdd(&ctl->next_item, (unsigned long long)__popcll(need_mask));
+        const uint32_t flo = (uint32_t)__shfl((int)(uint32_t)first, (int)leader);
+        const uint32_t fhi = (uint32_t)__shfl((int)(uint32_t)(first >> 32), (int)leader);
+        first = ((unsigned long long)fhi << 32) | flo;
+        if (need) {
+            const unsigned long long mine = first + (unsigned long long)__popcll(need_mask & lanemask_lt);
+            if (mine >= rp.total_items) {
+                dead = true;
+                need = false;
+            } else {
+                item = (uint32_t)mine;
+                uint32_t s_begin;
+                item_geometry(rp, item, row, col, s_begin, s_end);
+                s_cur = s_begin;
+                if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
+                    // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
+                    double* dst = rp.partial + (size_t)item * 3;
+                    dst[0] = dst[1] = dst[2] = 0.0;
+                    if (row < cam.H && col < cam.W) n_paths += s_end - s_begin;
+                } else {
+                    has_item = true;
+                    fresh = true;
+                    need = false;
+                }
+            }
+        }
+        need_mask = __ballot(need);
+    }
+    if (want && dead) {
+        ps->has_item = 0;
+        wf.state[slot] = WF_DEAD;
+        retired++;
+    }
+    if (want && has_item) {
+        if (!fresh) {
+            uint32_t s_begin_unused, s_end_unused;
+            item_geometry(rp, item, row, col, s_begin_unused, s_end_unused);
+        }
+        // start the slot's next sample (main.rs:68-76)
+        Rng rng;
+        rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
+        rng.draw = 0;
+        V3 o, d;
+        // image origin is upper left, camera origin lower right (main.rs:74-75)
+        primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
+        RaySlot* rs = wf.rays + slot;
+        rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
+        rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
+        rs->bounce = 1;
+        ps->thr[0] = ps->thr[1] = ps->thr[2] = 1.0;
+        ps->light[0] = ps->light[1] = ps->light[2] = 0.0;
+        ps->key = rng.key;
+        ps->draw = rng.draw;
+        ps->s_cur = s_cur + 1u;
+        if (fresh) {
+            ps->has_item = 1;
+            ps->item = item;
+            ps->s_end = s_end;
+            ps->acc[0] = ps->acc[1] = ps->acc[2] = 0.0;
+        }
+        wf.state[slot] = WF_READY;
+        n_paths++;
+    }
+}
+
+// Initial fill of the pool (every live slot starts IDLE).
+__global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp, WfDev wf) {
+    __shared__ uint16_t lists[4][WINDOW];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint16_t* list = lists[threadIdx.x >> 6];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_windows = wf.np / WINDOW;
+    unsigned long long n_paths = 0;
+    uint32_t retired = 0;
+    for (uint32_t win = wave; win < n_windows; win += n_waves) {
+        const uint32_t count = compact_window(wf, win, WF_IDLE, list);
+        for (uint32_t k = 0; k < count; k += 64u) {
+            const bool valid = k + lane < count;
+            const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
+            next_sample(valid, slot, cam, rp, wf, n_paths, retired);
+        }
+    }
+    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
+    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+}
+
+// ------------------------------------------------------------------- trav
+
+// Fewer traversing lanes than this and the wave retires its finished queries and
+// takes new rays from its window list.
+constexpr int WF_REFILL_MIN = 52;
+// A leaf phase runs once this many lanes stand on a leaf (or none is on an interior record).
+constexpr int WF_LEAF_MIN = 24;
+
+template <bool COMPACT, bool COUNT>
+__global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+    extern __shared__ uint32_t lds_dyn[];
+    WfCtl* ctl = wf.ctl;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    // dynamic LDS: 4 stacks of stack_depth x 64 words, then 4 window lists of WINDOW uint16
+    uint32_t* stack = lds_dyn + (size_t)wave * sc.stack_depth * 64u + lane;
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)sc.stack_depth * 64u) + wave * WINDOW;
+    const uint32_t n_windows = wf.np / WINDOW;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+
+    uint32_t list_pos = 0, list_len = 0, list_win = 0;  // wave-uniform
+    bool no_more = false;                               // wave-uniform: window cursor ran off the end
+
+    bool active = false, pending = false;
+    uint32_t slot = 0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    Trav tv;
+    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
+    WorkCount wc{0, 0, 0, 0, 0};
+    unsigned long long n_rays = 0;
+    unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
+
+    for (;;) {
+        const bool at_int = active && trav_at_interior(tv);
+        const bool at_leaf = active && !trav_at_interior(tv);
+        const int n_int = __popcll(__ballot(at_int));
+        const int n_leaf = __popcll(__ballot(at_leaf));
+        if ((n_int + n_leaf < WF_REFILL_MIN && !no_more) || n_int + n_leaf == 0) {
+            // ---- retire finished queries: result and new state to the slot
+            if (pending) {
+                RaySlot* rs = wf.rays + slot;
+                rs->t = tv.best_t;
+                rs->prim = tv.best_prim;
+                wf.state[slot] = tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
+                pending = false;
+            }
+            if (no_more) break;  // only reached with no query in flight
+            // ---- idle lanes take rays from the wave's window list
+            bool need = !active;
+            unsigned long long need_mask = __ballot(need);
+            while (need_mask != 0ull) {
+                if (list_pos >= list_len) {
+                    uint32_t w = 0;
+                    if (lane == 0) w = atomicAdd(&ctl->next_window, 1u);
+                    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+                    if (w >= n_windows) {
+                        no_more = true;
+                        break;
+                    }
+                    list_win = w;
+                    list_len = compact_window(wf, w, WF_READY, list);
+                    list_pos = 0;
+                    continue;
+                }
+                const uint32_t avail = list_len - list_pos;
+                const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+                if (need && rank < avail) {
+                    slot = list_win * WINDOW + (uint32_t)list[list_pos + rank];
+                    const RaySlot* rs = wf.rays + slot;
+                    o = mk(rs->o[0], rs->o[1], rs->o[2]);
+                    d = mk(rs->d[0], rs->d[1], rs->d[2]);
+                    n_rays++;
+                    trav_init(sc, o, d, tv);
+                    if (tv.cur == TRAV_DONE)
+                        pending = true;  // missed the root box: retired at the next refill
+                    else
+                        active = true;
+                    need = false;
+                }
+                const uint32_t wanted = (uint32_t)__popcll(need_mask);
+                list_pos += wanted < avail ? wanted : avail;
+                need_mask = __ballot(need);
+            }
+            if (__ballot(active || pending) == 0ull && no_more) break;
+            continue;
+        }
+        if (n_leaf >= WF_LEAF_MIN || n_int == 0) {
+            // ---- leaf phase: every lane standing on a leaf tests its primitives
+            if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
+            if (at_leaf) {
+                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                if (tv.cur == TRAV_DONE) active = false, pending = true;
+            }
+        } else {
+            // ---- interior phase: one record for every lane standing on one
+            if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
+            if (at_int) {
+                trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
+                if (tv.cur == TRAV_DONE) active = false, pending = true;
+            }
+        }
+    }
+
+    Counters* c = rp.counters;
+    if (n_rays) atomicAdd(&c->rays, n_rays);
+    if (COUNT) {
+        if (wc.interior) atomicAdd(&c->interior_visits, (unsigned long long)wc.interior);
+        if (wc.tri) atomicAdd(&c->tri_tests, (unsigned long long)wc.tri);
+        if (wc.sphere) atomicAdd(&c->sphere_tests, (unsigned long long)wc.sphere);
+        if (wc.plane) atomicAdd(&c->plane_tests, (unsigned long long)wc.plane);
+        atomicAdd(&c->step_wave, u_int_wave), atomicAdd(&c->step_lane, u_int_lane);
+        atomicAdd(&c->inner_wave, u_leaf_lane), atomicAdd(&c->leaf_wave, u_leaf_wave);
+    }
+}
+
+// -------------------------------------------------------------------- hit
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+    __shared__ uint16_t lists[4][WINDOW];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint16_t* list = lists[threadIdx.x >> 6];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_windows = wf.np / WINDOW;
+    unsigned long long n_paths = 0;
+    uint32_t retired = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
+    for (uint32_t win = wave; win < n_windows; win += n_waves) {
+        const uint32_t count = compact_window(wf, win, WF_HIT, list);
+        for (uint32_t k = 0; k < count; k += 64u) {
+            const bool valid = k + lane < count;
+            const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
+            bool ended = false;
+            if (valid) {
+            RaySlot* rs = wf.rays + slot;
+            PathSlot* ps = wf.paths + slot;
+            const V3 o = mk(rs->o[0], rs->o[1], rs->o[2]);
+            const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
+            const double t = rs->t;
+            const uint32_t prim = rs->prim;
+            const uint32_t bounce = rs->bounce;
+            V3 thr = mk(ps->thr[0], ps->thr[1], ps->thr[2]);
+            V3 light = mk(ps->light[0], ps->light[1], ps->light[2]);
+            Rng rng{ps->key, ps->draw};
+            // lib.rs:528-551
+            const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
+            const V3 position = v_add(o, v_scale(d, t));
+            const V3 normal = prim_normal<COMPACT>(rec, position);
+            const V3 view = v_unit(v_scale(d, -1.0));
+            const SurfaceDev* surf = sc.surfaces + (rec.tag() >> 8);
+            const Scatter ev = material_evaluate(surf, normal, view, rng);
+            if (ev.scatter) {
+                light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
+                thr = v_mul(thr, ev.color);
+                const double p = rr_max(rr_max(thr.x, thr.y), thr.z);
+                if (rng.next() > p) {
+                    ended = true;
+                } else if (bounce >= rp.max_bounces) {  // loop bound of lib.rs:525; lib.rs:559
+                    ended = true;
+                } else {
+                    thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
+                    rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
+                    rs->d[0] = ev.dir.x, rs->d[1] = ev.dir.y, rs->d[2] = ev.dir.z;
+                    rs->bounce = bounce + 1u;
+                    ps->thr[0] = thr.x, ps->thr[1] = thr.y, ps->thr[2] = thr.z;
+                    ps->light[0] = light.x, ps->light[1] = light.y, ps->light[2] = light.z;
+                    ps->draw = rng.draw;
+                    wf.state[slot] = WF_READY;
+                }
+            } else {
+                ended = true;  // lib.rs:550
+            }
+            if (ended) {  // radiance() returns `light`; main.rs:69 adds it to the pixel
+                ps->acc[0] += light.x;
+                ps->acc[1] += light.y;
+                ps->acc[2] += light.z;
+            }
+            }
+            next_sample(ended, slot, cam, rp, wf, n_paths, retired);
+        }
+    }
+    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
+    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+}
+
+// ------------------------------------------------------------------- miss
+
+__global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+    __shared__ uint16_t lists[4][WINDOW];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint16_t* list = lists[threadIdx.x >> 6];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_windows = wf.np / WINDOW;
+    unsigned long long n_escaped = 0, n_paths = 0;
+    uint32_t retired = 0;
+    for (uint32_t win = wave; win < n_windows; win += n_waves) {
+        const uint32_t count = compact_window(wf, win, WF_MISS, list);
+        n_escaped += count;
+        for (uint32_t k = 0; k < count; k += 64u) {
+            const bool valid = k + lane < count;
+            const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
+            if (valid) {
+            const RaySlot* rs = wf.rays + slot;
+            PathSlot* ps = wf.paths + slot;
+            const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
+            const V3 thr = mk(ps->thr[0], ps->thr[1], ps->thr[2]);
+            const V3 light = mk(ps->light[0], ps->light[1], ps->light[2]);
+            const V3 result = v_add(light, v_mul(thr, background(sc, d)));  // lib.rs:555
+            ps->acc[0] += result.x;
+            ps->acc[1] += result.y;
+            ps->acc[2] += result.z;
+            }
+            next_sample(valid, slot, cam, rp, wf, n_paths, retired);
+        }
+    }
+    if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
+    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
+    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+}
+
+// ----------------------------------------------------------- launch glue
+
+static inline uint32_t trav_lds_bytes(uint32_t stack_depth) { return 4u * 64u * stack_depth * 4u + 4u * WINDOW * 2u; }
+
+hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, wf, live);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, cam, rp, wf);
+    return hipGetLastError();
+}
+
+template <bool COMPACT, bool COUNT>
+static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
+                                hipStream_t stream) {
+    const uint32_t lds = trav_lds_bytes(sc.stack_depth);
+    hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
+                          uint32_t blocks, hipStream_t stream) {
+    if (compact)
+        return count ? launch_trav_t<true, true>(sc, rp, wf, blocks, stream)
+                     : launch_trav_t<true, false>(sc, rp, wf, blocks, stream);
+    return count ? launch_trav_t<false, true>(sc, rp, wf, blocks, stream)
+                 : launch_trav_t<false, false>(sc, rp, wf, blocks, stream);
+}
+
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu) {
+    const uint32_t lds = trav_lds_bytes(stack_depth);
+    const void* fn = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, false>)
+                             : reinterpret_cast<const void*>(&wf_trav_kernel<false, false>);
+    const void* fnc = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, true>)
+                              : reinterpret_cast<const void*>(&wf_trav_kernel<false, true>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (compact) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false>, 256, lds);
+}
+
+hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+                         uint32_t blocks, hipStream_t stream) {
+    if (compact)
+        hipLaunchKernelGGL(wf_hit_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else
+        hipLaunchKernelGGL(wf_hit_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_miss(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+                          uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_miss_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    return hipGetLastError();
+}
+
+}  // namespace rayrs

@@ -20,8 +20,8 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False):
     info = scene.info()
     img, st = rayrs_amd.render(scene, cam, min(spp, 4), mb, sample_chunk=chunk)  # warm
     img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, count_work=count)
-    mr = st['rays'] / st['kernel_ms'] / 1e3
-    print(f"cfg={cfg} {w}x{h}x{spp} chunk={chunk} Mray/s={mr:.1f} kernel={st['kernel_ms']:.1f}ms rays={st['rays']}", flush=True)
+    mr = st['rays'] / st['trace_ms'] / 1e3
+    print(f"cfg={cfg} {w}x{h}x{spp} chunk={chunk} Mray/s={mr:.1f} trace={st['trace_ms']:.1f}ms trav={st['kernel_ms']:.1f}ms rounds={st['kernel_launches']} rays={st['rays']}", flush=True)
     if count:
         prims = st['tri_tests'] + st['sphere_tests'] + st['plane_tests']
         print(f"  visits/ray={st['interior_visits']/st['rays']:.1f} prims/ray={prims/st['rays']:.2f} | lane utilisation: "
@@ -32,15 +32,16 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "c2"):
-        run(2, 1024, 1024, 16)
-        run(2, 1024, 1024, 64, chunk=16)
+        run(2, 1024, 1024, 256, chunk=16)
     if what in ("all", "c4"):
         run(4, 1024, 1024, 16)
     if what in ("all", "c3"):
-        run(3, 1024, 1024, 16)
+        run(3, 1024, 1024, 256, chunk=16)
     if what in ("all", "c5"):
-        run(5, 1024, 1024, 64)
+        run(5, 1024, 1024, 256, chunk=16)
     if what == "u5":
-        run(5, 1024, 1024, 16, count=True)
+        run(5, 1024, 1024, 128, chunk=16, count=True)
     if what == "u2":
-        run(2, 1024, 1024, 16, count=True)
+        run(2, 1024, 1024, 128, chunk=16, count=True)
+    if what == "big5":
+        run(5, 2048, 2048, 64, chunk=16)
