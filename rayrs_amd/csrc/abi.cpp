@@ -394,6 +394,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.n_local_tiles = (uint32_t)n_local;
     rp.total_items = n_local * rp.nchunks * 64ull;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
+    rp.refill_min = 52;
+    rp.leaf_min = 24;
+    if (const char* env = getenv("RAYRS_REFILL_MIN")) rp.refill_min = (uint32_t)atoi(env);
+    if (const char* env = getenv("RAYRS_LEAF_MIN")) rp.leaf_min = (uint32_t)atoi(env);
     rp.out_format = params->out_format;
     rp.out = out_device;
     rp.counters = scene->d_counters;

@@ -6,10 +6,6 @@
 
 namespace rayrs {
 
-hipError_t launch_trace(bool compact, bool count, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
-                        uint32_t blocks, hipStream_t stream);
-hipError_t trace_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu);
-uint32_t trace_lds_bytes(uint32_t stack_depth);
 hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream);
 
 hipError_t launch_test_math(int fn, const double* x, const double* y, uint64_t n, double* out, hipStream_t stream);

@@ -1,232 +1,11 @@
-// kernels.hip -- gfx950 kernels: the persistent path-tracing kernel, the resolve
-// kernel and the single-function self-test kernels.
-//
-// trace_kernel: persistent waves.  A work item is (8x8 tile, sample chunk, pixel
-// in tile); 64 consecutive items are the 64 pixels of one tile for one chunk of
-// samples, so the lanes of a wave start from neighbouring pixels.  Each lane owns
-// one item at a time and runs its samples one after the other (a finished path is
-// replaced in place by the lane's next sample, so no lane waits for another
-// lane's path), and a lane whose item is finished takes the next unclaimed item
-// from the wave's pool: __ballot finds the idle lanes, the popcount of the lower
-// lanes ranks them, and the pool is refilled 64 items at a time with one atomic
-// on the device-wide queue head.  The per-lane traversal stack lives in LDS
-// (entry k of lane l at word k*64 + l: conflict-free).  Path state is f64 in
-// registers.
+// kernels.hip -- the resolve kernel (per-pixel sum of the item sums) and the
+// single-function self-test kernels.  The path pipeline itself is wavefront.hip.
 #include <hip/hip_runtime.h>
 
 #include "device_path.h"
 #include "kernels.h"
 
 namespace rayrs {
-
-// Lane states of the path state machine.
-constexpr uint32_t ST_IDLE = 0;   // no path: needs its item's next sample, a new item, or is out of work
-constexpr uint32_t ST_TRAV = 1;   // a BVH query is in progress (Trav holds its state)
-constexpr uint32_t ST_SHADE = 2;  // the query has finished and waits for the shading phase
-
-// Shading runs for the waiting lanes once fewer than TRAV_MIN lanes of the wave
-// are still traversing; until then the traversing lanes keep taking macro steps.
-constexpr int TRAV_MIN = 40;
-// A leaf phase runs once this many lanes stand on a leaf (or none is on an interior record).
-constexpr int LEAF_MIN = 16;
-
-template <bool COMPACT, bool COUNT>
-__global__ void __launch_bounds__(256, 2) trace_kernel(SceneDev sc, CameraDev cam, RenderDev rp) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* stack = lds_stack + (size_t)wave * sc.stack_depth * 64u + lane;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-
-    // wave-uniform pool of claimed items
-    unsigned long long pool_next = 0, pool_end = 0;
-
-    // lane state
-    uint32_t state = ST_IDLE;
-    bool dead = false, has_item = false;
-    uint32_t item = 0, row = 0, col = 0, s_cur = 0, s_end = 0, bounce = 0;
-    double acc_x = 0, acc_y = 0, acc_z = 0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1), light = mk(0, 0, 0);
-    Rng rng{0, 0};
-    Trav tv;
-    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
-    unsigned long long n_rays = 0, n_paths = 0, n_escaped = 0;
-    WorkCount wc{0, 0, 0, 0, 0};
-    unsigned long long wc_int = 0, wc_tri = 0, wc_sph = 0, wc_pln = 0;
-    unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0, u_shade_wave = 0,
-                       u_shade_lane = 0;
-
-    for (;;) {
-        // wave-uniform scheduling decision
-        const bool at_int = state == ST_TRAV && trav_at_interior(tv);
-        const bool at_leaf = state == ST_TRAV && !trav_at_interior(tv);
-        const int n_int = __popcll(__ballot(at_int));
-        const int n_leaf = __popcll(__ballot(at_leaf));
-        if (n_int + n_leaf >= TRAV_MIN) {
-            if (n_leaf >= LEAF_MIN || n_int == 0) {
-                // ---- leaf phase: every lane standing on a leaf tests its primitives
-                if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
-                if (at_leaf) {
-                    trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-                    if (tv.cur == TRAV_DONE) state = ST_SHADE;
-                }
-            } else {
-                // ---- interior phase: one record for every lane standing on one
-                if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
-                if (at_int) {
-                    trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
-                    if (tv.cur == TRAV_DONE) state = ST_SHADE;
-                }
-            }
-            continue;
-        }
-        {
-
-            if (COUNT) {
-                if (__ballot(state == ST_SHADE) != 0ull) u_shade_wave++;
-                if (state == ST_SHADE) u_shade_lane++;
-            }
-            // ---- shade the finished queries: the rest of one radiance() iteration (lib.rs:526-556)
-            if (state == ST_SHADE) {
-                bool finished = false;
-                V3 result = light;
-                if (tv.best_prim != 0xffffffffu) {
-                    const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, tv.best_prim);
-                    const V3 position = v_add(o, v_scale(d, tv.best_t));
-                    const V3 normal = prim_normal<COMPACT>(rec, position);
-                    const V3 view = v_unit(v_scale(d, -1.0));
-                    const SurfaceDev* surf = sc.surfaces + (rec.tag() >> 8);
-                    const Scatter ev = material_evaluate(surf, normal, view, rng);
-                    if (ev.scatter) {
-                        light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
-                        thr = v_mul(thr, ev.color);
-                        const double p = rr_max(rr_max(thr.x, thr.y), thr.z);
-                        if (rng.next() > p) {
-                            finished = true;
-                            result = light;
-                        } else {
-                            thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
-                            o = position;
-                            d = ev.dir;
-                        }
-                    } else {
-                        finished = true;  // lib.rs:550
-                        result = light;
-                    }
-                } else {
-                    n_escaped++;
-                    finished = true;
-                    result = v_add(light, v_mul(thr, background(sc, d)));  // lib.rs:555
-                }
-                if (!finished && bounce >= rp.max_bounces) {  // loop bound of lib.rs:525; lib.rs:559
-                    finished = true;
-                    result = light;
-                }
-                if (finished) {
-                    acc_x += result.x;  // main.rs:69
-                    acc_y += result.y;
-                    acc_z += result.z;
-                    state = ST_IDLE;
-                } else {
-                    bounce++;
-                    n_rays++;
-                    trav_init(sc, o, d, tv);
-                    state = tv.cur == TRAV_DONE ? ST_SHADE : ST_TRAV;
-                }
-            }
-            // ---- A: an item whose samples are all done is written out
-            if (state == ST_IDLE && has_item && s_cur >= s_end) {
-                double* dst = rp.partial + (size_t)item * 3;
-                dst[0] = acc_x;
-                dst[1] = acc_y;
-                dst[2] = acc_z;
-                has_item = false;
-            }
-            // ---- B: idle lanes take items from the wave's pool (ballot + rank)
-            bool need = state == ST_IDLE && !has_item && !dead;
-            unsigned long long need_mask = __ballot(need);
-            while (need_mask != 0ull) {
-                if (pool_next >= pool_end) {
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&rp.counters->queue_head, 64ull);
-                    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-                    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-                    base = ((unsigned long long)bhi << 32) | blo;
-                    if (base >= rp.total_items) {
-                        if (need) dead = true;
-                        break;
-                    }
-                    pool_next = base;
-                    pool_end = base + 64ull < rp.total_items ? base + 64ull : rp.total_items;
-                }
-                const uint32_t avail = (uint32_t)(pool_end - pool_next);
-                const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
-                if (need && rank < avail) {
-                    item = (uint32_t)(pool_next + rank);
-                    need = false;
-                    has_item = true;
-                    const uint32_t pit = item & 63u;
-                    const uint32_t tc = item >> 6;
-                    const uint32_t chunk = tc % rp.nchunks;
-                    const uint32_t tile = (tc / rp.nchunks) * rp.tile_ranks + rp.tile_rank;
-                    row = (tile / rp.tiles_x) * 8u + (pit >> 3);
-                    col = (tile % rp.tiles_x) * 8u + (pit & 7u);
-                    s_cur = chunk * rp.chunk;
-                    s_end = s_cur + rp.chunk < rp.spp ? s_cur + rp.chunk : rp.spp;
-                    if (row >= cam.H || col >= cam.W) s_cur = s_end;  // padding pixel of an edge tile
-                    acc_x = acc_y = acc_z = 0.0;
-                }
-                const uint32_t wanted = (uint32_t)__popcll(need_mask);
-                pool_next += wanted < avail ? wanted : avail;
-                need_mask = __ballot(need);
-            }
-            // ---- C: start the lane's next sample (main.rs:68-76)
-            if (state == ST_IDLE && has_item && s_cur < s_end) {
-                rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
-                rng.draw = 0;
-                // image origin is upper left, camera origin lower right (main.rs:74-75)
-                primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
-                thr = mk(1.0, 1.0, 1.0);
-                light = mk(0.0, 0.0, 0.0);
-                s_cur++;
-                n_paths++;
-                if (rp.max_bounces == 0) {  // radiance() with an empty loop returns zeros
-                    state = ST_IDLE;
-                } else {
-                    bounce = 1;
-                    n_rays++;
-                    trav_init(sc, o, d, tv);
-                    state = tv.cur == TRAV_DONE ? ST_SHADE : ST_TRAV;
-                }
-            }
-            // all lanes out of work and nothing in flight
-            if (__ballot(has_item || state != ST_IDLE) == 0ull) break;
-        }
-        // when few lanes are traversing, let them advance once per scheduling round as well
-        if (state == ST_TRAV) {
-            if (trav_at_interior(tv))
-                trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
-            else
-                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-            if (tv.cur == TRAV_DONE) state = ST_SHADE;
-        }
-    }
-    if (COUNT) wc_int += wc.interior, wc_tri += wc.tri, wc_sph += wc.sphere, wc_pln += wc.plane;
-
-    Counters* c = rp.counters;
-    if (n_rays) atomicAdd(&c->rays, n_rays);
-    if (n_paths) atomicAdd(&c->paths, n_paths);
-    if (COUNT) {
-        if (n_escaped) atomicAdd(&c->escaped_paths, n_escaped);
-        if (wc_int) atomicAdd(&c->interior_visits, wc_int);
-        if (wc_tri) atomicAdd(&c->tri_tests, wc_tri);
-        if (wc_sph) atomicAdd(&c->sphere_tests, wc_sph);
-        if (wc_pln) atomicAdd(&c->plane_tests, wc_pln);
-        atomicAdd(&c->step_wave, u_int_wave), atomicAdd(&c->step_lane, u_int_lane);
-        atomicAdd(&c->inner_wave, u_leaf_lane), atomicAdd(&c->leaf_wave, u_leaf_wave);
-        atomicAdd(&c->shade_wave, u_shade_wave), atomicAdd(&c->shade_lane, u_shade_lane);
-    }
-}
 
 // Adds the chunk sums of each pixel in chunk order, applies pixel / spp
 // (main.rs:89; Div<f64> = multiply by 1/spp) and writes the framebuffer.
@@ -266,43 +45,6 @@ __global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev r
 // ------------------------------------------------------------ launch glue
 
 static inline uint32_t lds_bytes_for(uint32_t stack_depth) { return 4u * 64u * stack_depth * 4u; }
-
-template <bool COMPACT, bool COUNT>
-static hipError_t launch_trace_t(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, uint32_t blocks,
-                                 hipStream_t stream) {
-    const uint32_t lds = lds_bytes_for(sc.stack_depth);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<COMPACT, COUNT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((trace_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, cam, rp);
-    return hipGetLastError();
-}
-
-hipError_t launch_trace(bool compact, bool count, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
-                        uint32_t blocks, hipStream_t stream) {
-    if (compact) {
-        return count ? launch_trace_t<true, true>(sc, cam, rp, blocks, stream)
-                     : launch_trace_t<true, false>(sc, cam, rp, blocks, stream);
-    }
-    return count ? launch_trace_t<false, true>(sc, cam, rp, blocks, stream)
-                 : launch_trace_t<false, false>(sc, cam, rp, blocks, stream);
-}
-
-uint32_t trace_lds_bytes(uint32_t stack_depth) { return lds_bytes_for(stack_depth); }
-
-hipError_t trace_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu) {
-    const uint32_t lds = lds_bytes_for(stack_depth);
-    if (compact) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<true, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<true, false>, 256, lds);
-    }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<false, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false>, 256, lds);
-}
 
 hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream) {
     const uint64_t n = (uint64_t)rp.n_local_tiles * 64u;

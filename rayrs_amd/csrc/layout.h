@@ -83,7 +83,6 @@ struct CameraDev {
 struct Counters {
     unsigned long long rays, paths, nan_pixels, neg_pixels;
     unsigned long long interior_visits, tri_tests, sphere_tests, plane_tests, escaped_paths;
-    unsigned long long queue_head;  // work queue (items)
     // lane-utilisation diagnostics (count_work only): *_wave counts executions of a
     // phase by a wave x 64, *_lane the lanes that were active in it
     unsigned long long step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
@@ -98,6 +97,7 @@ struct RenderDev {
     uint32_t n_local_tiles;
     uint32_t out_format;
     uint64_t total_items;  // n_local_tiles * nchunks * 64
+    uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
     double* partial;       // total_items * 3
     Counters* counters;
     void* out;

@@ -204,11 +204,10 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
 
 // ------------------------------------------------------------------- trav
 
-// Fewer traversing lanes than this and the wave retires its finished queries and
-// takes new rays from its window list.
-constexpr int WF_REFILL_MIN = 52;
-// A leaf phase runs once this many lanes stand on a leaf (or none is on an interior record).
-constexpr int WF_LEAF_MIN = 24;
+// Scheduling thresholds (RenderDev::refill_min / leaf_min): with fewer traversing
+// lanes than refill_min the wave retires its finished queries and takes new rays
+// from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
+// none is on an interior record).
 
 template <bool COMPACT, bool COUNT>
 __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
@@ -239,7 +238,7 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
         const bool at_leaf = active && !trav_at_interior(tv);
         const int n_int = __popcll(__ballot(at_int));
         const int n_leaf = __popcll(__ballot(at_leaf));
-        if ((n_int + n_leaf < WF_REFILL_MIN && !no_more) || n_int + n_leaf == 0) {
+        if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
             // ---- retire finished queries: result and new state to the slot
             if (pending) {
                 RaySlot* rs = wf.rays + slot;
@@ -288,7 +287,7 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
             if (__ballot(active || pending) == 0ull && no_more) break;
             continue;
         }
-        if (n_leaf >= WF_LEAF_MIN || n_int == 0) {
+        if (n_leaf >= (int)rp.leaf_min || n_int == 0) {
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
