@@ -90,7 +90,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import rayrs_amd
-    from rayrs_amd import procedural, scenes
+    from rayrs_amd import procedural, scenes, tiles
 
     cam_args, objs, heur, spp, max_bounces = scenes.config(args.config)
     reduced = False
@@ -116,7 +116,7 @@ def main():
         fb.zero_()
         rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
         if use_dist:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            tiles.reduce_framebuffer(fb, dst=0)
         return rayrs_amd.render_finish(scene)
 
     def fence():

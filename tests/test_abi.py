@@ -1,0 +1,117 @@
+"""The C-ABI library without a GPU: it loads, exports every symbol include/rayrs_hip.h
+declares, validates arguments like the reference's assert!s and never aborts."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rayrs_amd
+from rayrs_amd import _ffi, procedural, scenes
+from rayrs_amd.api import Axis, BvhHeuristic, Emission, Material, Object
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDRI = procedural.make_hdri(32, 16)
+NR, DARK = Material.NoReflect(), Emission.Dark()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rayrs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rayrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = _ffi.lib()
+    names = declared_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(L, name), name
+    assert sorted(_ffi.SYMBOLS) == names
+
+
+def test_product_never_loads_the_oracle():
+    """The shipped library must not depend on anything under oracle/."""
+    import subprocess
+    out = subprocess.run(["ldd", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rayrs_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in text and "_oracle" not in text and "librayrs_oracle" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/librayrs_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _ffi.lib()
+
+
+def test_strerror_and_status_codes():
+    L = _ffi.lib()
+    assert L.rayrs_strerror(0) == b"ok"
+    assert b"assert" in L.rayrs_strerror(-1)
+    assert L.rayrs_objects_create(None) == -1
+
+
+@pytest.mark.parametrize("bad", [
+    lambda: Object.sphere(0.0, (0, 0, 0), NR, DARK),                                   # geometry.rs:97
+    lambda: Object.plane(Axis.Z, 1., -1., 1., -1., 0., NR, DARK),                      # geometry.rs:205
+    lambda: Object.sphere(1.0, (0, 0, 0), Material.LambertianDiffuse((1.1, 0, 0)), DARK),  # material.rs:609
+    lambda: Object.sphere(1.0, (0, 0, 0), Material.CookTorranceGlass((1, 1, 1), 0.0, 1.45), DARK),  # :865
+    lambda: Object.sphere(1.0, (0, 0, 0), Material.Glass((1, 1, 1), 0.0), DARK),       # :675
+    lambda: Object.sphere(1.0, (0, 0, 0), NR, Emission.new(-1.0, (1, 1, 1))),          # :1068
+])
+def test_object_asserts_become_value_errors(bad):
+    with pytest.raises(ValueError):
+        rayrs_amd.Scene([bad()], 1e-6, 1e6, BvhHeuristic.Sah(1000), HDRI, device=-1)
+
+
+def test_scene_and_camera_asserts():
+    s = Object.sphere(1.0, (0, 0, 0), NR, DARK)
+    for zn, zf in ((-1.0, 1e6), (1.0, 1.0), (2.0, 1.0)):                               # lib.rs:234-235
+        with pytest.raises(ValueError):
+            rayrs_amd.Scene([s], zn, zf, BvhHeuristic.Midpoint, HDRI, device=-1)
+    with pytest.raises(ValueError):                                                     # bvh.rs:229
+        rayrs_amd.Scene([], 1e-6, 1e6, BvhHeuristic.Midpoint, HDRI, device=-1)
+    for fov, w, h, la in ((0., 1., 1., (0, 0, 1)), (180., 1., 1., (0, 0, 1)), (90., 0., 1., (0, 0, 1)),
+                          (90., 1., -1., (0, 0, 1)), (90., 1., 1., (0, 0, 0))):          # lib.rs:108-111
+        with pytest.raises(ValueError):
+            rayrs_amd.Camera((0, 0, 0), (0, 1, 0), la, fov, w, h, 100)
+
+
+def test_camera_matches_reference_doc_test():
+    cam = rayrs_amd.Camera((1, 1, 1), (0, 1, 0), (0, 0, 0), 90., 20., 10., 90)          # lib.rs:141-173
+    assert cam.x_pixels() == 4580 and cam.y_pixels() == 2290
+    import _oracle
+    oc = _oracle.OracleCamera((1, 1, 1), (0, 1, 0), (0, 0, 0), 90., 20., 10., 90)
+    for f in ("origin", "e_x", "e_y", "z"):
+        assert list(getattr(cam.desc, f)) == list(getattr(oc.desc, f))
+
+
+def test_host_only_scene_cannot_render_but_can_be_inspected():
+    cam_args, objs, heur = scenes.diffuse_single_sphere()
+    sc = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+    info = sc.info()
+    assert info["n_objects"] == 2 and info["n_prims"] == 2 and info["n_interior"] == 0
+    cam = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 32, 32))
+    with pytest.raises(_ffi.RayrsError) as e:
+        rayrs_amd.render(sc, cam, 1)
+    assert e.value.status == -4
+
+
+def test_mesh_index_out_of_range_is_rejected():
+    verts = np.zeros((3, 3), dtype=np.float32)
+    idx = np.array([[0, 1, 3]], dtype=np.uint32)
+    with pytest.raises(ValueError):
+        rayrs_amd.Scene(Object.from_triangles(verts, idx, NR, DARK), 1e-6, 1e6, BvhHeuristic.Midpoint, HDRI, device=-1)
+
+
+def test_box_geom_keeps_the_reference_face_order():
+    """lib.rs:444-505: X, XRev, ZRev, Z, YRev, Y -- and both Y faces at lower_left.y."""
+    faces = Object.box_geom((0, 1, 2), (3, 4, 5), NR, DARK)
+    assert [f.axis for f in faces] == [Axis.X, Axis.XRev, Axis.ZRev, Axis.Z, Axis.YRev, Axis.Y]
+    assert faces[4].pos == 1.0 and faces[5].pos == 1.0

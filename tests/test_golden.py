@@ -1,0 +1,116 @@
+"""Committed golden vectors (tests/golden/golden_v1.npz, made by make_golden.py).
+
+CPU: the oracle must still reproduce every vector bit for bit (any change of the
+oracle or of the numeric contract shows up here).  GPU: the kernels, called
+through the C ABI, must reproduce the same vectors bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _oracle
+from golden import make_golden as G
+from rayrs_amd import scenes
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+HDRI = GOLD["hdri"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_fixture_inputs_are_reproducible():
+    from rayrs_amd import procedural
+    assert np.array_equal(HDRI, procedural.make_hdri(*G.HDRI_SHAPE))
+
+
+@pytest.mark.parametrize("name", list(G.MATERIALS))
+def test_oracle_material_vectors(name):
+    n, v, k = G.material_inputs(192, 7)
+    sc, col, dr, nd = _oracle.material_evaluate(G.MATERIALS[name], n, v, k)
+    assert np.array_equal(sc, GOLD[f"mat/{name}/scattered"])
+    assert np.array_equal(nd, GOLD[f"mat/{name}/draws"])
+    assert np.array_equal(bits(col), bits(GOLD[f"mat/{name}/color"]))
+    assert np.array_equal(bits(dr), bits(GOLD[f"mat/{name}/dir"]))
+
+
+@pytest.mark.parametrize("name", list(G.SCENES))
+def test_oracle_intersections_and_frame(name):
+    cam_args, objs, heur = G.SCENES[name]()
+    o, d = G.rays(256, 11)
+    for builder in (0, 1):  # literal reference builder and the swept one
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI, builder=builder)
+        for trav in (0, 1):  # recursive reference traversal and the ordered one
+            t, obj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=trav)
+            assert np.array_equal(obj, GOLD[f"isect/{name}/obj"])
+            assert np.array_equal(bits(t), bits(GOLD[f"isect/{name}/t"]))
+    ocam = _oracle.OracleCamera(*scenes.camera_for_resolution(cam_args, G.FRAME["w"], G.FRAME["h"]))
+    img, st = osc.render(ocam, G.FRAME["spp"], G.FRAME["max_bounces"], seed=G.FRAME["seed"], traversal=1)
+    assert st["rays"] == int(GOLD[f"frame/{name}/rays"][0])
+    assert np.array_equal(bits(img), bits(GOLD[f"frame/{name}/rgb"]))
+
+
+def test_oracle_background_vectors():
+    cam_args, objs, heur = scenes.diffuse_single_sphere()
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+    assert np.array_equal(bits(osc.background(GOLD["background/dirs"])), bits(GOLD["background/rgb"]))
+    # integral texel coordinates give black (all four weights zero), SURVEY 7(h)
+    assert np.all(GOLD["background/rgb"][2] == 0.0) or np.all(GOLD["background/rgb"][3] == 0.0)
+
+
+# ------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(G.MATERIALS))
+def test_gpu_material_vectors(name):
+    from rayrs_amd import _ffi
+    n, v, k = G.material_inputs(192, 7)
+    cnt = len(k)
+    sc = np.zeros(cnt, dtype=np.int32)
+    col = np.zeros((cnt, 3))
+    dr = np.zeros((cnt, 3))
+    nd = np.zeros(cnt, dtype=np.uint32)
+    m = G.MATERIALS[name].desc()
+    _ffi.check(_ffi.lib().rayrs_test_material(0, C.byref(m), n.ctypes.data, v.ctypes.data, k.ctypes.data, cnt,
+                                              sc.ctypes.data, col.ctypes.data, dr.ctypes.data, nd.ctypes.data),
+               "rayrs_test_material")
+    hit = GOLD[f"mat/{name}/scattered"] == 1
+    assert np.array_equal(sc, GOLD[f"mat/{name}/scattered"])
+    assert np.array_equal(nd, GOLD[f"mat/{name}/draws"])
+    assert np.array_equal(bits(col[hit]), bits(GOLD[f"mat/{name}/color"][hit]))
+    assert np.array_equal(bits(dr[hit]), bits(GOLD[f"mat/{name}/dir"][hit]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(G.SCENES))
+def test_gpu_intersections_and_frame(name):
+    import rayrs_amd
+    from rayrs_amd import _ffi
+    cam_args, objs, heur = G.SCENES[name]()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    o, d = G.rays(256, 11)
+    t = np.zeros(len(o))
+    obj = np.zeros(len(o), dtype=np.int64)
+    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data,
+                                             obj.ctypes.data), "rayrs_test_intersect")
+    assert np.array_equal(obj, GOLD[f"isect/{name}/obj"])
+    assert np.array_equal(bits(t), bits(GOLD[f"isect/{name}/t"]))
+    cam = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, G.FRAME["w"], G.FRAME["h"]))
+    img, st = rayrs_amd.render(scene, cam, G.FRAME["spp"], G.FRAME["max_bounces"], seed=G.FRAME["seed"], out_f64=True)
+    assert st["rays"] == int(GOLD[f"frame/{name}/rays"][0])
+    assert np.array_equal(bits(img), bits(GOLD[f"frame/{name}/rgb"]))
+
+
+@pytest.mark.gpu
+def test_gpu_background_vectors():
+    import rayrs_amd
+    from rayrs_amd import _ffi
+    cam_args, objs, heur = scenes.diffuse_single_sphere()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    d = np.ascontiguousarray(GOLD["background/dirs"])
+    out = np.zeros_like(d)
+    _ffi.check(scene._L.rayrs_test_background(scene._h, d.ctypes.data, len(d), out.ctypes.data),
+               "rayrs_test_background")
+    assert np.array_equal(bits(out), bits(GOLD["background/rgb"]))
