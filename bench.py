@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json configs[n-1]; 5 is the headline")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only)")
     ap.add_argument("--res", type=int, default=0, help="override resolution (development only)")
-    ap.add_argument("--sample-chunk", type=int, default=64)
+    ap.add_argument("--sample-chunk", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

@@ -5,7 +5,7 @@ import numpy as np
 import rayrs_amd
 from rayrs_amd import scenes, procedural
 
-def run(cfg, w, h, spp, chunk=0, level=None, count=False):
+def run(cfg, w, h, spp, chunk=0, level=None, count=False, ranks=1):
     if level is not None:
         cam_args, objs, heur = scenes.mesh_scene(level)
         cam_args = scenes.camera_for_resolution(cam_args, w, h); mb = 50
@@ -19,9 +19,9 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False):
     cam = rayrs_amd.Camera(*cam_args)
     info = scene.info()
     img, st = rayrs_amd.render(scene, cam, min(spp, 4), mb, sample_chunk=chunk)  # warm
-    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, count_work=count)
+    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, count_work=count, tile_ranks=ranks)
     mr = st['rays'] / st['trace_ms'] / 1e3
-    print(f"cfg={cfg} {w}x{h}x{spp} chunk={chunk} Mray/s={mr:.1f} trace={st['trace_ms']:.1f}ms trav={st['kernel_ms']:.1f}ms rounds={st['kernel_launches']} rays={st['rays']}", flush=True)
+    print(f"cfg={cfg} {w}x{h}x{spp} chunk={chunk} ranks={ranks} Mray/s={mr:.1f} trace={st['trace_ms']:.1f}ms trav={st['kernel_ms']:.1f}ms rounds={st['kernel_launches']} rays={st['rays']}", flush=True)
     if count:
         prims = st['tri_tests'] + st['sphere_tests'] + st['plane_tests']
         print(f"  visits/ray={st['interior_visits']/st['rays']:.1f} prims/ray={prims/st['rays']:.2f} | lane utilisation: "
@@ -45,3 +45,6 @@ if __name__ == "__main__":
         run(2, 1024, 1024, 128, chunk=16, count=True)
     if what == "big5":
         run(5, 2048, 2048, 64, chunk=16)
+    if what == "shard8":
+        chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+        run(5, 2048, 2048, 1024, chunk=chunk, ranks=8)

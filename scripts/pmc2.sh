@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage: scripts/pmc2.sh <tag> <probe-arg> <kernel-name-pattern> "<counters pass1>" "<counters pass2>" ...
-TAG=$1; ARG=$2; PAT=$3; shift 3
+# usage: scripts/pmc2.sh <tag> <probe-arg> "<counters pass1>" "<counters pass2>" ...
+# Prints, per kernel, the sum of every counter over its dispatches (run on the GPU box via gpurun).
+TAG=$1; ARG=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -9,18 +10,23 @@ for P in "$@"; do
   i=$((i+1))
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/scripts/perf_probe.py $ARG > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done
-python - <<PY
-import csv, glob, collections
-agg = collections.defaultdict(float); n = collections.Counter()
-for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
+python - "$OUT" <<'PY'
+import csv, glob, collections, sys
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
+for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if '' in row['Kernel_Name']:
-            agg[row['Counter_Name']] += float(row['Counter_Value']); n[row['Counter_Name']] += 1
-for k in sorted(agg): print(f"{k:32s} {agg[k]:.6g}  (dispatches {n[k]})")
-tot=0
-for f in glob.glob("$OUT/p1/*/*kernel_trace.csv"):
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('rayrs::', '')[:28]
+        agg[k][row['Counter_Name']] += float(row['Counter_Value'])
+        disp[k].add(row['Dispatch_Id'])
+dur = collections.defaultdict(int)
+for f in glob.glob(out + "/p1/*/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
-        if '' in row['Kernel_Name']:
-            tot += int(row['End_Timestamp'])-int(row['Start_Timestamp'])
-print("trace_kernel total ns (pass 1):", tot)
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('rayrs::', '')[:28]
+        dur[k] += int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+for k in sorted(agg, key=lambda k: -dur[k]):
+    if not k.startswith('wf_'): continue
+    print(f"== {k}: {len(disp[k])} dispatches, {dur[k]/1e6:.1f} ms (pass 1)")
+    for c in sorted(agg[k]): print(f"   {c:30s} {agg[k][c]:.5g}")
 PY
