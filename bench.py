@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
+                    "rehearsing the N>1 path on a box with fewer GPUs than ranks")
+    ap.add_argument("--device", type=int, default=-1, help="force the HIP device of every rank (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -74,6 +77,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device >= 0:
+        local_rank = args.device
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if rank == 0:
@@ -84,7 +89,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
         dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
@@ -92,7 +100,10 @@ def main():
     import rayrs_amd
     from rayrs_amd import procedural, scenes, tiles
 
-    cam_args, objs, heur, spp, max_bounces = scenes.config(args.config)
+    # the mesh takes the route a scanned model would: written as a binary PLY, read back by the library's loader
+    import tempfile
+    ply_path = os.path.join(tempfile.gettempdir(), f"rayrs_bench_mesh_rank{rank}.ply") if args.config in (3, 5) else None
+    cam_args, objs, heur, spp, max_bounces = scenes.config(args.config, ply_path=ply_path)
     reduced = False
     if args.spp:
         spp, reduced = args.spp, True
@@ -115,9 +126,14 @@ def main():
     def step():
         fb.zero_()
         rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
-        if use_dist:
-            tiles.reduce_framebuffer(fb, dst=0)
-        return rayrs_amd.render_finish(scene)
+        if use_dist and args.backend == "nccl":
+            tiles.reduce_framebuffer(fb, dst=0)       # RCCL over xGMI, ordered after the render on this stream
+        st = rayrs_amd.render_finish(scene)
+        if use_dist and args.backend != "nccl":       # rehearsal: reduce through host memory
+            host = fb.cpu()
+            tiles.reduce_framebuffer(host, dst=0)
+            fb.copy_(host)
+        return st
 
     def fence():
         if use_dist:
@@ -137,7 +153,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_begin
 
-    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if use_dist:
         r = tot[:1].clone()
         e = tot[1:].clone()

@@ -32,7 +32,8 @@ typedef enum {
     RAYRS_HIP_ERROR = -2,   /* a HIP runtime call failed (see rayrs_last_error) */
     RAYRS_OOM = -3,
     RAYRS_NO_DEVICE = -4,   /* scene was created host-only or no GPU present */
-    RAYRS_UNSUPPORTED = -5  /* e.g. BVH deeper than the kernel's LDS stack */
+    RAYRS_UNSUPPORTED = -5, /* e.g. BVH deeper than the kernel's LDS stack */
+    RAYRS_IO_ERROR = -6     /* file missing or malformed (see rayrs_io_last_error) */
 } rayrs_status;
 
 const char* rayrs_strerror(int status);
@@ -235,6 +236,32 @@ int rayrs_test_material(int device, const rayrs_material* mat, const double* nor
                         uint32_t* draws);
 /* Scene::background for n directions. */
 int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
+
+/* ---- file formats either side of the path (host only) ---- */
+
+const char* rayrs_io_last_error(void);
+/* frees a buffer returned by one of the loaders below */
+void rayrs_buffer_free(void* p);
+
+/* PLY 1.0, ascii or binary_little_endian: element vertex {x,y,z (+ ignored properties)},
+ * element face {list vertex_indices}; polygons are fan-triangulated, winding kept.
+ * (The reference's `ply` crate is entirely commented out, ply/src/lib.rs:1-350, so this
+ * follows the public format.)  verts: nverts*3 f32, idx: ntris*3 -- feed them to
+ * rayrs_object_from_triangles_f32. */
+int rayrs_ply_load(const char* path, float** verts, uint32_t* nverts, uint32_t** idx, uint32_t* ntris);
+int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const uint32_t* idx, uint32_t ntris,
+                   int binary);
+/* wavefront_obj::load_obj_file, wavefront_obj.rs:15-45: `v x y z` / `f i j k` lines only. */
+int rayrs_obj_load(const char* path, double** verts, uint32_t* nverts, uint32_t** idx, uint32_t* ntris);
+/* Radiance .hdr: what HdrDecoder / HDREncoder do at rayrs/src/main.rs:36-41 and :113-121.
+ * rgb: w*h*3 f32, top row first. */
+int rayrs_hdr_load(const char* path, float** rgb, uint32_t* w, uint32_t* h);
+int rayrs_hdr_save(const char* path, const float* rgb, uint32_t w, uint32_t h);
+/* Image::to_raw_bytes(gamma), image.rs:193-222: clip(0,1).powf(gamma), (255.99*x) as u8.
+ * out: w*h*3 bytes; counts = {clamped, NaN, negative} pixels (image.rs:218-220). */
+int rayrs_image_to_bytes(const float* rgb, uint32_t w, uint32_t h, double gamma, uint8_t* out, uint64_t counts[3]);
+int rayrs_ppm_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h); /* image.rs:248-251 */
+int rayrs_png_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h); /* main.rs:104-110 */
 
 #ifdef __cplusplus
 }

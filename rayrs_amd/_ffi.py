@@ -21,6 +21,8 @@ SYMBOLS = [
     "rayrs_render", "rayrs_render_launch", "rayrs_render_finish",
     "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
     "rayrs_test_background",
+    "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
+    "rayrs_hdr_load", "rayrs_hdr_save", "rayrs_image_to_bytes", "rayrs_ppm_save", "rayrs_png_save",
 ]
 
 
@@ -115,6 +117,18 @@ def lib():
     L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rayrs_test_material.argtypes = [C.c_int, mp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     L.rayrs_test_background.argtypes = [vp, vp, C.c_uint64, vp]
+    L.rayrs_io_last_error.restype = C.c_char_p
+    L.rayrs_buffer_free.argtypes = [vp]
+    L.rayrs_buffer_free.restype = None
+    u32p = C.POINTER(C.c_uint32)
+    L.rayrs_ply_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, C.POINTER(vp), u32p]
+    L.rayrs_ply_save.argtypes = [C.c_char_p, vp, C.c_uint32, vp, C.c_uint32, C.c_int]
+    L.rayrs_obj_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, C.POINTER(vp), u32p]
+    L.rayrs_hdr_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, u32p]
+    L.rayrs_hdr_save.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.rayrs_image_to_bytes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_double, vp, C.POINTER(C.c_uint64)]
+    L.rayrs_ppm_save.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.rayrs_png_save.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rayrs_strerror",):
@@ -127,7 +141,7 @@ class RayrsError(RuntimeError):
     def __init__(self, status, where):
         L = lib()
         msg = L.rayrs_strerror(status).decode()
-        extra = L.rayrs_last_error().decode()
+        extra = L.rayrs_last_error().decode() if status != -6 else L.rayrs_io_last_error().decode()
         super().__init__(f"{where}: {msg} ({status})" + (f" [{extra}]" if extra else ""))
         self.status = status
 

@@ -106,6 +106,7 @@ const char* rayrs_strerror(int status) {
         case RAYRS_OOM: return "out of memory";
         case RAYRS_NO_DEVICE: return "no HIP device for this scene";
         case RAYRS_UNSUPPORTED: return "unsupported (size or depth limit)";
+        case RAYRS_IO_ERROR: return "file missing or malformed";
         default: return "unknown status";
     }
 }

@@ -102,13 +102,19 @@ def material_test():  # :276-331
 
 # ---- mesh scenes (obj_scene, test_scenes.rs:70-109, with a generated mesh)
 
-def mesh_scene(level: int, mat=None, area_light: bool = False):
+def mesh_scene(level: int, mat=None, area_light: bool = False, ply_path=None):
     """Floor + one closed mesh of 20 * 4**level triangles (+ an emissive
     rectangle).  The light is a Lambertian plane with Emission::Emissive: an
-    emitter whose material does not scatter contributes nothing (lib.rs:550)."""
+    emitter whose material does not scatter contributes nothing (lib.rs:550).
+    With ply_path the mesh is written to that PLY file and read back through the
+    library's PLY loader, which is how a real scanned model would arrive."""
     if mat is None:
         mat = Material.CookTorrance((1, 1, 1), 0.05, Fresnel.SchlickMetallic((0.722, 0.451, 0.2)))  # copper_suzanne
     verts, idx = procedural.blob_mesh(level)
+    if ply_path is not None:
+        from . import io
+        io.save_ply(ply_path, verts, idx, binary=True)
+        verts, idx = io.load_ply(ply_path)
     objs = [_floor()]
     objs += Object.from_triangles(verts, idx, mat, Emission.Dark())
     if area_light:
@@ -119,7 +125,7 @@ def mesh_scene(level: int, mat=None, area_light: bool = False):
 
 # ---- the benchmark configurations of BASELINE.json
 
-def config(n: int):
+def config(n: int, ply_path=None):
     """(camera_args, objects, heuristic, spp, max_bounces) of configs[n-1]."""
     if n == 1:  # single diffuse sphere, 256x256, 64 spp
         cam, objs, h = diffuse_single_sphere()
@@ -128,12 +134,12 @@ def config(n: int):
         cam, objs, h = cook_torrance_spheres_metallic()
         return camera_for_resolution(cam, 1024, 1024), objs, h, 256, 50
     if n == 3:  # ~70k-triangle mesh + area light, 1024x1024, 512 spp
-        cam, objs, h = mesh_scene(6, Material.LambertianDiffuse((0.8, 0.8, 0.8)), area_light=True)
+        cam, objs, h = mesh_scene(6, Material.LambertianDiffuse((0.8, 0.8, 0.8)), area_light=True, ply_path=ply_path)
         return camera_for_resolution(cam, 1024, 1024), objs, h, 512, 50
     if n == 4:  # frosted-glass spheres, max depth 32, 2048x2048, 4096 spp
         cam, objs, h = cook_torrance_spheres_frosted_glass()
         return camera_for_resolution(cam, 2048, 2048), objs, h, 4096, 32
     if n == 5:  # 1M-triangle mesh (20 * 4**8 = 1,310,720), 2048x2048, 1024 spp
-        cam, objs, h = mesh_scene(8)
+        cam, objs, h = mesh_scene(8, ply_path=ply_path)
         return camera_for_resolution(cam, 2048, 2048), objs, h, 1024, 50
     raise ValueError("config 1..5")
