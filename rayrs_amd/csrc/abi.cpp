@@ -370,6 +370,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (!scene || !camera || !params || !out_device) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
+    if (params->max_bounces > 8000u) return RAYRS_UNSUPPORTED;  // bounce and draw counters are 16-bit in the pool
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
     HIP_TRY(hipSetDevice(scene->device));
@@ -433,13 +434,15 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         if (scene->wf_block) HIP_TRY(hipFree(scene->wf_block));
         scene->wf_block = nullptr;
         scene->wf.np = 0;
-        const size_t bytes = (size_t)np * (sizeof(RaySlot) + sizeof(PathSlot) + 1);
+        const size_t bytes = (size_t)np * (sizeof(RaySlot) + sizeof(HotSlot) + sizeof(ItemSlot) + 1);
         HIP_TRY(hipMalloc(&scene->wf_block, bytes));
         uint8_t* p = static_cast<uint8_t*>(scene->wf_block);
-        scene->wf.paths = reinterpret_cast<PathSlot*>(p);
-        p += (size_t)np * sizeof(PathSlot);
         scene->wf.rays = reinterpret_cast<RaySlot*>(p);
         p += (size_t)np * sizeof(RaySlot);
+        scene->wf.hot = reinterpret_cast<HotSlot*>(p);
+        p += (size_t)np * sizeof(HotSlot);
+        scene->wf.items = reinterpret_cast<ItemSlot*>(p);
+        p += (size_t)np * sizeof(ItemSlot);
         scene->wf.state = p;
         scene->wf.np = np;
     }

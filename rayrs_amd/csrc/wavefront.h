@@ -6,30 +6,39 @@
 
 namespace rayrs {
 
+// Per-slot state, split by who touches it so that a kernel dirties only the lines it needs.
+
 // What the traversal kernel reads and writes: one 64-byte record per slot.
 struct RaySlot {
     double o[3];
     double d[3];
     double t;        // closest hit (valid when prim != 0xffffffff)
     uint32_t prim;   // DFS slot of the closest primitive, 0xffffffff = miss
-    uint32_t bounce; // number of the BVH query in flight, 1-based (loop counter of lib.rs:525)
+    uint32_t bd;     // bounce | draw << 16: number of the BVH query in flight, 1-based (loop counter of
+                     // lib.rs:525), and the path's next RNG draw index
 };
 static_assert(sizeof(RaySlot) == 64, "RaySlot");
 
-// The rest of a path and of the item (pixel, sample chunk) it belongs to: 128 bytes.
-struct PathSlot {
-    double thr[3];    // throughput, lib.rs:522
-    double light[3];  // lib.rs:523
-    double acc[3];    // sum of the item's finished samples, main.rs:67-69
+// Path state the hit/miss kernels carry from bounce to bounce.  While bounce == 1 the
+// throughput is (1,1,1) and the light (0,0,0) (lib.rs:522-523) and are not stored.
+struct HotSlot {
+    double thr[3];    // throughput
+    double light[3];
     uint64_t key;     // rr_path_key of the sample in flight
-    uint32_t draw;    // next draw index
+    uint64_t pad;
+};
+static_assert(sizeof(HotSlot) == 64, "HotSlot");
+
+// The item (pixel, sample chunk) the slot is working on; touched only when a path ends.
+struct ItemSlot {
+    double acc[3];    // sum of the item's finished samples, main.rs:67-69
     uint32_t item;
     uint32_t s_cur;   // next sample of the item to start
     uint32_t s_end;
     uint32_t has_item;
-    uint32_t pad[7];
+    uint64_t pad;
 };
-static_assert(sizeof(PathSlot) == 128, "PathSlot");
+static_assert(sizeof(ItemSlot) == 48, "ItemSlot");
 
 // slot states
 constexpr uint8_t WF_IDLE = 0;   // no path in flight: gen_kernel's input
@@ -47,7 +56,8 @@ struct WfCtl {
 
 struct WfDev {
     RaySlot* rays;
-    PathSlot* paths;
+    HotSlot* hot;
+    ItemSlot* items;
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024

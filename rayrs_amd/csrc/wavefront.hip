@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     }
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
-    wf.paths[i].has_item = 0;
+    wf.items[i].has_item = 0;
 }
 
 // -------------------------------------------------------------------- gen
@@ -85,27 +85,40 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
 // next item from the device-wide counter -- and emit its primary ray; the slot
 // becomes READY, or DEAD when the counter has run out.  Called by all 64 lanes
 // (it uses wave ballots); lanes without `want` only take part in those.
-RR_DEV void next_sample(bool want, uint32_t slot, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
-                        unsigned long long& n_paths, uint32_t& retired) {
+// The item record is passed in registers (ItemRegs): its loads are issued by the caller
+// together with the slot's other records, so that they are not one more memory round trip
+// at the end of the lane's work.
+struct ItemRegs {
+    double acc[3];
+    uint32_t item, s_cur, s_end, has_item;
+};
+
+RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
+    const ItemSlot* is = wf.items + slot;
+    ItemRegs r;
+    r.acc[0] = is->acc[0], r.acc[1] = is->acc[1], r.acc[2] = is->acc[2];
+    r.item = is->item, r.s_cur = is->s_cur, r.s_end = is->s_end, r.has_item = is->has_item;
+    return r;
+}
+
+RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const CameraDev& cam,
+                        const RenderDev& rp, const WfDev& wf, unsigned long long& n_paths, uint32_t& retired) {
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    PathSlot* ps = wf.paths + slot;
-    bool has_item = false;
-    uint32_t item = 0, s_cur = 0, s_end = 0, row = 0, col = 0;
-    if (want) {
-        has_item = ps->has_item != 0u;
-        item = ps->item;
-        s_cur = ps->s_cur;
-        s_end = ps->s_end;
-    }
+    ItemSlot* ps = wf.items + slot;
+    bool has_item = want && ir.has_item != 0u;
+    uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end, row = 0, col = 0;
     // an item whose samples are all done is written out (its sum goes to the resolve kernel)
+    bool keep_acc = false;
     if (want && has_item && s_cur >= s_end) {
         double* dst = rp.partial + (size_t)item * 3;
-        dst[0] = ps->acc[0];
-        dst[1] = ps->acc[1];
-        dst[2] = ps->acc[2];
+        dst[0] = ir.acc[0];
+        dst[1] = ir.acc[1];
+        dst[2] = ir.acc[2];
         has_item = false;
+    } else if (want && has_item) {
+        keep_acc = acc_dirty;  // the item goes on: its updated sum has to reach the slot
     }
     // slots without an item take the next ones from the device-wide item counter
     bool need = want && !has_item;
@@ -163,17 +176,16 @@ RR_DEV void next_sample(bool want, uint32_t slot, const CameraDev& cam, const Re
         RaySlot* rs = wf.rays + slot;
         rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
         rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
-        rs->bounce = 1;
-        ps->thr[0] = ps->thr[1] = ps->thr[2] = 1.0;
-        ps->light[0] = ps->light[1] = ps->light[2] = 0.0;
-        ps->key = rng.key;
-        ps->draw = rng.draw;
+        rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
+        wf.hot[slot].key = rng.key;
         ps->s_cur = s_cur + 1u;
         if (fresh) {
             ps->has_item = 1;
             ps->item = item;
             ps->s_end = s_end;
             ps->acc[0] = ps->acc[1] = ps->acc[2] = 0.0;
+        } else if (keep_acc) {
+            ps->acc[0] = ir.acc[0], ps->acc[1] = ir.acc[1], ps->acc[2] = ir.acc[2];
         }
         wf.state[slot] = WF_READY;
         n_paths++;
@@ -195,7 +207,8 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            next_sample(valid, slot, cam, rp, wf, n_paths, retired);
+            const ItemRegs ir = load_item(wf, slot);
+            next_sample(valid, slot, ir, false, cam, rp, wf, n_paths, retired);
         }
     }
     if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
@@ -335,17 +348,21 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
             bool ended = false;
+            ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
             if (valid) {
             RaySlot* rs = wf.rays + slot;
-            PathSlot* ps = wf.paths + slot;
+            HotSlot* hs = wf.hot + slot;
             const V3 o = mk(rs->o[0], rs->o[1], rs->o[2]);
             const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
             const double t = rs->t;
             const uint32_t prim = rs->prim;
-            const uint32_t bounce = rs->bounce;
-            V3 thr = mk(ps->thr[0], ps->thr[1], ps->thr[2]);
-            V3 light = mk(ps->light[0], ps->light[1], ps->light[2]);
-            Rng rng{ps->key, ps->draw};
+            const uint32_t bounce = rs->bd & 0xffffu;
+            // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
+            const V3 thr_in = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+            const V3 light_in = mk(hs->light[0], hs->light[1], hs->light[2]);
+            V3 thr = bounce > 1u ? thr_in : mk(1.0, 1.0, 1.0);
+            V3 light = bounce > 1u ? light_in : mk(0.0, 0.0, 0.0);
+            Rng rng{hs->key, rs->bd >> 16};
             // lib.rs:528-551
             const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
             const V3 position = v_add(o, v_scale(d, t));
@@ -365,22 +382,21 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
                     rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
                     rs->d[0] = ev.dir.x, rs->d[1] = ev.dir.y, rs->d[2] = ev.dir.z;
-                    rs->bounce = bounce + 1u;
-                    ps->thr[0] = thr.x, ps->thr[1] = thr.y, ps->thr[2] = thr.z;
-                    ps->light[0] = light.x, ps->light[1] = light.y, ps->light[2] = light.z;
-                    ps->draw = rng.draw;
+                    rs->bd = (bounce + 1u) | (rng.draw << 16);
+                    hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
+                    hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
                     wf.state[slot] = WF_READY;
                 }
             } else {
                 ended = true;  // lib.rs:550
             }
             if (ended) {  // radiance() returns `light`; main.rs:69 adds it to the pixel
-                ps->acc[0] += light.x;
-                ps->acc[1] += light.y;
-                ps->acc[2] += light.z;
+                ir.acc[0] += light.x;
+                ir.acc[1] += light.y;
+                ir.acc[2] += light.z;
             }
             }
-            next_sample(ended, slot, cam, rp, wf, n_paths, retired);
+            next_sample(ended, slot, ir, true, cam, rp, wf, n_paths, retired);
         }
     }
     if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
@@ -404,18 +420,23 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
+            ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
             if (valid) {
             const RaySlot* rs = wf.rays + slot;
-            PathSlot* ps = wf.paths + slot;
+            const HotSlot* hs = wf.hot + slot;
             const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
-            const V3 thr = mk(ps->thr[0], ps->thr[1], ps->thr[2]);
-            const V3 light = mk(ps->light[0], ps->light[1], ps->light[2]);
+            // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
+            const V3 thr_in = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+            const V3 light_in = mk(hs->light[0], hs->light[1], hs->light[2]);
+            const bool first = (rs->bd & 0xffffu) <= 1u;
+            const V3 thr = first ? mk(1.0, 1.0, 1.0) : thr_in;
+            const V3 light = first ? mk(0.0, 0.0, 0.0) : light_in;
             const V3 result = v_add(light, v_mul(thr, background(sc, d)));  // lib.rs:555
-            ps->acc[0] += result.x;
-            ps->acc[1] += result.y;
-            ps->acc[2] += result.z;
+            ir.acc[0] += result.x;
+            ir.acc[1] += result.y;
+            ir.acc[2] += result.z;
             }
-            next_sample(valid, slot, cam, rp, wf, n_paths, retired);
+            next_sample(valid, slot, ir, true, cam, rp, wf, n_paths, retired);
         }
     }
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
