@@ -434,15 +434,11 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         if (scene->wf_block) HIP_TRY(hipFree(scene->wf_block));
         scene->wf_block = nullptr;
         scene->wf.np = 0;
-        const size_t bytes = (size_t)np * (sizeof(RaySlot) + sizeof(HotSlot) + sizeof(ItemSlot) + 1);
+        const size_t bytes = (size_t)np * (sizeof(Slot) + 1);
         HIP_TRY(hipMalloc(&scene->wf_block, bytes));
         uint8_t* p = static_cast<uint8_t*>(scene->wf_block);
-        scene->wf.rays = reinterpret_cast<RaySlot*>(p);
-        p += (size_t)np * sizeof(RaySlot);
-        scene->wf.hot = reinterpret_cast<HotSlot*>(p);
-        p += (size_t)np * sizeof(HotSlot);
-        scene->wf.items = reinterpret_cast<ItemSlot*>(p);
-        p += (size_t)np * sizeof(ItemSlot);
+        scene->wf.slots = reinterpret_cast<Slot*>(p);
+        p += (size_t)np * sizeof(Slot);
         scene->wf.state = p;
         scene->wf.np = np;
     }

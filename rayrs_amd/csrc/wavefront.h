@@ -40,6 +40,18 @@ struct ItemSlot {
 };
 static_assert(sizeof(ItemSlot) == 48, "ItemSlot");
 
+// One slot = 192 contiguous bytes.  Random 64-byte accesses to HBM run at ~0.9 TB/s on this
+// chip against ~6 TB/s streamed (scripts/ubench/fetch_calib.hip), i.e. the number of separate
+// DRAM rows a kernel opens per slot matters more than the bytes it moves: keeping the three
+// records of a slot adjacent makes a slot one row activation per kernel.
+struct Slot {
+    RaySlot ray;
+    HotSlot hot;
+    ItemSlot item;
+    uint64_t pad[2];
+};
+static_assert(sizeof(Slot) == 192, "Slot");
+
 // slot states
 constexpr uint8_t WF_IDLE = 0;   // no path in flight: gen_kernel's input
 constexpr uint8_t WF_READY = 1;  // ray written, waiting for the traversal kernel
@@ -55,9 +67,7 @@ struct WfCtl {
 };
 
 struct WfDev {
-    RaySlot* rays;
-    HotSlot* hot;
-    ItemSlot* items;
+    Slot* slots;
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024

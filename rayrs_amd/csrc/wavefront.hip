@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     }
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
-    wf.items[i].has_item = 0;
+    wf.slots[i].item.has_item = 0;
 }
 
 // -------------------------------------------------------------------- gen
@@ -94,7 +94,7 @@ struct ItemRegs {
 };
 
 RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
-    const ItemSlot* is = wf.items + slot;
+    const ItemSlot* is = &wf.slots[slot].item;
     ItemRegs r;
     r.acc[0] = is->acc[0], r.acc[1] = is->acc[1], r.acc[2] = is->acc[2];
     r.item = is->item, r.s_cur = is->s_cur, r.s_end = is->s_end, r.has_item = is->has_item;
@@ -106,7 +106,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    ItemSlot* ps = wf.items + slot;
+    ItemSlot* ps = &wf.slots[slot].item;
     bool has_item = want && ir.has_item != 0u;
     uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end, row = 0, col = 0;
     // an item whose samples are all done is written out (its sum goes to the resolve kernel)
@@ -173,11 +173,11 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         V3 o, d;
         // image origin is upper left, camera origin lower right (main.rs:74-75)
         primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
-        RaySlot* rs = wf.rays + slot;
+        RaySlot* rs = &wf.slots[slot].ray;
         rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
         rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
         rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
-        wf.hot[slot].key = rng.key;
+        wf.slots[slot].hot.key = rng.key;
         ps->s_cur = s_cur + 1u;
         if (fresh) {
             ps->has_item = 1;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
         if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
             // ---- retire finished queries: result and new state to the slot
             if (pending) {
-                RaySlot* rs = wf.rays + slot;
+                RaySlot* rs = &wf.slots[slot].ray;
                 rs->t = tv.best_t;
                 rs->prim = tv.best_prim;
                 wf.state[slot] = tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
                 const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
                 if (need && rank < avail) {
                     slot = list_win * WINDOW + (uint32_t)list[list_pos + rank];
-                    const RaySlot* rs = wf.rays + slot;
+                    const RaySlot* rs = &wf.slots[slot].ray;
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
@@ -350,8 +350,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             bool ended = false;
             ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
             if (valid) {
-            RaySlot* rs = wf.rays + slot;
-            HotSlot* hs = wf.hot + slot;
+            RaySlot* rs = &wf.slots[slot].ray;
+            HotSlot* hs = &wf.slots[slot].hot;
             const V3 o = mk(rs->o[0], rs->o[1], rs->o[2]);
             const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
             const double t = rs->t;
@@ -422,8 +422,8 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
             ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
             if (valid) {
-            const RaySlot* rs = wf.rays + slot;
-            const HotSlot* hs = wf.hot + slot;
+            const RaySlot* rs = &wf.slots[slot].ray;
+            const HotSlot* hs = &wf.slots[slot].hot;
             const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
             // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
             const V3 thr_in = mk(hs->thr[0], hs->thr[1], hs->thr[2]);

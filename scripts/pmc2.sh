@@ -27,6 +27,5 @@ for f in glob.glob(out + "/p1/*/*kernel_trace.csv"):
         dur[k] += int(row['End_Timestamp']) - int(row['Start_Timestamp'])
 for k in sorted(agg, key=lambda k: -dur[k]):
     if not k.startswith('wf_'): continue
-    print(f"== {k}: {len(disp[k])} dispatches, {dur[k]/1e6:.1f} ms (pass 1)")
-    for c in sorted(agg[k]): print(f"   {c:30s} {agg[k][c]:.5g}")
+    print(f"== {k}: {len(disp[k])} dispatches, {dur[k]/1e6:.1f} ms (pass 1) :: " + " ".join(f"{c}={agg[k][c]:.5g}" for c in sorted(agg[k])))
 PY
