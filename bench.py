@@ -177,11 +177,21 @@ def main():
         assert cst["rays"] == st["rays"], "counting launch traced a different frame"
         # the dominant kernel is the traversal kernel, launched once per path round
         launches = st["kernel_launches"]
+        # HBM bytes per launch come from PMC passes of this same command (they cannot be collected
+        # in-process): profiles/r01_final_hbm_traffic.json, valid for the unreduced headline workload only
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+        if os.path.exists(tpath) and not reduced and args.config == 5 and world == 1 and args.sample_chunk == 16:
+            tj = json.load(open(tpath))
+            k = tj["kernels"]["wf_trav_kernel"]
+            if k["launches"] == launches:
+                traffic = k["bytes_per_launch"]
+                traffic_src = "profiles/r01_final_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, calibrated)"
         abytes = algorithmic_bytes(cst, info) / launches          # per launch
         avg_ms = sum(kernel_ms) / len(kernel_ms) / launches       # per launch, HIP events on the render stream
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "wf_trav_kernel", "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
                     "kernel_share_of_step": round(sum(kernel_ms) / len(kernel_ms) / (max_elapsed / args.steps * 1e3), 3),
                     "algorithmic_bytes_per_launch": int(abytes),
