@@ -59,7 +59,9 @@ struct rayrs_scene {
     uint64_t device_bytes = 0;
     // path pool and queues of the wavefront pipeline
     WfDev wf = {};
-    void* wf_block = nullptr;    // one allocation holding rays, paths and the six queues
+    void* wf_block = nullptr;    // one allocation holding the slot records and the state bytes
+    unsigned long long* d_wave_items = nullptr;  // per-wave reserved item ranges
+    uint32_t wave_items_cap = 0;
     uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
@@ -219,6 +221,7 @@ static void scene_free_device(rayrs_scene* s) {
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->wf_block) (void)hipFree(s->wf_block);
+    if (s->d_wave_items) (void)hipFree(s->d_wave_items);
     if (s->wf.ctl) (void)hipFree(s->wf.ctl);
     if (s->h_live) (void)hipHostFree(s->h_live);
     for (auto& e : s->ev)
@@ -451,6 +454,16 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     uint32_t flat_blocks = (np / 1024u + 3u) / 4u;  // one wave per window
     const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
     if (flat_blocks > flat_cap) flat_blocks = flat_cap;
+    // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three
+    wf.n_flat_waves = flat_blocks * 4u;
+    if (wf.n_flat_waves > scene->wave_items_cap) {
+        if (scene->d_wave_items) HIP_TRY(hipFree(scene->d_wave_items));
+        scene->d_wave_items = nullptr;
+        scene->wave_items_cap = 0;
+        HIP_TRY(hipMalloc((void**)&scene->d_wave_items, (size_t)wf.n_flat_waves * 2 * sizeof(unsigned long long)));
+        scene->wave_items_cap = wf.n_flat_waves;
+    }
+    wf.wave_items = scene->d_wave_items;
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));

@@ -71,6 +71,10 @@ struct WfDev {
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024
+    // per-wave reserved item ranges [next, end) of the gen/hit/miss kernels, which all run with
+    // the same grid (n_flat_waves waves) and give wave w the same windows
+    unsigned long long* wave_items;
+    uint32_t n_flat_waves;
 };
 
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);

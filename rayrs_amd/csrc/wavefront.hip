@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
         c->live_slots = live;
         c->next_item = 0ull;
     }
+    if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
     wf.slots[i].item.has_item = 0;
@@ -101,8 +102,33 @@ RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
     return r;
 }
 
+// A wave's private range of reserved item ids [next, end).  Items are taken from the
+// device-wide counter ITEM_RESERVE at a time (one atomic), not one batch at a time: with
+// ~10^5 batches per round finishing items, per-batch atomics on the single counter word
+// (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
+// The range lives in registers during a launch and in WfDev::wave_items between launches.
+constexpr uint32_t ITEM_RESERVE = 256;
+
+struct ItemRange {
+    unsigned long long next, end;
+};
+
+RR_DEV ItemRange load_item_range(const WfDev& wf, uint32_t wave) {
+    ItemRange r;
+    r.next = wf.wave_items[2 * (size_t)wave];
+    r.end = wf.wave_items[2 * (size_t)wave + 1];
+    return r;
+}
+RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r) {
+    if ((threadIdx.x & 63u) == 0) {
+        wf.wave_items[2 * (size_t)wave] = r.next;
+        wf.wave_items[2 * (size_t)wave + 1] = r.end;
+    }
+}
+
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const CameraDev& cam,
-                        const RenderDev& rp, const WfDev& wf, unsigned long long& n_paths, uint32_t& retired) {
+                        const RenderDev& rp, const WfDev& wf, ItemRange& range, unsigned long long& n_paths,
+                        uint32_t& retired) {
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
@@ -120,40 +146,46 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     } else if (want && has_item) {
         keep_acc = acc_dirty;  // the item goes on: its updated sum has to reach the slot
     }
-    // slots without an item take the next ones from the device-wide item counter
+    // slots without an item take the next ones from the wave's reserved range (ballot + rank),
+    // which is refilled from the device-wide counter
     bool need = want && !has_item;
     bool fresh = false;
     bool dead = false;
     unsigned long long need_mask = __ballot(need);
     while (need_mask != 0ull) {
-        const uint32_t leader = (uint32_t)__ffsll((long long)need_mask) - 1u;
-        unsigned long long first = 0;
-        if (lane == leader) first = atomicAdd(&ctl->next_item, (unsigned long long)__popcll(need_mask));
-        const uint32_t flo = (uint32_t)__shfl((int)(uint32_t)first, (int)leader);
-        const uint32_t fhi = (uint32_t)__shfl((int)(uint32_t)(first >> 32), (int)leader);
-        first = ((unsigned long long)fhi << 32) | flo;
-        if (need) {
-            const unsigned long long mine = first + (unsigned long long)__popcll(need_mask & lanemask_lt);
-            if (mine >= rp.total_items) {
-                dead = true;
-                need = false;
+        if (range.next >= range.end) {  // wave-uniform
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(&ctl->next_item, (unsigned long long)ITEM_RESERVE);
+            const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
+            const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
+            first = ((unsigned long long)fhi << 32) | flo;
+            if (first >= rp.total_items) {  // the counter has run out: these slots are done
+                if (need) dead = true;
+                break;
+            }
+            range.next = first;
+            range.end = first + ITEM_RESERVE < rp.total_items ? first + ITEM_RESERVE : rp.total_items;
+        }
+        const uint32_t avail = (uint32_t)(range.end - range.next);
+        const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+        if (need && rank < avail) {
+            item = (uint32_t)(range.next + rank);
+            uint32_t s_begin;
+            item_geometry(rp, item, row, col, s_begin, s_end);
+            s_cur = s_begin;
+            if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
+                // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
+                double* dst = rp.partial + (size_t)item * 3;
+                dst[0] = dst[1] = dst[2] = 0.0;
+                if (row < cam.H && col < cam.W) n_paths += s_end - s_begin;
             } else {
-                item = (uint32_t)mine;
-                uint32_t s_begin;
-                item_geometry(rp, item, row, col, s_begin, s_end);
-                s_cur = s_begin;
-                if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
-                    // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
-                    double* dst = rp.partial + (size_t)item * 3;
-                    dst[0] = dst[1] = dst[2] = 0.0;
-                    if (row < cam.H && col < cam.W) n_paths += s_end - s_begin;
-                } else {
-                    has_item = true;
-                    fresh = true;
-                    need = false;
-                }
+                has_item = true;
+                fresh = true;
+                need = false;
             }
         }
+        const uint32_t wanted = (uint32_t)__popcll(need_mask);
+        range.next += wanted < avail ? wanted : avail;
         need_mask = __ballot(need);
     }
     if (want && dead) {
@@ -202,15 +234,17 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
     const uint32_t n_windows = wf.np / WINDOW;
     unsigned long long n_paths = 0;
     uint32_t retired = 0;
+    ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
             const ItemRegs ir = load_item(wf, slot);
-            next_sample(valid, slot, ir, false, cam, rp, wf, n_paths, retired);
+            next_sample(valid, slot, ir, false, cam, rp, wf, range, n_paths, retired);
         }
     }
+    store_item_range(wf, wave, range);
     if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
     if (retired) atomicSub(&wf.ctl->live_slots, retired);
 }
@@ -342,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     unsigned long long n_paths = 0;
     uint32_t retired = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
+    ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_HIT, list);
         for (uint32_t k = 0; k < count; k += 64u) {
@@ -396,9 +431,10 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 ir.acc[2] += light.z;
             }
             }
-            next_sample(ended, slot, ir, true, cam, rp, wf, n_paths, retired);
+            next_sample(ended, slot, ir, true, cam, rp, wf, range, n_paths, retired);
         }
     }
+    store_item_range(wf, wave, range);
     if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
     if (retired) atomicSub(&wf.ctl->live_slots, retired);
 }
@@ -414,6 +450,7 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t n_windows = wf.np / WINDOW;
     unsigned long long n_escaped = 0, n_paths = 0;
     uint32_t retired = 0;
+    ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_MISS, list);
         n_escaped += count;
@@ -436,9 +473,10 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
             }
-            next_sample(valid, slot, ir, true, cam, rp, wf, n_paths, retired);
+            next_sample(valid, slot, ir, true, cam, rp, wf, range, n_paths, retired);
         }
     }
+    store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
     if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
     if (retired) atomicSub(&wf.ctl->live_slots, retired);
