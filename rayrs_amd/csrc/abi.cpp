@@ -451,7 +451,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->blocks_per_cu;
-    uint32_t flat_blocks = (np / 1024u + 3u) / 4u;  // one wave per window
+    uint32_t flat_blocks = (np / wf_window_slots() + 3u) / 4u;  // one wave per window
     const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
     if (flat_blocks > flat_cap) flat_blocks = flat_cap;
     // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three

@@ -77,6 +77,7 @@ struct WfDev {
     uint32_t n_flat_waves;
 };
 
+uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
 hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                          hipStream_t stream);

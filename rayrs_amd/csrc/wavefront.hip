@@ -12,7 +12,7 @@
 //
 // A slot is one (pixel, sample-chunk) item with at most one path in flight, so the
 // samples of an item are summed in order, exactly as the reference's per-pixel loop
-// does.  Every slot carries a one-byte state; a kernel takes a window of 1024
+// does.  Every slot carries a one-byte state; a kernel takes a window of 512
 // consecutive slots, compacts the slots that are in its state into a list in LDS
 // (__ballot + popcount rank) and works through the list 64 at a time, so its waves
 // run with all lanes on the same code.  There are no global queues and no atomics
@@ -28,7 +28,8 @@
 
 namespace rayrs {
 
-constexpr uint32_t WINDOW = 1024;  // slots per window = 64 lanes x 16 state bytes
+constexpr uint32_t SPL = 8;             // state bytes per lane
+constexpr uint32_t WINDOW = 64 * SPL;  // slots per window
 
 // Builds, in LDS, the list of slots of window `win` whose state is `want`.
 // Returns the list length (wave-uniform).  list entries are offsets inside the window.
@@ -36,19 +37,40 @@ RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     const uint32_t base = win * WINDOW;
-    // np is a multiple of WINDOW (the host rounds the pool up), so the 16-byte load is in range
-    const uint4 st = reinterpret_cast<const uint4*>(wf.state + base)[lane];
-    const uint32_t words[4] = {st.x, st.y, st.z, st.w};
+    // np is a multiple of 1024 (the host rounds the pool up), so the load is in range
+    uint32_t words[SPL / 4];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(wf.state + base) + lane * (SPL / 4);
+#pragma unroll
+        for (uint32_t k = 0; k < SPL / 4; k++) words[k] = src[k];
+    }
     uint32_t count = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < (int)SPL; j++) {
         const uint32_t s = (words[j >> 2] >> ((j & 3) * 8)) & 0xffu;
         const bool m = s == (uint32_t)want;
         const unsigned long long mask = __ballot(m);
-        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = (uint16_t)(lane * 16u + (uint32_t)j);
+        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = (uint16_t)(lane * SPL + (uint32_t)j);
         count += (uint32_t)__popcll(mask);
     }
     return count;
+}
+
+// Sum over the 64 lanes (every lane must call it); the result is valid in lane 0 (and all lanes).
+RR_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// One atomic per wave for a per-lane counter.
+RR_DEV void wave_atomic_add(unsigned long long* dst, unsigned long long v) {
+    const unsigned long long s = wave_sum(v);
+    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(dst, s);
 }
 
 RR_DEV void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
@@ -245,8 +267,11 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
         }
     }
     store_item_range(wf, wave, range);
-    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
-    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+    wave_atomic_add(&rp.counters->paths, n_paths);
+    {
+        const uint32_t r = (uint32_t)wave_sum(retired);
+        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
+    }
 }
 
 // ------------------------------------------------------------------- trav
@@ -268,7 +293,9 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
     const uint32_t n_windows = wf.np / WINDOW;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
 
+    constexpr uint32_t WIN_CLAIM = 1;
     uint32_t list_pos = 0, list_len = 0, list_win = 0;  // wave-uniform
+    uint32_t win_next = 0, win_end = 0;                 // wave-uniform: claimed windows not yet listed
     bool no_more = false;                               // wave-uniform: window cursor ran off the end
 
     bool active = false, pending = false;
@@ -300,15 +327,19 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
-                    uint32_t w = 0;
-                    if (lane == 0) w = atomicAdd(&ctl->next_window, 1u);
-                    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-                    if (w >= n_windows) {
-                        no_more = true;
-                        break;
+                    if (win_next >= win_end) {  // claim the next WIN_CLAIM windows with one atomic
+                        uint32_t w = 0;
+                        if (lane == 0) w = atomicAdd(&ctl->next_window, WIN_CLAIM);
+                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+                        if (w >= n_windows) {
+                            no_more = true;
+                            break;
+                        }
+                        win_next = w;
+                        win_end = w + WIN_CLAIM < n_windows ? w + WIN_CLAIM : n_windows;
                     }
-                    list_win = w;
-                    list_len = compact_window(wf, w, WF_READY, list);
+                    list_win = win_next++;
+                    list_len = compact_window(wf, list_win, WF_READY, list);
                     list_pos = 0;
                     continue;
                 }
@@ -352,14 +383,14 @@ __global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev 
     }
 
     Counters* c = rp.counters;
-    if (n_rays) atomicAdd(&c->rays, n_rays);
+    wave_atomic_add(&c->rays, n_rays);
     if (COUNT) {
-        if (wc.interior) atomicAdd(&c->interior_visits, (unsigned long long)wc.interior);
-        if (wc.tri) atomicAdd(&c->tri_tests, (unsigned long long)wc.tri);
-        if (wc.sphere) atomicAdd(&c->sphere_tests, (unsigned long long)wc.sphere);
-        if (wc.plane) atomicAdd(&c->plane_tests, (unsigned long long)wc.plane);
-        atomicAdd(&c->step_wave, u_int_wave), atomicAdd(&c->step_lane, u_int_lane);
-        atomicAdd(&c->inner_wave, u_leaf_lane), atomicAdd(&c->leaf_wave, u_leaf_wave);
+        wave_atomic_add(&c->interior_visits, wc.interior);
+        wave_atomic_add(&c->tri_tests, wc.tri);
+        wave_atomic_add(&c->sphere_tests, wc.sphere);
+        wave_atomic_add(&c->plane_tests, wc.plane);
+        wave_atomic_add(&c->step_wave, u_int_wave), wave_atomic_add(&c->step_lane, u_int_lane);
+        wave_atomic_add(&c->inner_wave, u_leaf_lane), wave_atomic_add(&c->leaf_wave, u_leaf_wave);
     }
 }
 
@@ -435,8 +466,11 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
         }
     }
     store_item_range(wf, wave, range);
-    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
-    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+    wave_atomic_add(&rp.counters->paths, n_paths);
+    {
+        const uint32_t r = (uint32_t)wave_sum(retired);
+        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
+    }
 }
 
 // ------------------------------------------------------------------- miss
@@ -478,13 +512,18 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
     }
     store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
-    if (n_paths) atomicAdd(&rp.counters->paths, n_paths);
-    if (retired) atomicSub(&wf.ctl->live_slots, retired);
+    wave_atomic_add(&rp.counters->paths, n_paths);
+    {
+        const uint32_t r = (uint32_t)wave_sum(retired);
+        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
+    }
 }
 
 // ----------------------------------------------------------- launch glue
 
 static inline uint32_t trav_lds_bytes(uint32_t stack_depth) { return 4u * 64u * stack_depth * 4u + 4u * WINDOW * 2u; }
+
+uint32_t wf_window_slots() { return WINDOW; }
 
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
     hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, wf, live);
