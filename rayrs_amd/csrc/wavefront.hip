@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
 // none is on an interior record).
 
 template <bool COMPACT, bool COUNT>
-__global__ void __launch_bounds__(256, 4) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+__global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
