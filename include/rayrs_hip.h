@@ -133,14 +133,18 @@ typedef struct {
     uint32_t n_interior;   /* two-child records */
     uint32_t n_prims;      /* leaf primitives in DFS order (== n_objects) */
     uint32_t root_ref;
-    uint32_t depth;        /* stack entries the traversal can need */
+    uint32_t depth;        /* levels of interior records */
     uint32_t compact;      /* 1 = f32 node boxes / f32 triangle vertices (exactly representable) */
     uint32_t n_surfaces;
-    uint32_t node_bytes;   /* bytes of one interior record on the device */
+    uint32_t node_bytes;   /* bytes of one wide interior record on the device */
     uint32_t prim_bytes;   /* bytes of one primitive record on the device */
     uint64_t device_bytes; /* total scene footprint in HBM */
     double root_box[6];    /* xmin,xmax,ymin,ymax,zmin,zmax */
     double build_seconds;
+    uint32_t n_wide;        /* four-slot records the kernels traverse (two levels of the tree each) */
+    uint32_t wide_root_ref;
+    uint32_t wide_depth;    /* stack entries the traversal can need */
+    uint32_t reserved;
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -150,6 +154,12 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
  * 1 = 1..4 primitives behind a box test (payload = first<<2 | count-1),
  * 2 = one primitive with no box test (payload = prim<<2). */
 int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t* child_ref, uint32_t* prim_object);
+/* The records the kernels actually walk: two levels of the tree above folded into one
+ * record of up to four slots (wide_box: n_wide*4*6 f64, wide_ref: n_wide*4 u32, kind 3 =
+ * unused slot).  A slot's box is the one whose test gates the reference's access to that
+ * subtree: the grandchild's own box, or its parent's when the grandchild is a direct leaf
+ * (bvh.rs:297, :302), which then appears as a one-primitive kind-1 reference. */
+int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -200,11 +210,15 @@ typedef struct {
     uint64_t escaped_paths;
     /* lane-utilisation diagnostics (count_work only); each *_wave value is summed over
      * all 64 lanes of the waves that executed the phase, *_lane over the active lanes */
-    uint64_t step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
+    uint64_t step_wave, step_lane, inner_wave, leaf_wave;
+    /* shader-clock ticks the traversal kernel's waves spent in interior steps, in leaf steps
+     * and in retiring/refilling (count_work only), summed over waves */
+    uint64_t interior_ticks, leaf_ticks;
     double kernel_ms;       /* summed HIP-event time of the traversal kernel's launches on its stream */
     double total_ms;        /* all kernels of the render: path rounds + resolve */
     uint64_t kernel_launches; /* launches of the traversal kernel (= path rounds) */
     double trace_ms;        /* all path rounds (gen + traversal + hit + miss kernels) */
+    uint64_t refill_ticks;
 } rayrs_render_stats;
 
 /* Renders into a HOST buffer of y_pixels*x_pixels*3 elements (row-major,

@@ -821,6 +821,9 @@ struct orc_scene {
     double* child_box;
     uint32_t* child_ref;
     uint32_t* prim_object;
+    double* wide_box;   /* n_wide * 4 * 6 */
+    uint32_t* wide_ref; /* n_wide * 4 */
+    uint32_t wide_cap;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -835,6 +838,8 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->child_box);
     free(s->child_ref);
     free(s->prim_object);
+    free(s->wide_box);
+    free(s->wide_ref);
     free(s);
 }
 
@@ -1150,6 +1155,7 @@ static tnode* build_rec(build_t* b, size_t lo, size_t hi, int sah) {
 #define REF_KIND_INTERIOR 0u
 #define REF_KIND_RANGE 1u
 #define REF_KIND_SINGLE 2u
+#define REF_KIND_NONE 3u
 
 static int node_is_bottom(const tnode* n) {
     for (int i = 0; i < n->nchild; i++)
@@ -1244,6 +1250,133 @@ static void flatten(orc_scene* s) {
     s->finfo.root_box[5] = s->root->box.zmax;
 }
 
+/* Two levels of the two-child records folded into one record of up to four slots.  A slot
+ * carries the box whose test gates the reference's access to that subtree: a grandchild's
+ * own box (boxes nest exactly, so passing it implies passing its parent's), or the parent's
+ * box for a grandchild that is a direct leaf (bvh.rs:297, :302 do not test those), which is
+ * then written as a one-primitive range.  Returns the wide reference of record `n`. */
+static uint32_t fold_wide(orc_scene* s, uint32_t n, uint32_t* stack_need) {
+    uint32_t rec = s->finfo.n_wide++;
+    uint32_t refs[4];
+    const double* boxes[4];
+    int ns = 0;
+    for (int c = 0; c < 2; c++) {
+        uint32_t r = s->child_ref[(size_t)n * 2 + c];
+        const double* bx = s->child_box + ((size_t)n * 2 + c) * 6;
+        if ((r >> 30) != REF_KIND_INTERIOR) {
+            refs[ns] = r;
+            boxes[ns++] = bx;
+            continue;
+        }
+        uint32_t m = r & 0x3fffffffu;
+        for (int g = 0; g < 2; g++) {
+            uint32_t rg = s->child_ref[(size_t)m * 2 + g];
+            if ((rg >> 30) == REF_KIND_SINGLE) {
+                refs[ns] = (REF_KIND_RANGE << 30) | (rg & 0x3fffffffu);
+                boxes[ns++] = bx;
+            } else {
+                refs[ns] = rg;
+                boxes[ns++] = s->child_box + ((size_t)m * 2 + g) * 6;
+            }
+        }
+    }
+    uint32_t below = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t ref = REF_KIND_NONE << 30;
+        if (i < ns) {
+            ref = refs[i];
+            memcpy(s->wide_box + ((size_t)rec * 4 + i) * 6, boxes[i], 6 * sizeof(double));
+            if ((ref >> 30) == REF_KIND_INTERIOR) {
+                uint32_t need = 0;
+                ref = fold_wide(s, ref & 0x3fffffffu, &need);
+                if (need > below) below = need;
+            }
+        }
+        s->wide_ref[(size_t)rec * 4 + i] = ref;
+    }
+    *stack_need = (uint32_t)(ns - 1) + below;
+    return (REF_KIND_INTERIOR << 30) | rec;
+}
+
+/* The product renumbers the wide records: the ORC_WIDE_FRONT records with the largest boxes
+ * first (largest first, ties by index), the rest behind them in their depth-first order
+ * (scene_host.cpp front_largest; the kernel keeps the front ones in LDS).  Restated here so
+ * that the two exports can be compared word for word. */
+#define ORC_WIDE_FRONT 256u
+
+static double wide_record_area(const orc_scene* s, uint32_t rec) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int any = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t kind = s->wide_ref[(size_t)rec * 4 + i] >> 30;
+        if (kind != REF_KIND_INTERIOR && kind != REF_KIND_RANGE) continue;
+        const double* b = s->wide_box + ((size_t)rec * 4 + i) * 6;
+        for (int a = 0; a < 3; a++) {
+            if (!any || b[2 * a] < lo[a]) lo[a] = b[2 * a];
+            if (!any || b[2 * a + 1] > hi[a]) hi[a] = b[2 * a + 1];
+        }
+        any = 1;
+    }
+    if (!any) return 0.0;
+    double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return 2.0 * (ex * ey + ey * ez + ex * ez);
+}
+
+static void front_largest(orc_scene* s) {
+    uint32_t n = s->finfo.n_wide;
+    uint32_t k = n < ORC_WIDE_FRONT ? n : ORC_WIDE_FRONT;
+    if (k == 0) return;
+    double* area = (double*)malloc((size_t)n * sizeof(double));
+    uint32_t* order = (uint32_t*)malloc((size_t)n * sizeof(uint32_t)); /* order[new] = old */
+    uint32_t* new_of = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    uint8_t* taken = (uint8_t*)calloc(n, 1);
+    for (uint32_t r = 0; r < n; r++) area[r] = wide_record_area(s, r);
+    for (uint32_t i = 0; i < k; i++) { /* selection: k passes, first strictly largest wins */
+        uint32_t best = 0xffffffffu;
+        for (uint32_t r = 0; r < n; r++)
+            if (!taken[r] && (best == 0xffffffffu || area[r] > area[best])) best = r;
+        taken[best] = 1;
+        order[i] = best;
+    }
+    uint32_t at = k;
+    for (uint32_t r = 0; r < n; r++)
+        if (!taken[r]) order[at++] = r;
+    for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
+    double* box = (double*)calloc((size_t)(n ? n : 1) * 24, sizeof(double));
+    uint32_t* ref = (uint32_t*)calloc((size_t)(n ? n : 1) * 4, sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t old = order[i];
+        for (int c = 0; c < 4; c++) {
+            uint32_t r = s->wide_ref[(size_t)old * 4 + c];
+            if ((r >> 30) == REF_KIND_INTERIOR) r = (REF_KIND_INTERIOR << 30) | new_of[r & 0x3fffffffu];
+            ref[(size_t)i * 4 + c] = r;
+        }
+        memcpy(box + (size_t)i * 24, s->wide_box + (size_t)old * 24, 24 * sizeof(double));
+    }
+    s->finfo.wide_root_ref = (REF_KIND_INTERIOR << 30) | new_of[s->finfo.wide_root_ref & 0x3fffffffu];
+    free(s->wide_box);
+    free(s->wide_ref);
+    s->wide_box = box;
+    s->wide_ref = ref;
+    free(area);
+    free(order);
+    free(new_of);
+    free(taken);
+}
+
+static void flatten_wide(orc_scene* s) {
+    uint32_t cap = s->finfo.n_interior ? s->finfo.n_interior : 1;
+    s->wide_box = (double*)calloc((size_t)cap * 24, sizeof(double));
+    s->wide_ref = (uint32_t*)calloc((size_t)cap * 4, sizeof(uint32_t));
+    s->finfo.n_wide = 0;
+    s->finfo.wide_depth = 0;
+    if ((s->finfo.root_ref >> 30) == REF_KIND_INTERIOR)
+        s->finfo.wide_root_ref = fold_wide(s, s->finfo.root_ref & 0x3fffffffu, &s->finfo.wide_depth);
+    else
+        s->finfo.wide_root_ref = s->finfo.root_ref;
+    front_largest(s);
+}
+
 /* Scene::new lib.rs:227-245, Bvh::build bvh.rs:199-210 */
 int orc_scene_build(orc_scene* s, double z_near, double z_far, int heuristic, uint32_t splits, int builder,
                     uint32_t hdri_w, uint32_t hdri_h, const float* hdri_rgb) {
@@ -1292,6 +1425,7 @@ int orc_scene_build(orc_scene* s, double z_near, double z_far, int heuristic, ui
     for (size_t i = 0; i < nt; i++) s->hdri[i] = rr_max(rr_min((double)hdri_rgb[i], 3.0), 0.0);
 
     flatten(s);
+    flatten_wide(s);
     s->built = 1;
     return 0;
 }
@@ -1307,6 +1441,13 @@ int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_re
     memcpy(child_box, s->child_box, (size_t)s->finfo.n_interior * 12 * sizeof(double));
     memcpy(child_ref, s->child_ref, (size_t)s->finfo.n_interior * 2 * sizeof(uint32_t));
     memcpy(prim_object, s->prim_object, (size_t)s->finfo.n_prims * sizeof(uint32_t));
+    return 0;
+}
+
+int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide_ref) {
+    if (!s || !s->built) return -1;
+    memcpy(wide_box, s->wide_box, (size_t)s->finfo.n_wide * 24 * sizeof(double));
+    memcpy(wide_ref, s->wide_ref, (size_t)s->finfo.n_wide * 4 * sizeof(uint32_t));
     return 0;
 }
 
@@ -1442,8 +1583,98 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
     return best;
 }
 
+/* Diagnostics: when set, isect_wide adds one to hist[record] per visit and to
+ * hist[n_wide + min(sp, 63)] the stack height seen at each visit (single-threaded use). */
+static uint64_t* g_visit_hist = NULL;
+void orc_set_visit_histogram(uint64_t* hist) { g_visit_hist = hist; }
+
+/* The same on the folded records (the walk the HIP traversal kernel makes): up to four
+ * boxes per record, the hit slots entered nearest first (ties by slot), the rest pushed
+ * farthest first. */
+static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
+    isect_t best = {0, 0.0, -1};
+    uint32_t best_prim = 0xffffffffu;
+    double best_t = tmax;
+    v3 inv = V(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+    double entry;
+    if (!aabb_intersect_entry(s->finfo.root_box, ray, inv, tmin, tmax, &entry)) return best;
+    uint32_t stack[512];
+    int sp = 0;
+    uint32_t cur = s->finfo.wide_root_ref;
+    for (;;) {
+        if ((cur >> 30) == REF_KIND_INTERIOR) {
+            uint32_t rec = cur & 0x3fffffffu;
+            if (cnt) cnt->interior_visits++;
+            if (g_visit_hist) {
+                g_visit_hist[rec]++;
+                g_visit_hist[s->finfo.n_wide + (uint32_t)(sp < 63 ? sp : 63)]++;
+            }
+            int hit[4], n = 0;
+            double ent[4];
+            const uint32_t* refs = s->wide_ref + (size_t)rec * 4;
+            for (int c = 0; c < 4; c++) {
+                uint32_t kind = refs[c] >> 30;
+                hit[c] = 0;
+                ent[c] = 0.0;
+                if (kind == REF_KIND_SINGLE) {
+                    hit[c] = 1;
+                    ent[c] = tmin;
+                } else if (kind != REF_KIND_NONE) {
+                    hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
+                    if (hit[c] && ent[c] > best_t) hit[c] = 0;
+                }
+                n += hit[c];
+            }
+            if (n > 0) {
+                /* visit order: by entry, then by slot */
+                int order[4], k = 0;
+                for (int c = 0; c < 4; c++)
+                    if (hit[c]) order[k++] = c;
+                for (int a = 1; a < n; a++) { /* stable insertion sort */
+                    int c = order[a], b = a;
+                    while (b > 0 && ent[order[b - 1]] > ent[c]) {
+                        order[b] = order[b - 1];
+                        b--;
+                    }
+                    order[b] = c;
+                }
+                for (int a = n - 1; a >= 1; a--) stack[sp++] = refs[order[a]];
+                cur = refs[order[0]];
+                continue;
+            }
+        } else {
+            uint32_t first = (cur & 0x3fffffffu) >> 2;
+            uint32_t count = (cur & 3u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                uint32_t p = first + k;
+                int obj = (int)s->prim_object[p];
+                const shape_t* g = &s->objs[obj].geom;
+                if (cnt) {
+                    if (g->kind == ORC_SHAPE_TRIANGLE) cnt->tri_tests++;
+                    else if (g->kind == ORC_SHAPE_SPHERE) cnt->sphere_tests++;
+                    else cnt->plane_tests++;
+                }
+                double t;
+                if (shape_intersect(g, ray, &t) && t > tmin && t < tmax) {
+                    if (!best.hit || t < best.t || (t == best.t && p < best_prim)) {
+                        best.hit = 1;
+                        best.t = t;
+                        best.obj = obj;
+                        best_prim = p;
+                        best_t = t;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
 static inline isect_t scene_intersect(const orc_scene* s, ray_t ray, int traversal, trav_counters* cnt) {
     if (traversal == 0) return isect_reference(s, s->root, ray, s->t0, s->t1);
+    if (traversal == 2) return isect_wide(s, ray, s->t0, s->t1, cnt);
     return isect_ordered(s, ray, s->t0, s->t1, cnt);
 }
 
@@ -1717,7 +1948,9 @@ int64_t orc_bvh_intersect(const orc_scene* s, const double o[3], const double d[
                           int traversal, double* t) {
     if (!s || !s->built) return -2;
     ray_t r = {v_from(o), v_from(d)};
-    isect_t h = traversal == 0 ? isect_reference(s, s->root, r, tmin, tmax) : isect_ordered(s, r, tmin, tmax, NULL);
+    isect_t h = traversal == 0   ? isect_reference(s, s->root, r, tmin, tmax)
+                : traversal == 2 ? isect_wide(s, r, tmin, tmax, NULL)
+                                 : isect_ordered(s, r, tmin, tmax, NULL);
     if (!h.hit) return -1;
     *t = h.t;
     return h.obj;

@@ -17,6 +17,7 @@ SYMBOLS = [
     "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
     "rayrs_object_from_spheres", "rayrs_object_box_geom",
     "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
+    "rayrs_scene_export_wide",
     "rayrs_camera_new",
     "rayrs_render", "rayrs_render_launch", "rayrs_render_finish",
     "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
@@ -48,7 +49,8 @@ class SceneInfo(C.Structure):
                 ("root_ref", C.c_uint32), ("depth", C.c_uint32), ("compact", C.c_uint32),
                 ("n_surfaces", C.c_uint32), ("node_bytes", C.c_uint32), ("prim_bytes", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
-                ("build_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
+                ("wide_depth", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
@@ -62,9 +64,9 @@ class RenderStats(C.Structure):
                 ("neg_pixels", C.c_uint64), ("interior_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64), ("escaped_paths", C.c_uint64),
                 ("step_wave", C.c_uint64), ("step_lane", C.c_uint64), ("inner_wave", C.c_uint64),
-                ("leaf_wave", C.c_uint64), ("shade_wave", C.c_uint64), ("shade_lane", C.c_uint64),
+                ("leaf_wave", C.c_uint64), ("interior_ticks", C.c_uint64), ("leaf_ticks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
-                ("trace_ms", C.c_double)]
+                ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -107,6 +109,7 @@ def lib():
     L.rayrs_scene_destroy.restype = None
     L.rayrs_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
+    L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
     L.rayrs_camera_new.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                    C.POINTER(CameraDesc)]
     L.rayrs_render.argtypes = [vp, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp, C.POINTER(RenderStats)]

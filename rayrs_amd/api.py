@@ -306,6 +306,15 @@ class Scene:
                    "rayrs_scene_export_bvh")
         return box[:i["n_interior"]], ref[:i["n_interior"]], prim[:i["n_prims"]]
 
+    def export_wide(self):
+        """The four-slot records the kernels walk: (box[n_wide,4,6], ref[n_wide,4])."""
+        i = self.info()
+        box = np.zeros((max(i["n_wide"], 1), 4, 6), dtype=np.float64)
+        ref = np.zeros((max(i["n_wide"], 1), 4), dtype=np.uint32)
+        _ffi.check(self._L.rayrs_scene_export_wide(self._h, box.ctypes.data, ref.ctypes.data),
+                   "rayrs_scene_export_wide")
+        return box[:i["n_wide"]], ref[:i["n_wide"]]
+
     def close(self):
         if self._h is not None:
             self._L.rayrs_scene_destroy(self._h)

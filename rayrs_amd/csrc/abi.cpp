@@ -30,7 +30,9 @@ int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
-constexpr uint32_t MAX_STACK_DEPTH = 96;  // 4 waves * 64 lanes * 96 * 4 B = 96 KiB of LDS per workgroup
+constexpr uint32_t MAX_STACK_DEPTH = 96;  // 4 waves * 64 lanes * 96 * 4 B = 96 KiB of LDS per workgroup (self-test kernel)
+constexpr uint32_t TRAV_STACK_LDS = 12;
+constexpr uint32_t TRAV_HOT_BYTES = 15u * 1024u;
 
 }  // namespace
 
@@ -56,6 +58,10 @@ struct rayrs_scene {
     bool last_count = false;
     int cu_count = 0;
     int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
+    uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
+    uint32_t hot_records = 0;    // leading wide records kept in LDS
+    uint32_t* d_stack_spill = nullptr;
+    size_t stack_spill_words = 0;
     uint64_t device_bytes = 0;
     // path pool and queues of the wavefront pipeline
     WfDev wf = {};
@@ -222,6 +228,7 @@ static void scene_free_device(rayrs_scene* s) {
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->wf_block) (void)hipFree(s->wf_block);
     if (s->d_wave_items) (void)hipFree(s->d_wave_items);
+    if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
     if (s->wf.ctl) (void)hipFree(s->wf.ctl);
     if (s->h_live) (void)hipHostFree(s->h_live);
     for (auto& e : s->ev)
@@ -257,8 +264,23 @@ static int scene_upload(rayrs_scene* s) {
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_rgba.size() * sizeof(float);
-    const uint32_t depth = f.depth ? f.depth : 1;
-    HIP_TRY(wf_trav_occupancy(f.compact, depth, &s->blocks_per_cu));
+    // A traversal workgroup's LDS: the first stack_lds entries of each lane's stack (deeper
+    // entries overflow to HBM; measured on the 1M-triangle scene 99.9 % of visits happen with
+    // at most 10 pending), 4 KiB of window lists, and the hot_records largest wide records.
+    // 12 + 4 + 15 KiB lets five workgroups (the kernel's launch bound) share a CU's 160 KiB.
+    const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
+    s->stack_lds = depth < TRAV_STACK_LDS ? depth : TRAV_STACK_LDS;
+    if (const char* env = getenv("RAYRS_STACK_LDS")) {
+        const int v = atoi(env);
+        if (v >= 1 && (uint32_t)v <= depth) s->stack_lds = (uint32_t)v;
+    }
+    uint32_t hot = TRAV_HOT_BYTES / (f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u);
+    if (const char* env = getenv("RAYRS_HOT_RECORDS")) {
+        const int v = atoi(env);
+        if (v >= 0 && (uint32_t)v <= WIDE_FRONT) hot = (uint32_t)v;
+    }
+    s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
+    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
     HIP_TRY(hipMalloc((void**)&s->wf.ctl, sizeof(WfCtl)));
     HIP_TRY(hipHostMalloc((void**)&s->h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
@@ -281,7 +303,7 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     s->n_objects = objs->list.objs.size();
     s->device = device;
     if (device >= 0) {
-        if (s->flat.depth > MAX_STACK_DEPTH) {
+        if (s->flat.wide_depth > MAX_STACK_DEPTH) {
             delete s;
             return RAYRS_UNSUPPORTED;
         }
@@ -307,7 +329,10 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->depth = f.depth;
     info->compact = f.compact ? 1u : 0u;
     info->n_surfaces = (uint32_t)scene->surfaces.size();
-    info->node_bytes = f.compact ? (uint32_t)sizeof(NodeF32) : (uint32_t)sizeof(NodeF64);
+    info->node_bytes = f.compact ? (uint32_t)sizeof(Node4F32) : (uint32_t)sizeof(Node4F64);
+    info->n_wide = f.n_wide();
+    info->wide_root_ref = f.wide_root_ref;
+    info->wide_depth = f.wide_depth;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
     for (int i = 0; i < 6; i++) info->root_box[i] = f.root_box[i];
@@ -322,6 +347,14 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
     if (child_ref && !f.child_ref.empty()) std::memcpy(child_ref, f.child_ref.data(), f.child_ref.size() * 4);
     if (prim_object && !f.prim_object.empty())
         std::memcpy(prim_object, f.prim_object.data(), f.prim_object.size() * 4);
+    return RAYRS_OK;
+}
+
+int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
+    if (!scene) return RAYRS_INVALID_ARG;
+    const FlatScene& f = scene->flat;
+    if (wide_box && !f.wide_box.empty()) std::memcpy(wide_box, f.wide_box.data(), f.wide_box.size() * 8);
+    if (wide_ref && !f.wide_ref.empty()) std::memcpy(wide_ref, f.wide_ref.data(), f.wide_ref.size() * 4);
     return RAYRS_OK;
 }
 
@@ -343,8 +376,10 @@ static SceneDev make_scene_dev(const rayrs_scene* s) {
     sc.hdri = s->d_hdri;
     sc.hdri_w = s->flat.hdri_w;
     sc.hdri_h = s->flat.hdri_h;
-    sc.root_ref = s->flat.root_ref;
-    sc.stack_depth = s->flat.depth ? s->flat.depth : 1;
+    sc.root_ref = s->flat.wide_root_ref;
+    sc.stack_depth = s->flat.wide_depth ? s->flat.wide_depth : 1;
+    sc.stack_lds = s->stack_lds;
+    sc.hot_records = s->hot_records;
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
@@ -451,6 +486,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->blocks_per_cu;
+    {
+        // whole round-robin rounds covering about static_pct % of the pool's windows
+        uint32_t static_pct = 50;
+        if (const char* env = getenv("RAYRS_STATIC_PCT")) static_pct = (uint32_t)atoi(env);
+        if (static_pct > 100) static_pct = 100;
+        const uint64_t n_windows = np / wf_window_slots(), n_waves = (uint64_t)trav_blocks * 4u;
+        rp.static_windows = (uint32_t)(n_windows * static_pct / 100u / n_waves * n_waves);
+    }
     uint32_t flat_blocks = (np / wf_window_slots() + 3u) / 4u;  // one wave per window
     const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
     if (flat_blocks > flat_cap) flat_blocks = flat_cap;
@@ -464,6 +507,19 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         scene->wave_items_cap = wf.n_flat_waves;
     }
     wf.wave_items = scene->d_wave_items;
+    wf.trav_threads = trav_blocks * 256u;
+    {
+        const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
+        const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
+        if (words > scene->stack_spill_words) {
+            if (scene->d_stack_spill) HIP_TRY(hipFree(scene->d_stack_spill));
+            scene->d_stack_spill = nullptr;
+            scene->stack_spill_words = 0;
+            HIP_TRY(hipMalloc((void**)&scene->d_stack_spill, words * sizeof(uint32_t)));
+            scene->stack_spill_words = words;
+        }
+        wf.stack_spill = scene->d_stack_spill;
+    }
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
@@ -541,7 +597,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->plane_tests = c.plane_tests;
         stats->escaped_paths = c.escaped_paths;
         stats->step_wave = c.step_wave, stats->step_lane = c.step_lane, stats->inner_wave = c.inner_wave;
-        stats->leaf_wave = c.leaf_wave, stats->shade_wave = c.shade_wave, stats->shade_lane = c.shade_lane;
+        stats->leaf_wave = c.leaf_wave, stats->interior_ticks = c.interior_ticks, stats->leaf_ticks = c.leaf_ticks;
+        stats->refill_ticks = c.refill_ticks;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;

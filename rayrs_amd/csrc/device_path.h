@@ -240,6 +240,23 @@ RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 // is decided from it.
 constexpr uint32_t TRAV_DONE = 0xffffffffu;
 
+// A lane's traversal stack.  Entry k lives in LDS at lds[k * 64] while k < cap; deeper
+// entries, which only the worst-case visit order of a deep tree reaches, go to a per-lane
+// strip of HBM (entry k at spill[(k - cap) * stride]).  Sizing LDS for the common case
+// instead of the bound is what lets five workgroups share a CU on the 1M-triangle scene.
+struct LaneStack {
+    uint32_t* lds;
+    uint32_t* spill;
+    uint32_t cap, stride;
+    RR_DEV void put(int k, uint32_t v) const {
+        if ((uint32_t)k < cap) lds[k * 64] = v;
+        else spill[(size_t)((uint32_t)k - cap) * stride] = v;
+    }
+    RR_DEV uint32_t get(int k) const {
+        return (uint32_t)k < cap ? lds[k * 64] : spill[(size_t)((uint32_t)k - cap) * stride];
+    }
+};
+
 struct Trav {
     V3 inv;
     double best_t;
@@ -262,73 +279,125 @@ RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.cur = hit ? sc.root_ref : TRAV_DONE;
 }
 
-RR_DEV void trav_pop(uint32_t* stack, Trav& tv) {
+RR_DEV void trav_pop(const LaneStack& stack, Trav& tv) {
     if (tv.sp > 0) {
         tv.sp--;
-        tv.cur = stack[tv.sp * 64];
+        tv.cur = stack.get(tv.sp);
     } else {
         tv.cur = TRAV_DONE;
     }
 }
 
-// One interior record: both child boxes tested, nearer child entered, farther pushed.
+// One wide record (layout.h): up to four boxes tested, the hit slots entered nearest first
+// (ties by slot), the others pushed farthest first.
+RR_DEV bool slab_f32(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, bool nx, bool ny,
+                     bool nz, V3 o, V3 inv, double tmin, double tmax, double& entry) {
+    return slab(f32bits_to_f64(nx ? x1 : x0), f32bits_to_f64(nx ? x0 : x1), f32bits_to_f64(ny ? y1 : y0),
+                f32bits_to_f64(ny ? y0 : y1), f32bits_to_f64(nz ? z1 : z0), f32bits_to_f64(nz ? z0 : z1), o, inv, tmin,
+                tmax, entry);
+}
+
+RR_DEV bool slab_f64(uint4 x, uint4 y, uint4 z, bool nx, bool ny, bool nz, V3 o, V3 inv, double tmin, double tmax,
+                     double& entry) {
+    const double x0 = f64_from(x.x, x.y), x1 = f64_from(x.z, x.w);
+    const double y0 = f64_from(y.x, y.y), y1 = f64_from(y.z, y.w);
+    const double z0 = f64_from(z.x, z.y), z1 = f64_from(z.z, z.w);
+    return slab(nx ? x1 : x0, nx ? x0 : x1, ny ? y1 : y0, ny ? y0 : y1, nz ? z1 : z0, nz ? z0 : z1, o, inv, tmin, tmax,
+                entry);
+}
+
+// The first `count` wide records, copied to LDS by the traversal kernel: the records with the
+// largest boxes (scene_host.cpp front_largest), which most queries read.  Random 16-byte reads
+// cost the vector L1 about a cycle per lane; LDS serves them several times faster.  Records are
+// spaced one granule (16 bytes) more than their size apart, so that lanes reading the same
+// piece of 16 different records use 16 different bank groups.
+struct HotNodes {
+    const uint4* lds;
+    uint32_t count;
+    template <bool COMPACT>
+    RR_DEV static constexpr uint32_t stride() { return COMPACT ? 9u : 17u; }  // granules
+};
+
 template <bool COMPACT, bool COUNT>
-RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, uint32_t* stack, Trav& tv, WorkCount& wc) {
+RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
+                               WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
     const V3 inv = tv.inv;
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
     const uint32_t rec = tv.cur & 0x3fffffffu;
     if (COUNT) wc.interior++;
-    double e0, e1;
-    bool h0, h1;
-    uint32_t r0, r1;
+    double e0, e1, e2, e3;
+    bool h0, h1, h2, h3;
+    uint32_t r0, r1, r2, r3;
     if (COMPACT) {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 4;
-        const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
-        r0 = e.x, r1 = e.y;
-        // box0 = a.x a.y a.z a.w b.x b.y ; box1 = b.z b.w c.x c.y c.z c.w  (xmin xmax ymin ymax zmin zmax)
-        h0 = slab(f32bits_to_f64(nx ? a.y : a.x), f32bits_to_f64(nx ? a.x : a.y), f32bits_to_f64(ny ? a.w : a.z),
-                  f32bits_to_f64(ny ? a.z : a.w), f32bits_to_f64(nz ? b.y : b.x), f32bits_to_f64(nz ? b.x : b.y), o,
-                  inv, tmin, tmax, e0);
-        h1 = slab(f32bits_to_f64(nx ? b.w : b.z), f32bits_to_f64(nx ? b.z : b.w), f32bits_to_f64(ny ? c.y : c.x),
-                  f32bits_to_f64(ny ? c.x : c.y), f32bits_to_f64(nz ? c.w : c.z), f32bits_to_f64(nz ? c.z : c.w), o,
-                  inv, tmin, tmax, e1);
+        uint4 a, b, c, d, f, g, r;
+        if (rec < hot.count) {
+            const uint4* src = hot.lds + rec * HotNodes::stride<true>();
+            a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
+            a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+        }
+        r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+        // slot k = dwords 6k .. 6k+5 (xmin xmax ymin ymax zmin zmax)
+        h0 = slab_f32(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, o, inv, tmin, tmax, e0);
+        h1 = slab_f32(b.z, b.w, c.x, c.y, c.z, c.w, nx, ny, nz, o, inv, tmin, tmax, e1);
+        h2 = slab_f32(d.x, d.y, d.z, d.w, f.x, f.y, nx, ny, nz, o, inv, tmin, tmax, e2);
+        h3 = slab_f32(f.z, f.w, g.x, g.y, g.z, g.w, nx, ny, nz, o, inv, tmin, tmax, e3);
     } else {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
-        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6];
-        r0 = q6.x, r1 = q6.y;
-        const double x0 = f64_from(q0.x, q0.y), x1 = f64_from(q0.z, q0.w);
-        const double y0 = f64_from(q1.x, q1.y), y1 = f64_from(q1.z, q1.w);
-        const double z0 = f64_from(q2.x, q2.y), z1 = f64_from(q2.z, q2.w);
-        h0 = slab(nx ? x1 : x0, nx ? x0 : x1, ny ? y1 : y0, ny ? y0 : y1, nz ? z1 : z0, nz ? z0 : z1, o, inv, tmin,
-                  tmax, e0);
-        const double u0 = f64_from(q3.x, q3.y), u1 = f64_from(q3.z, q3.w);
-        const double v0 = f64_from(q4.x, q4.y), v1 = f64_from(q4.z, q4.w);
-        const double w0 = f64_from(q5.x, q5.y), w1 = f64_from(q5.z, q5.w);
-        h1 = slab(nx ? u1 : u0, nx ? u0 : u1, ny ? v1 : v0, ny ? v0 : v1, nz ? w1 : w0, nz ? w0 : w1, o, inv, tmin,
-                  tmax, e1);
+        // slot by slot (a whole 208-byte record in registers would not fit five waves per SIMD);
+        // the scenes that need this layout are the sphere rows, whose few records all sit in LDS
+        const bool in_lds = rec < hot.count;
+        const uint4* lsrc = hot.lds + (in_lds ? rec : 0u) * HotNodes::stride<false>();
+        const uint4* gsrc = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 16;
+        uint4 x, y, z, r;
+        if (in_lds) x = lsrc[0], y = lsrc[1], z = lsrc[2], r = lsrc[12];
+        else x = gsrc[0], y = gsrc[1], z = gsrc[2], r = gsrc[12];
+        r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+        h0 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e0);
+        if (in_lds) x = lsrc[3], y = lsrc[4], z = lsrc[5];
+        else x = gsrc[3], y = gsrc[4], z = gsrc[5];
+        h1 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e1);
+        if (in_lds) x = lsrc[6], y = lsrc[7], z = lsrc[8];
+        else x = gsrc[6], y = gsrc[7], z = gsrc[8];
+        h2 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e2);
+        if (in_lds) x = lsrc[9], y = lsrc[10], z = lsrc[11];
+        else x = gsrc[9], y = gsrc[10], z = gsrc[11];
+        h3 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e3);
     }
-    // a direct leaf child is not box-tested by the reference (bvh.rs:297, :302)
-    const bool s0 = (r0 >> 30) == REF_SINGLE, s1 = (r1 >> 30) == REF_SINGLE;
-    h0 = s0 || (h0 && !(e0 > tv.best_t));
-    h1 = s1 || (h1 && !(e1 > tv.best_t));
-    e0 = s0 ? tmin : e0;
-    e1 = s1 ? tmin : e1;
-    if (h0 && h1) {
-        const bool swap = e1 < e0;
-        stack[tv.sp * 64] = swap ? r0 : r1;
-        tv.sp++;
-        tv.cur = swap ? r1 : r0;
-    } else if (h0 || h1) {
-        tv.cur = h0 ? r0 : r1;
-    } else {
+    // a direct leaf is not box-tested by the reference (bvh.rs:297, :302); an unused slot is never entered
+    const uint32_t k0 = r0 >> 30, k1 = r1 >> 30, k2 = r2 >> 30, k3 = r3 >> 30;
+    h0 = k0 == REF_SINGLE || (k0 != REF_NONE && h0 && !(e0 > tv.best_t));
+    h1 = k1 == REF_SINGLE || (k1 != REF_NONE && h1 && !(e1 > tv.best_t));
+    h2 = k2 == REF_SINGLE || (k2 != REF_NONE && h2 && !(e2 > tv.best_t));
+    h3 = k3 == REF_SINGLE || (k3 != REF_NONE && h3 && !(e3 > tv.best_t));
+    const double far = __builtin_huge_val();
+    e0 = k0 == REF_SINGLE ? tmin : (h0 ? e0 : far);
+    e1 = k1 == REF_SINGLE ? tmin : (h1 ? e1 : far);
+    e2 = k2 == REF_SINGLE ? tmin : (h2 ? e2 : far);
+    e3 = k3 == REF_SINGLE ? tmin : (h3 ? e3 : far);
+    const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (n == 0) {
         trav_pop(stack, tv);
+        return;
     }
+    // rank of a hit slot = number of hit slots visited before it
+    const int c01 = e1 < e0, c02 = e2 < e0, c03 = e3 < e0, c12 = e2 < e1, c13 = e3 < e1, c23 = e3 < e2;
+    const int k_0 = c01 + c02 + c03;
+    const int k_1 = (1 - c01) + c12 + c13;
+    const int k_2 = (1 - c02) + (1 - c12) + c23;
+    const int k_3 = (1 - c03) + (1 - c13) + (1 - c23);
+    const int top = tv.sp + n - 1;  // rank k >= 1 is stored at entry top - k
+    if (h0) { if (k_0 == 0) tv.cur = r0; else stack.put(top - k_0, r0); }
+    if (h1) { if (k_1 == 0) tv.cur = r1; else stack.put(top - k_1, r1); }
+    if (h2) { if (k_2 == 0) tv.cur = r2; else stack.put(top - k_2, r2); }
+    if (h3) { if (k_3 == 0) tv.cur = r3; else stack.put(top - k_3, r3); }
+    tv.sp = top;
 }
 
 // One leaf reference: its 1..4 primitives in DFS order, then pop.
 template <bool COMPACT, bool COUNT>
-RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, Trav& tv, WorkCount& wc) {
+RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
     const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
     const uint32_t count = (tv.cur & 3u) + 1u;
@@ -356,13 +425,14 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, Trav
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
 template <bool COMPACT, bool COUNT>
-RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, uint32_t* stack, double& t_hit, uint32_t& prim_hit,
+RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
     trav_init(sc, o, d, tv);
+    const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
-            trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
+            trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
         else
             trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }

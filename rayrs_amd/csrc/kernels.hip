@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* stack = lds_stack + (size_t)wave * sc.stack_depth * 64u + lane;
+    const LaneStack stack{lds_stack + (size_t)wave * sc.stack_depth * 64u + lane, nullptr, sc.stack_depth, 0u};
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double t = 0.0;

@@ -39,6 +39,27 @@ struct NodeF64 {  // 128 B
 static_assert(sizeof(NodeF32) == 64, "NodeF32");
 static_assert(sizeof(NodeF64) == 128, "NodeF64");
 
+// The records the traversal kernel reads are "wide": two levels of the reference's binary
+// tree folded into one record of up to four slots, so that a query makes half as many
+// dependent fetches.  A slot holds the box whose test gates the reference's access to that
+// subtree: the grandchild's own box (which implies its parent's, boxes nest exactly) or, for
+// a grandchild that is a direct leaf (no box test of its own in the reference, bvh.rs:297,
+// :302), its parent's box.  Unused slots carry REF_NONE.
+struct Node4F32 {  // 128 B
+    float box[4][6];
+    uint32_t ref[4];
+    uint32_t pad[4];
+};
+struct Node4F64 {  // 256 B
+    double box[4][6];
+    uint32_t ref[4];
+    uint32_t pad[12];
+};
+// records renumbered to the front, largest box first (scene_host.cpp front_largest)
+constexpr uint32_t WIDE_FRONT = 256;
+static_assert(sizeof(Node4F32) == 128, "Node4F32");
+static_assert(sizeof(Node4F64) == 256, "Node4F64");
+
 // Primitive records are raw dwords: the payload starts at dword 0 and the tag
 // is the last dword.
 //   triangle: p1,p2,p3 as 9 f32 (compact) or 9 f64 (full)
@@ -69,7 +90,9 @@ struct SceneDev {
     const float* hdri;  // RGBA f32 texels (A unused), clipped to [0,3]
     uint32_t hdri_w, hdri_h;
     uint32_t root_ref;
-    uint32_t stack_depth;
+    uint32_t stack_depth;  // entries a traversal can have pending (FlatScene::wide_depth)
+    uint32_t stack_lds;    // how many of them live in LDS; the rest overflow to HBM (LaneStack)
+    uint32_t hot_records;  // leading wide records the traversal kernel copies to LDS (HotNodes)
     double root_box[6];
     double t0, t1;  // Scene::t_range, lib.rs:218
 };
@@ -85,7 +108,8 @@ struct Counters {
     unsigned long long interior_visits, tri_tests, sphere_tests, plane_tests, escaped_paths;
     // lane-utilisation diagnostics (count_work only): *_wave counts executions of a
     // phase by a wave x 64, *_lane the lanes that were active in it
-    unsigned long long step_wave, step_lane, inner_wave, leaf_wave, shade_wave, shade_lane;
+    unsigned long long step_wave, step_lane, inner_wave, leaf_wave;
+    unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
 };
 
 struct RenderDev {
@@ -98,6 +122,8 @@ struct RenderDev {
     uint32_t out_format;
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
+    uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
+    uint32_t pad1;
     double* partial;       // total_items * 3
     Counters* counters;
     void* out;

@@ -280,6 +280,112 @@ struct Builder {
 
 inline bool f32_exact(double v) { return (double)(float)v == v; }
 
+// Folds two levels of the binary tree into one wide record (layout.h).  Returns the wide
+// reference that replaces binary interior record `n`; *stack_need is the number of stack
+// entries a traversal below this record can have pending.
+uint32_t fold_wide(FlatScene& f, uint32_t n, uint32_t* stack_need);
+
+// Surface area of the box around a wide record's tested slots.
+double record_area(const FlatScene& f, uint32_t rec) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t kind = f.wide_ref[(size_t)rec * 4 + i] >> 30;
+        if (kind != REF_INTERIOR && kind != REF_RANGE) continue;
+        const double* b = &f.wide_box[((size_t)rec * 4 + i) * 6];
+        for (int a = 0; a < 3; a++) {
+            if (!any || b[2 * a] < lo[a]) lo[a] = b[2 * a];
+            if (!any || b[2 * a + 1] > hi[a]) hi[a] = b[2 * a + 1];
+        }
+        any = true;
+    }
+    if (!any) return 0.0;
+    const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return 2.0 * (ex * ey + ey * ez + ex * ez);
+}
+
+// Renumbers the wide records so that the WIDE_FRONT records with the largest boxes come
+// first, largest first (ties: lower index first); the others keep their depth-first order
+// behind them.  A ray meets a box with probability proportional to its surface area, so
+// these are the records nearly every query reads -- in the benchmark scenes the floor
+// plane's 50 x 50 box rides down a chain of eight of them -- and the traversal kernel keeps
+// the first of them in LDS (wavefront.hip) instead of asking the vector L1 for them.
+void front_largest(FlatScene& f) {
+    const uint32_t n = f.n_wide();
+    const uint32_t k = n < WIDE_FRONT ? n : WIDE_FRONT;
+    if (k == 0) return;
+    std::vector<double> area(n);
+    for (uint32_t r = 0; r < n; r++) area[r] = record_area(f, r);
+    std::vector<uint32_t> order(n);
+    for (uint32_t r = 0; r < n; r++) order[r] = r;
+    auto larger = [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
+    std::partial_sort(order.begin(), order.begin() + k, order.end(), larger);
+    std::vector<uint8_t> in_front(n, 0);
+    for (uint32_t i = 0; i < k; i++) in_front[order[i]] = 1;
+    uint32_t at = k;
+    for (uint32_t r = 0; r < n; r++)
+        if (!in_front[r]) order[at++] = r;  // order[new] = old
+    std::vector<uint32_t> new_of(n);
+    for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
+    std::vector<double> box(f.wide_box.size());
+    std::vector<uint32_t> ref(f.wide_ref.size());
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t old = order[i];
+        for (int c = 0; c < 4; c++) {
+            uint32_t r = f.wide_ref[(size_t)old * 4 + c];
+            if ((r >> 30) == REF_INTERIOR) r = (REF_INTERIOR << 30) | new_of[r & 0x3fffffffu];
+            ref[(size_t)i * 4 + c] = r;
+        }
+        for (int c = 0; c < 24; c++) box[(size_t)i * 24 + c] = f.wide_box[(size_t)old * 24 + c];
+    }
+    f.wide_box.swap(box);
+    f.wide_ref.swap(ref);
+    f.wide_root_ref = (REF_INTERIOR << 30) | new_of[f.wide_root_ref & 0x3fffffffu];
+}
+
+uint32_t fold_wide(FlatScene& f, uint32_t n, uint32_t* stack_need) {
+    const uint32_t rec = f.n_wide();
+    f.wide_ref.resize(f.wide_ref.size() + 4, REF_NONE << 30);
+    f.wide_box.resize(f.wide_box.size() + 24, 0.0);
+    struct Slot {
+        uint32_t ref;
+        const double* box;
+    } slots[4];
+    int ns = 0;
+    for (int c = 0; c < 2; c++) {
+        const uint32_t r = f.child_ref[(size_t)n * 2 + c];
+        const double* box = &f.child_box[((size_t)n * 2 + c) * 6];
+        if ((r >> 30) == REF_INTERIOR) {
+            const uint32_t m = r & 0x3fffffffu;
+            for (int g = 0; g < 2; g++) {
+                const uint32_t rg = f.child_ref[(size_t)m * 2 + g];
+                if ((rg >> 30) == REF_SINGLE)  // reached whenever m's box is hit: a one-primitive range behind m's box
+                    slots[ns++] = {(REF_RANGE << 30) | (rg & 0x3fffffffu), box};
+                else
+                    slots[ns++] = {rg, &f.child_box[((size_t)m * 2 + g) * 6]};
+            }
+        } else {
+            slots[ns++] = {r, box};  // a range behind its box, or a direct leaf (no box test)
+        }
+    }
+    uint32_t below = 0;
+    for (int i = 0; i < ns; i++) {
+        uint32_t ref = slots[i].ref;
+        const double* box = slots[i].box;  // taken before the recursion may reallocate wide_box, not child_box
+        double bx[6];
+        for (int k = 0; k < 6; k++) bx[k] = box[k];
+        if ((ref >> 30) == REF_INTERIOR) {
+            uint32_t need = 0;
+            ref = fold_wide(f, ref & 0x3fffffffu, &need);
+            if (need > below) below = need;
+        }
+        f.wide_ref[(size_t)rec * 4 + i] = ref;
+        for (int k = 0; k < 6; k++) f.wide_box[((size_t)rec * 4 + i) * 6 + k] = bx[k];
+    }
+    *stack_need = (uint32_t)(ns - 1) + below;
+    return (REF_INTERIOR << 30) | rec;
+}
+
 void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
 void put_f32(uint32_t* dst, float v) { std::memcpy(dst, &v, 4); }
 
@@ -315,12 +421,25 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     f.root_box[0] = root.xmin, f.root_box[1] = root.xmax, f.root_box[2] = root.ymin;
     f.root_box[3] = root.ymax, f.root_box[4] = root.zmin, f.root_box[5] = root.zmax;
 
+    // ---- fold two levels into one record
+    if ((f.root_ref >> 30) == REF_INTERIOR) {
+        f.wide_box.reserve((size_t)f.n_interior() * 16);
+        f.wide_ref.reserve((size_t)f.n_interior() * 3);
+        f.wide_root_ref = fold_wide(f, f.root_ref & 0x3fffffffu, &f.wide_depth);
+    } else {
+        f.wide_root_ref = f.root_ref;
+        f.wide_depth = 0;
+    }
+
+    front_largest(f);
+
     // ---- choose the layout
     bool compact = true;
-    for (size_t r = 0; r < f.child_ref.size() && compact; r++) {
-        if ((f.child_ref[r] >> 30) == REF_SINGLE) continue;  // box never read
+    for (size_t r = 0; r < f.wide_ref.size() && compact; r++) {
+        const uint32_t kind = f.wide_ref[r] >> 30;
+        if (kind == REF_SINGLE || kind == REF_NONE) continue;  // box never read
         for (int k = 0; k < 6; k++)
-            if (!f32_exact(f.child_box[r * 6 + k])) {
+            if (!f32_exact(f.wide_box[r * 6 + k])) {
                 compact = false;
                 break;
             }
@@ -337,25 +456,26 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     }
     f.compact = compact;
 
-    // ---- interior records
-    const uint32_t n_int = f.n_interior();
+    // ---- wide interior records
+    const uint32_t n_wide = f.n_wide();
     if (compact) {
-        f.node_bytes.assign((size_t)std::max(n_int, 1u) * sizeof(NodeF32), 0);
-        NodeF32* nodes = reinterpret_cast<NodeF32*>(f.node_bytes.data());
-        for (uint32_t r = 0; r < n_int; r++)
-            for (int ch = 0; ch < 2; ch++) {
-                nodes[r].ref[ch] = f.child_ref[(size_t)r * 2 + ch];
-                const bool unused = (nodes[r].ref[ch] >> 30) == REF_SINGLE;
+        f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F32), 0);
+        Node4F32* nodes = reinterpret_cast<Node4F32*>(f.node_bytes.data());
+        for (uint32_t r = 0; r < n_wide; r++)
+            for (int ch = 0; ch < 4; ch++) {
+                nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
+                const uint32_t kind = nodes[r].ref[ch] >> 30;
+                const bool unused = kind == REF_SINGLE || kind == REF_NONE;
                 for (int k = 0; k < 6; k++)
-                    nodes[r].box[ch][k] = unused ? 0.f : (float)f.child_box[((size_t)r * 2 + ch) * 6 + k];
+                    nodes[r].box[ch][k] = unused ? 0.f : (float)f.wide_box[((size_t)r * 4 + ch) * 6 + k];
             }
     } else {
-        f.node_bytes.assign((size_t)std::max(n_int, 1u) * sizeof(NodeF64), 0);
-        NodeF64* nodes = reinterpret_cast<NodeF64*>(f.node_bytes.data());
-        for (uint32_t r = 0; r < n_int; r++)
-            for (int ch = 0; ch < 2; ch++) {
-                nodes[r].ref[ch] = f.child_ref[(size_t)r * 2 + ch];
-                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = f.child_box[((size_t)r * 2 + ch) * 6 + k];
+        f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F64), 0);
+        Node4F64* nodes = reinterpret_cast<Node4F64*>(f.node_bytes.data());
+        for (uint32_t r = 0; r < n_wide; r++)
+            for (int ch = 0; ch < 4; ch++) {
+                nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
+                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = f.wide_box[((size_t)r * 4 + ch) * 6 + k];
             }
     }
 

@@ -52,6 +52,11 @@ struct FlatScene {
     std::vector<uint32_t> prim_object;
     uint32_t root_ref = 0;
     uint32_t depth = 0;
+    // the same tree with two levels folded into one record (what the kernels traverse)
+    std::vector<double> wide_box;    // n_wide * 24
+    std::vector<uint32_t> wide_ref;  // n_wide * 4
+    uint32_t wide_root_ref = 0;
+    uint32_t wide_depth = 0;         // stack entries the traversal can need
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images
@@ -63,6 +68,7 @@ struct FlatScene {
     double build_seconds = 0;
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }
+    uint32_t n_wide() const { return (uint32_t)(wide_ref.size() / 4); }
 };
 
 // Scene::new (lib.rs:227-245) minus the upload.  Returns RAYRS_* status.

@@ -75,6 +75,10 @@ struct WfDev {
     // the same grid (n_flat_waves waves) and give wave w the same windows
     unsigned long long* wave_items;
     uint32_t n_flat_waves;
+    // overflow strips of the traversal stacks (LaneStack): one word per thread of the traversal
+    // grid per entry beyond SceneDev::stack_lds
+    uint32_t trav_threads;
+    uint32_t* stack_spill;
 };
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
@@ -83,7 +87,7 @@ hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev&
                          hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu);
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
 hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_miss(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,

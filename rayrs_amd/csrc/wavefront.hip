@@ -287,16 +287,31 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // dynamic LDS: 4 stacks of stack_depth x 64 words, then 4 window lists of WINDOW uint16
-    uint32_t* stack = lds_dyn + (size_t)wave * sc.stack_depth * 64u + lane;
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)sc.stack_depth * 64u) + wave * WINDOW;
-    const uint32_t n_windows = wf.np / WINDOW;
+    // dynamic LDS: 4 stacks of stack_lds x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
+    const LaneStack stack{lds_dyn + (size_t)wave * sc.stack_lds * 64u + lane,
+                          wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)sc.stack_lds * 64u) + wave * WINDOW;
+    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)sc.stack_lds * 64u + 4u * WINDOW / 2u);
+    {
+        constexpr uint32_t G = COMPACT ? 8u : 16u;  // 16-byte granules per record
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+        for (uint32_t i = threadIdx.x; i < sc.hot_records * G; i += 256u)
+            hot_lds[(i / G) * HotNodes::stride<COMPACT>() + i % G] = src[i];
+        __syncthreads();
+    }
+    const HotNodes hot{hot_lds, sc.hot_records};
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
 
-    constexpr uint32_t WIN_CLAIM = 1;
-    uint32_t list_pos = 0, list_len = 0, list_win = 0;  // wave-uniform
-    uint32_t win_next = 0, win_end = 0;                 // wave-uniform: claimed windows not yet listed
-    bool no_more = false;                               // wave-uniform: window cursor ran off the end
+    const uint32_t n_windows = wf.np / WINDOW;
+    // Windows of the pool are handed out in two ways.  The first rp.static_windows windows are
+    // dealt round robin: wave g takes g, g + n_waves, ... and asks nobody.  The rest go to whoever
+    // runs dry first, through one atomic cursor (WfCtl::next_window), which evens out the
+    // waves' finishing times.  All of the pool through the cursor costs a fifth of the waves'
+    // time waiting for it: a single word takes about 90 atomics per microsecond on this chip.
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t static_next = blockIdx.x * 4u + wave;       // wave-uniform
+    uint32_t list_pos = 0, list_len = 0, list_base = 0;  // wave-uniform
+    bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
     bool active = false, pending = false;
     uint32_t slot = 0;
@@ -306,6 +321,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
+    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
 
     for (;;) {
         const bool at_int = active && trav_at_interior(tv);
@@ -327,26 +343,26 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
-                    if (win_next >= win_end) {  // claim the next WIN_CLAIM windows with one atomic
-                        uint32_t w = 0;
-                        if (lane == 0) w = atomicAdd(&ctl->next_window, WIN_CLAIM);
+                    uint32_t w = static_next;
+                    if (w < rp.static_windows) {
+                        static_next += n_waves;
+                    } else {
+                        if (lane == 0) w = rp.static_windows + atomicAdd(&ctl->next_window, 1u);
                         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-                        if (w >= n_windows) {
-                            no_more = true;
-                            break;
-                        }
-                        win_next = w;
-                        win_end = w + WIN_CLAIM < n_windows ? w + WIN_CLAIM : n_windows;
                     }
-                    list_win = win_next++;
-                    list_len = compact_window(wf, list_win, WF_READY, list);
+                    if (w >= n_windows) {
+                        no_more = true;
+                        break;
+                    }
+                    list_base = w * WINDOW;
+                    list_len = compact_window(wf, w, WF_READY, list);
                     list_pos = 0;
                     continue;
                 }
                 const uint32_t avail = list_len - list_pos;
                 const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
                 if (need && rank < avail) {
-                    slot = list_win * WINDOW + (uint32_t)list[list_pos + rank];
+                    slot = list_base + (uint32_t)list[list_pos + rank];
                     const RaySlot* rs = &wf.slots[slot].ray;
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
@@ -362,6 +378,10 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                 list_pos += wanted < avail ? wanted : avail;
                 need_mask = __ballot(need);
             }
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_refill += now - tk_last, tk_last = now;
+            }
             if (__ballot(active || pending) == 0ull && no_more) break;
             continue;
         }
@@ -372,12 +392,20 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                 trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_leaf += now - tk_last, tk_last = now;
+            }
         } else {
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                trav_interior_step<COMPACT, COUNT>(sc, o, stack, tv, wc);
+                trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
+            }
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_int += now - tk_last, tk_last = now;
             }
         }
     }
@@ -391,6 +419,10 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         wave_atomic_add(&c->plane_tests, wc.plane);
         wave_atomic_add(&c->step_wave, u_int_wave), wave_atomic_add(&c->step_lane, u_int_lane);
         wave_atomic_add(&c->inner_wave, u_leaf_lane), wave_atomic_add(&c->leaf_wave, u_leaf_wave);
+        if (lane == 0) {
+            atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
+            atomicAdd(&c->refill_ticks, tk_refill);
+        }
     }
 }
 
@@ -521,7 +553,9 @@ __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev 
 
 // ----------------------------------------------------------- launch glue
 
-static inline uint32_t trav_lds_bytes(uint32_t stack_depth) { return 4u * 64u * stack_depth * 4u + 4u * WINDOW * 2u; }
+static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
+    return 4u * 64u * stack_lds * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
+}
 
 uint32_t wf_window_slots() { return WINDOW; }
 
@@ -539,7 +573,7 @@ hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev&
 template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
-    const uint32_t lds = trav_lds_bytes(sc.stack_depth);
+    const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
     hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
@@ -553,8 +587,8 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
                  : launch_trav_t<false, false>(sc, rp, wf, blocks, stream);
 }
 
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_depth, int* blocks_per_cu) {
-    const uint32_t lds = trav_lds_bytes(stack_depth);
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+    const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
     const void* fn = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, false>)
                              : reinterpret_cast<const void*>(&wf_trav_kernel<false, false>);
     const void* fnc = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, true>)

@@ -26,7 +26,10 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False, ranks=1):
         prims = st['tri_tests'] + st['sphere_tests'] + st['plane_tests']
         print(f"  visits/ray={st['interior_visits']/st['rays']:.1f} prims/ray={prims/st['rays']:.2f} | lane utilisation: "
               f"interior {st['step_lane']/max(st['step_wave'],1)/1:.2f} leaf {st['inner_wave']/max(st['leaf_wave'],1):.2f} "
-              f"shade {st['shade_lane']/max(st['shade_wave'],1):.2f} | wave-phases/ray*64: int {st['step_wave']/st['rays']:.2f} leaf {st['leaf_wave']/st['rays']:.2f} shade {st['shade_wave']/st['rays']:.2f}", flush=True)
+              f"| wave-phases/ray*64: int {st['step_wave']/st['rays']:.2f} leaf {st['leaf_wave']/st['rays']:.2f}", flush=True)
+        tk = st['interior_ticks'] + st['leaf_ticks'] + st['refill_ticks']
+        print(f"  wave time: interior {st['interior_ticks']/tk:.2f} leaf {st['leaf_ticks']/tk:.2f} refill {st['refill_ticks']/tk:.2f} | "
+              f"ticks per wave-phase: interior {st['interior_ticks']/max(st['step_wave']/64,1):.0f} leaf {st['leaf_ticks']/max(st['leaf_wave']/64,1):.0f} | refill ticks per ray {st['refill_ticks']/st['rays']:.1f}", flush=True)
     return st
 
 if __name__ == "__main__":

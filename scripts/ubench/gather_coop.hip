@@ -37,10 +37,10 @@ template <int MODE> void run(const char* name, const uint4* t, uint32_t* out, ui
     hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, t, out, n_rec, iters); hipEventRecord(e1);
     hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
     const double recs = (double)blocks * 256 * iters;
-    printf("%-28s table %4u MB: %.3f ms, %.1f G records/s, %.2f TB/s\n", name, (unsigned)((uint64_t)n_rec * 64 >> 20), ms, recs / ms / 1e6, recs * 64 / ms / 1e9);
+    printf("%-28s table %6u KB: %.3f ms, %.1f G records/s, %.2f TB/s\n", name, (unsigned)((uint64_t)n_rec * 64 >> 10), ms, recs / ms / 1e6, recs * 64 / ms / 1e9);
 }
 int main() {
-    for (uint32_t n_rec : {1u << 14, 1u << 19, 1u << 21}) {   // 1 MB (L1/L2), 32 MB (L2/MALL), 128 MB (MALL)
+    for (uint32_t n_rec : {1u << 8, 1u << 11, 1u << 14, 1u << 19, 1u << 21}) {   // 16 KB (L1), 128 KB, 1 MB (L2), 32 MB (L2/MALL), 128 MB (MALL)
         uint4* t; uint32_t* out; hipMalloc(&t, (size_t)n_rec * 64); hipMalloc(&out, 256 * 8 * 256 * 4);
         hipMemset(t, 1, (size_t)n_rec * 64);
         run<0>("own record, 4 x dwordx4", t, out, n_rec);

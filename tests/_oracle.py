@@ -41,7 +41,8 @@ class OrcStats(C.Structure):
 
 class OrcFlatInfo(C.Structure):
     _fields_ = [("n_interior", C.c_uint32), ("n_prims", C.c_uint32), ("root_ref", C.c_uint32),
-                ("depth", C.c_uint32), ("root_box", C.c_double * 6)]
+                ("depth", C.c_uint32), ("root_box", C.c_double * 6), ("n_wide", C.c_uint32),
+                ("wide_root_ref", C.c_uint32), ("wide_depth", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -89,6 +90,7 @@ def lib():
     L.orc_radiance.argtypes = [vp, dp, dp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.c_int, dp]
     L.orc_flatten_info.argtypes = [vp, C.POINTER(OrcFlatInfo)]
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
+    L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_math_mode.argtypes = [C.c_int]
     L.orc_set_math_mode.restype = None
     _lib = L
@@ -190,7 +192,15 @@ class OracleScene:
         i = OrcFlatInfo()
         assert self._L.orc_flatten_info(self._h, C.byref(i)) == 0
         return {"n_interior": i.n_interior, "n_prims": i.n_prims, "root_ref": i.root_ref, "depth": i.depth,
-                "root_box": list(i.root_box)}
+                "root_box": list(i.root_box), "n_wide": i.n_wide, "wide_root_ref": i.wide_root_ref,
+                "wide_depth": i.wide_depth}
+
+    def export_wide(self):
+        i = self.flat_info()
+        box = np.zeros((max(i["n_wide"], 1), 4, 6), dtype=np.float64)
+        ref = np.zeros((max(i["n_wide"], 1), 4), dtype=np.uint32)
+        assert self._L.orc_flatten_export_wide(self._h, box.ctypes.data, ref.ctypes.data) == 0
+        return box[:i["n_wide"]], ref[:i["n_wide"]]
 
     def export_bvh(self):
         i = self.flat_info()

@@ -26,7 +26,59 @@ def same_tree(objs, heur):
         assert pi["root_box"] == oi["root_box"]
         assert np.array_equal(pr, orf) and np.array_equal(pp, op)
         assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64))
+        # the folded four-slot records the kernels walk
+        pwb, pwr = prod.export_wide()
+        owb, owr = orc.export_wide()
+        assert pi["n_wide"] == oi["n_wide"] and pi["wide_root_ref"] == oi["wide_root_ref"]
+        assert pi["wide_depth"] == oi["wide_depth"]
+        assert np.array_equal(pwr, owr)
+        used = (pwr >> 30) < 3
+        assert np.array_equal(pwb[used].view(np.uint64), owb[used].view(np.uint64))
+        check_fold(pb, pr, pwb, pwr, pi)
     return pi, pr, pp
+
+
+def check_fold(box, ref, wbox, wref, info):
+    """Independent structural check of the fold: walking the wide records reaches exactly the
+    primitives of the two-child tree, every box-tested reference of that tree appears once
+    behind its own box, and a direct leaf pulled up a level sits behind its parent's box."""
+    if info["n_interior"] == 0:
+        assert info["n_wide"] == 0 and info["wide_root_ref"] == info["root_ref"]
+        return
+    expect = []  # (ref, box bytes or None) reachable from binary record n, two levels at a time
+
+    def slots_of(n):
+        out = []
+        for c in range(2):
+            r = int(ref[n, c])
+            if r >> 30 == 0:
+                for g in range(2):
+                    rg = int(ref[r & 0x3fffffff, g])
+                    if rg >> 30 == 2:
+                        out.append(((1 << 30) | (rg & 0x3fffffff), box[n, c].tobytes(), None))
+                    else:
+                        out.append((rg, box[r & 0x3fffffff, g].tobytes(), (rg & 0x3fffffff) if rg >> 30 == 0 else None))
+            else:
+                out.append((r, None if r >> 30 == 2 else box[n, c].tobytes(), None))
+        return out
+
+    seen = 0
+    todo = [(info["root_ref"] & 0x3fffffff, info["wide_root_ref"] & 0x3fffffff)]
+    while todo:
+        n, w = todo.pop()
+        seen += 1
+        want = slots_of(n)
+        assert [int(x) >> 30 for x in wref[w, len(want):]] == [3] * (4 - len(want))
+        for k, (r, bx, sub) in enumerate(want):
+            got = int(wref[w, k])
+            if sub is None:
+                assert got == r
+            else:
+                assert got >> 30 == 0
+                todo.append((sub, got & 0x3fffffff))
+            if bx is not None:
+                assert wbox[w, k].tobytes() == bx
+    assert seen == info["n_wide"]
 
 
 SCENE_FNS = [scenes.diffuse_single_sphere, scenes.cook_torrance_spheres_metallic, scenes.material_test,
@@ -116,3 +168,7 @@ def test_large_mesh_builder_agreement():
     pb, pr, pp = prod.export_bvh()
     ob, orf, op = orc.export_bvh()
     assert np.array_equal(pr, orf) and np.array_equal(pp, op) and np.array_equal(pb, ob)
+    pwb, pwr = prod.export_wide()
+    owb, owr = orc.export_wide()
+    assert np.array_equal(pwr, owr) and np.array_equal(pwb[(pwr >> 30) < 3], owb[(owr >> 30) < 3])
+    check_fold(pb, pr, pwb, pwr, prod.info())

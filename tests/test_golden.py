@@ -42,7 +42,7 @@ def test_oracle_intersections_and_frame(name):
     o, d = G.rays(256, 11)
     for builder in (0, 1):  # literal reference builder and the swept one
         osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI, builder=builder)
-        for trav in (0, 1):  # recursive reference traversal and the ordered one
+        for trav in (0, 1, 2):  # recursive reference traversal, the ordered one, the folded one
             t, obj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=trav)
             assert np.array_equal(obj, GOLD[f"isect/{name}/obj"])
             assert np.array_equal(bits(t), bits(GOLD[f"isect/{name}/t"]))
@@ -50,6 +50,8 @@ def test_oracle_intersections_and_frame(name):
     img, st = osc.render(ocam, G.FRAME["spp"], G.FRAME["max_bounces"], seed=G.FRAME["seed"], traversal=1)
     assert st["rays"] == int(GOLD[f"frame/{name}/rays"][0])
     assert np.array_equal(bits(img), bits(GOLD[f"frame/{name}/rgb"]))
+    img2, st2 = osc.render(ocam, G.FRAME["spp"], G.FRAME["max_bounces"], seed=G.FRAME["seed"], traversal=2)
+    assert st2["rays"] == st["rays"] and np.array_equal(bits(img2), bits(img))
 
 
 def test_oracle_background_vectors():

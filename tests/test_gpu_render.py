@@ -90,9 +90,23 @@ def test_work_counters_match_oracle_ordered_traversal():
     roofline line can be computed on either side."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 48, 32, 4)
     img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    ref, ost = osc.render(ocam, 4, traversal=1)
+    ref, ost = osc.render(ocam, 4, traversal=2)  # the walk over the folded four-slot records
     assert_same_frame(img, ref)
     for k in ("rays", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "escaped_paths"):
+        assert st[k] == ost[k], k
+
+
+def test_traversal_stack_overflow_strip(monkeypatch):
+    """The traversal keeps the first entries of a lane's stack in LDS and the rest in an HBM
+    strip (device_path.h LaneStack).  With only two entries in LDS nearly every query uses the
+    strip; the frame and the work counters must not change."""
+    monkeypatch.setenv("RAYRS_STACK_LDS", "2")
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 64, 48, 4)
+    assert scene.info()["wide_depth"] > 8
+    img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    ref, ost = osc.render(ocam, 4, traversal=2)
+    assert_same_frame(img, ref)
+    for k in ("rays", "interior_visits", "tri_tests", "plane_tests"):
         assert st[k] == ost[k], k
 
 
