@@ -380,6 +380,7 @@ static SceneDev make_scene_dev(const rayrs_scene* s) {
     sc.stack_depth = s->flat.wide_depth ? s->flat.wide_depth : 1;
     sc.stack_lds = s->stack_lds;
     sc.hot_records = s->hot_records;
+    sc.n_surfaces = (uint32_t)s->surfaces.size();
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;

@@ -93,6 +93,8 @@ struct SceneDev {
     uint32_t stack_depth;  // entries a traversal can have pending (FlatScene::wide_depth)
     uint32_t stack_lds;    // how many of them live in LDS; the rest overflow to HBM (LaneStack)
     uint32_t hot_records;  // leading wide records the traversal kernel copies to LDS (HotNodes)
+    uint32_t n_surfaces;
+    uint32_t pad0;
     double root_box[6];
     double t0, t1;  // Scene::t_range, lib.rs:218
 };

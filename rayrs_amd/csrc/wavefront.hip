@@ -30,6 +30,7 @@ namespace rayrs {
 
 constexpr uint32_t SPL = 8;             // state bytes per lane
 constexpr uint32_t WINDOW = 64 * SPL;  // slots per window
+constexpr uint32_t HIT_SURFACES_LDS = 32;
 
 // Builds, in LDS, the list of slots of window `win` whose state is `want`.
 // Returns the list length (wave-uniform).  list entries are offsets inside the window.
@@ -431,6 +432,13 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
 template <bool COMPACT>
 __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
+    // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
+    // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
+    __shared__ SurfaceDev s_surf[HIT_SURFACES_LDS];
+    const uint32_t n_surf_lds = sc.n_surfaces < HIT_SURFACES_LDS ? sc.n_surfaces : HIT_SURFACES_LDS;
+    for (uint32_t i = threadIdx.x; i < n_surf_lds * (uint32_t)(sizeof(SurfaceDev) / 4); i += 256u)
+        reinterpret_cast<uint32_t*>(s_surf)[i] = reinterpret_cast<const uint32_t*>(sc.surfaces)[i];
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -466,7 +474,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             const V3 position = v_add(o, v_scale(d, t));
             const V3 normal = prim_normal<COMPACT>(rec, position);
             const V3 view = v_unit(v_scale(d, -1.0));
-            const SurfaceDev* surf = sc.surfaces + (rec.tag() >> 8);
+            const uint32_t sid = rec.tag() >> 8;
+            const SurfaceDev* surf = sid < n_surf_lds ? &s_surf[sid] : sc.surfaces + sid;
             const Scatter ev = material_evaluate(surf, normal, view, rng);
             if (ev.scatter) {
                 light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
