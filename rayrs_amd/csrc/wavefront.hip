@@ -34,17 +34,24 @@ constexpr uint32_t HIT_SURFACES_LDS = 32;
 
 // Builds, in LDS, the list of slots of window `win` whose state is `want`.
 // Returns the list length (wave-uniform).  list entries are offsets inside the window.
-RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint16_t* list) {
+static_assert(SPL == 8, "StateWords/BatchFeed assume two words per lane");
+struct StateWords {
+    uint32_t w[SPL / 4];  // this lane's SPL state bytes of a window
+};
+
+RR_DEV StateWords load_state_words(const WfDev& wf, uint32_t win) {
+    // np is a multiple of 1024 (the host rounds the pool up), so the load is in range
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(wf.state + win * WINDOW) + (threadIdx.x & 63u) * (SPL / 4);
+    StateWords r;
+#pragma unroll
+    for (uint32_t k = 0; k < SPL / 4; k++) r.w[k] = src[k];
+    return r;
+}
+
+RR_DEV uint32_t compact_words(const StateWords& sw, uint8_t want, uint16_t* list) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    const uint32_t base = win * WINDOW;
-    // np is a multiple of 1024 (the host rounds the pool up), so the load is in range
-    uint32_t words[SPL / 4];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(wf.state + base) + lane * (SPL / 4);
-#pragma unroll
-        for (uint32_t k = 0; k < SPL / 4; k++) words[k] = src[k];
-    }
+    const uint32_t* words = sw.w;
     uint32_t count = 0;
 #pragma unroll
     for (int j = 0; j < (int)SPL; j++) {
@@ -55,6 +62,48 @@ RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint
         count += (uint32_t)__popcll(mask);
     }
     return count;
+}
+
+RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint16_t* list) {
+    return compact_words(load_state_words(wf, win), want, list);
+}
+
+// The hit and miss kernels' walk over their slots: wave g of n_waves takes windows g,
+// g + n_waves, ... and within a window the slots of state `want`, 64 at a time.  The state
+// bytes of the following window are loaded while the current one is being worked on, and the
+// kernels fetch batch b + 1's slot records before they compute batch b, so that a wave waits
+// for memory once per batch (the record that depends on the slot's contents) instead of three
+// times.
+struct BatchFeed {
+    uint32_t win, next_win, n_waves, n_windows, count, k, total;  // wave-uniform
+    StateWords ahead;                                            // state bytes of window next_win
+    uint8_t want;
+    uint16_t* list;
+};
+
+RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_waves, uint8_t want, uint16_t* list) {
+    f.win = 0, f.next_win = wave, f.n_waves = n_waves, f.n_windows = wf.np / WINDOW;
+    f.count = 0, f.k = 0, f.total = 0, f.want = want, f.list = list;
+    f.ahead.w[0] = f.ahead.w[1] = 0;
+    if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
+}
+
+// Next batch: false when the wave's windows are exhausted.
+RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    while (f.k >= f.count) {
+        if (f.next_win >= f.n_windows) return false;
+        f.win = f.next_win;
+        f.next_win += f.n_waves;
+        f.count = compact_words(f.ahead, f.want, f.list);
+        f.total += f.count;
+        f.k = 0;
+        if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
+    }
+    valid = f.k + lane < f.count;
+    slot = f.win * WINDOW + (valid ? (uint32_t)f.list[f.k + lane] : 0u);
+    f.k += 64u;
+    return true;
 }
 
 // Sum over the 64 lanes (every lane must call it); the result is valid in lane 0 (and all lanes).
@@ -429,6 +478,31 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
 
 // -------------------------------------------------------------------- hit
 
+// What a batch reads from its slots before anything can be computed.
+struct HitIn {
+    uint32_t slot;
+    bool valid;
+    V3 o, d, thr, light;
+    double t;
+    uint32_t prim, bd;
+    uint64_t key;
+    ItemRegs ir;
+};
+
+RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0: harmless
+    const RaySlot* rs = &wf.slots[h.slot].ray;
+    const HotSlot* hs = &wf.slots[h.slot].hot;
+    h.o = mk(rs->o[0], rs->o[1], rs->o[2]);
+    h.d = mk(rs->d[0], rs->d[1], rs->d[2]);
+    h.t = rs->t;
+    h.prim = rs->prim;
+    h.bd = rs->bd;
+    h.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+    h.light = mk(hs->light[0], hs->light[1], hs->light[2]);
+    h.key = hs->key;
+    h.ir = load_item(wf, h.slot);
+}
+
 template <bool COMPACT>
 __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
@@ -439,36 +513,39 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     for (uint32_t i = threadIdx.x; i < n_surf_lds * (uint32_t)(sizeof(SurfaceDev) / 4); i += 256u)
         reinterpret_cast<uint32_t*>(s_surf)[i] = reinterpret_cast<const uint32_t*>(sc.surfaces)[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n_windows = wf.np / WINDOW;
     unsigned long long n_paths = 0;
     uint32_t retired = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
-    for (uint32_t win = wave; win < n_windows; win += n_waves) {
-        const uint32_t count = compact_window(wf, win, WF_HIT, list);
-        for (uint32_t k = 0; k < count; k += 64u) {
-            const bool valid = k + lane < count;
-            const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
+    BatchFeed feed;
+    feed_init(feed, wf, wave, n_waves, WF_HIT, list);
+    HitIn cur;
+    bool have = feed_next(feed, wf, cur.slot, cur.valid);
+    if (have) load_hit_in(wf, cur);
+    while (have) {
+        HitIn nxt;
+        const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
+        if (have_next) load_hit_in(wf, nxt);
+        {
+            const uint32_t slot = cur.slot;
+            const bool valid = cur.valid;
             bool ended = false;
-            ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
+            ItemRegs ir = cur.ir;
             if (valid) {
             RaySlot* rs = &wf.slots[slot].ray;
             HotSlot* hs = &wf.slots[slot].hot;
-            const V3 o = mk(rs->o[0], rs->o[1], rs->o[2]);
-            const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
-            const double t = rs->t;
-            const uint32_t prim = rs->prim;
-            const uint32_t bounce = rs->bd & 0xffffu;
+            const V3 o = cur.o;
+            const V3 d = cur.d;
+            const double t = cur.t;
+            const uint32_t prim = cur.prim;
+            const uint32_t bounce = cur.bd & 0xffffu;
             // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
-            const V3 thr_in = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-            const V3 light_in = mk(hs->light[0], hs->light[1], hs->light[2]);
-            V3 thr = bounce > 1u ? thr_in : mk(1.0, 1.0, 1.0);
-            V3 light = bounce > 1u ? light_in : mk(0.0, 0.0, 0.0);
-            Rng rng{hs->key, rs->bd >> 16};
+            V3 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
+            V3 light = bounce > 1u ? cur.light : mk(0.0, 0.0, 0.0);
+            Rng rng{cur.key, cur.bd >> 16};
             // lib.rs:528-551
             const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
             const V3 position = v_add(o, v_scale(d, t));
@@ -505,6 +582,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             }
             next_sample(ended, slot, ir, true, cam, rp, wf, range, n_paths, retired);
         }
+        cur = nxt;
+        have = have_next;
     }
     store_item_range(wf, wave, range);
     wave_atomic_add(&rp.counters->paths, n_paths);
@@ -516,41 +595,58 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
 
 // ------------------------------------------------------------------- miss
 
+struct MissIn {
+    uint32_t slot;
+    bool valid;
+    V3 d, thr, light;
+    uint32_t bd;
+    ItemRegs ir;
+};
+
+RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 0: harmless
+    const RaySlot* rs = &wf.slots[m.slot].ray;
+    const HotSlot* hs = &wf.slots[m.slot].hot;
+    m.d = mk(rs->d[0], rs->d[1], rs->d[2]);
+    m.bd = rs->bd;
+    m.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+    m.light = mk(hs->light[0], hs->light[1], hs->light[2]);
+    m.ir = load_item(wf, m.slot);
+}
+
 __global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n_windows = wf.np / WINDOW;
     unsigned long long n_escaped = 0, n_paths = 0;
     uint32_t retired = 0;
     ItemRange range = load_item_range(wf, wave);
-    for (uint32_t win = wave; win < n_windows; win += n_waves) {
-        const uint32_t count = compact_window(wf, win, WF_MISS, list);
-        n_escaped += count;
-        for (uint32_t k = 0; k < count; k += 64u) {
-            const bool valid = k + lane < count;
-            const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            ItemRegs ir = load_item(wf, slot);  // slot 0 for idle lanes: harmless
-            if (valid) {
-            const RaySlot* rs = &wf.slots[slot].ray;
-            const HotSlot* hs = &wf.slots[slot].hot;
-            const V3 d = mk(rs->d[0], rs->d[1], rs->d[2]);
-            // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
-            const V3 thr_in = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-            const V3 light_in = mk(hs->light[0], hs->light[1], hs->light[2]);
-            const bool first = (rs->bd & 0xffffu) <= 1u;
-            const V3 thr = first ? mk(1.0, 1.0, 1.0) : thr_in;
-            const V3 light = first ? mk(0.0, 0.0, 0.0) : light_in;
-            const V3 result = v_add(light, v_mul(thr, background(sc, d)));  // lib.rs:555
+    BatchFeed feed;
+    feed_init(feed, wf, wave, n_waves, WF_MISS, list);
+    MissIn cur;
+    bool have = feed_next(feed, wf, cur.slot, cur.valid);
+    if (have) load_miss_in(wf, cur);
+    while (have) {
+        MissIn nxt;
+        const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
+        if (have_next) load_miss_in(wf, nxt);
+        ItemRegs ir = cur.ir;
+        if (cur.valid) {
+            // throughput and light are loaded unconditionally and ignored while bounce == 1 (lib.rs:522-523)
+            const bool first = (cur.bd & 0xffffu) <= 1u;
+            const V3 thr = first ? mk(1.0, 1.0, 1.0) : cur.thr;
+            const V3 light = first ? mk(0.0, 0.0, 0.0) : cur.light;
+            const V3 result = v_add(light, v_mul(thr, background(sc, cur.d)));  // lib.rs:555
             ir.acc[0] += result.x;
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
-            }
-            next_sample(valid, slot, ir, true, cam, rp, wf, range, n_paths, retired);
         }
+        next_sample(cur.valid, cur.slot, ir, true, cam, rp, wf, range, n_paths, retired);
+        cur = nxt;
+        have = have_next;
     }
+    n_escaped = feed.total;
     store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
     wave_atomic_add(&rp.counters->paths, n_paths);
