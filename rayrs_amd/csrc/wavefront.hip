@@ -613,7 +613,7 @@ RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 
     m.ir = load_item(wf, m.slot);
 }
 
-__global__ void __launch_bounds__(256, 2) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+__global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
