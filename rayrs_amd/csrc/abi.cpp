@@ -32,7 +32,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 constexpr uint32_t MAX_STACK_DEPTH = 96;  // 4 waves * 64 lanes * 96 * 4 B = 96 KiB of LDS per workgroup (self-test kernel)
 constexpr uint32_t TRAV_STACK_LDS = 12;
-constexpr uint32_t TRAV_HOT_BYTES = 15u * 1024u;
+constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 
 }  // namespace
 
@@ -267,7 +267,7 @@ static int scene_upload(rayrs_scene* s) {
     // A traversal workgroup's LDS: the first stack_lds entries of each lane's stack (deeper
     // entries overflow to HBM; measured on the 1M-triangle scene 99.9 % of visits happen with
     // at most 10 pending), 4 KiB of window lists, and the hot_records largest wide records.
-    // 12 + 4 + 15 KiB lets five workgroups (the kernel's launch bound) share a CU's 160 KiB.
+    // 13 + 4 + 14 KiB lets five workgroups (the kernel's launch bound) share a CU's 160 KiB.
     const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
     s->stack_lds = depth < TRAV_STACK_LDS ? depth : TRAV_STACK_LDS;
     if (const char* env = getenv("RAYRS_STACK_LDS")) {

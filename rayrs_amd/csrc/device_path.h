@@ -245,7 +245,7 @@ constexpr uint32_t TRAV_DONE = 0xffffffffu;
 // strip of HBM (entry k at spill[(k - cap) * stride]).  Sizing LDS for the common case
 // instead of the bound is what lets five workgroups share a CU on the 1M-triangle scene.
 struct LaneStack {
-    uint32_t* lds;
+    uint32_t* lds;  // cap entries and one spare (never read) that branch-free pushes may scribble on
     uint32_t* spill;
     uint32_t cap, stride;
     RR_DEV void put(int k, uint32_t v) const {
@@ -365,34 +365,45 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         else x = gsrc[9], y = gsrc[10], z = gsrc[11];
         h3 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e3);
     }
-    // a direct leaf is not box-tested by the reference (bvh.rs:297, :302); an unused slot is never entered
-    const uint32_t k0 = r0 >> 30, k1 = r1 >> 30, k2 = r2 >> 30, k3 = r3 >> 30;
-    h0 = k0 == REF_SINGLE || (k0 != REF_NONE && h0 && !(e0 > tv.best_t));
-    h1 = k1 == REF_SINGLE || (k1 != REF_NONE && h1 && !(e1 > tv.best_t));
-    h2 = k2 == REF_SINGLE || (k2 != REF_NONE && h2 && !(e2 > tv.best_t));
-    h3 = k3 == REF_SINGLE || (k3 != REF_NONE && h3 && !(e3 > tv.best_t));
-    const double far = __builtin_huge_val();
-    e0 = k0 == REF_SINGLE ? tmin : (h0 ? e0 : far);
-    e1 = k1 == REF_SINGLE ? tmin : (h1 ? e1 : far);
-    e2 = k2 == REF_SINGLE ? tmin : (h2 ? e2 : far);
-    e3 = k3 == REF_SINGLE ? tmin : (h3 ? e3 : far);
+    // Direct leaves and unused slots need no special case here: their records carry the
+    // all-of-space and the inverted box (scene_host.cpp), for which the slab test above says
+    // "entered at t0" and "missed".  Boxes entered beyond the closest hit so far are skipped.
+    h0 = h0 && !(e0 > tv.best_t);
+    h1 = h1 && !(e1 > tv.best_t);
+    h2 = h2 && !(e2 > tv.best_t);
+    h3 = h3 && !(e3 > tv.best_t);
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (n == 0) {
         trav_pop(stack, tv);
         return;
     }
-    // rank of a hit slot = number of hit slots visited before it
+    const double far = __builtin_huge_val();
+    e0 = h0 ? e0 : far;
+    e1 = h1 ? e1 : far;
+    e2 = h2 ? e2 : far;
+    e3 = h3 ? e3 : far;
+    // rank of a hit slot = number of hit slots visited before it (nearer entry, then lower slot)
     const int c01 = e1 < e0, c02 = e2 < e0, c03 = e3 < e0, c12 = e2 < e1, c13 = e3 < e1, c23 = e3 < e2;
     const int k_0 = c01 + c02 + c03;
-    const int k_1 = (1 - c01) + c12 + c13;
-    const int k_2 = (1 - c02) + (1 - c12) + c23;
-    const int k_3 = (1 - c03) + (1 - c13) + (1 - c23);
-    const int top = tv.sp + n - 1;  // rank k >= 1 is stored at entry top - k
-    if (h0) { if (k_0 == 0) tv.cur = r0; else stack.put(top - k_0, r0); }
-    if (h1) { if (k_1 == 0) tv.cur = r1; else stack.put(top - k_1, r1); }
-    if (h2) { if (k_2 == 0) tv.cur = r2; else stack.put(top - k_2, r2); }
-    if (h3) { if (k_3 == 0) tv.cur = r3; else stack.put(top - k_3, r3); }
+    const int k_1 = 1 - c01 + c12 + c13;
+    const int k_2 = 2 - c02 - c12 + c23;
+    const int k_3 = 3 - c03 - c13 - c23;
+    tv.cur = (h0 && k_0 == 0) ? r0 : (h1 && k_1 == 0) ? r1 : (h2 && k_2 == 0) ? r2 : r3;
+    // rank k >= 1 goes to stack entry top - k; everything else to the lane's spare entry
+    const int top = tv.sp + n - 1;
     tv.sp = top;
+    if (__ballot((uint32_t)top > stack.cap) == 0ull) {  // all of the wave's entries are in LDS: no branches
+        const int spare = (int)stack.cap;
+        stack.lds[((h0 && k_0 > 0) ? top - k_0 : spare) * 64] = r0;
+        stack.lds[((h1 && k_1 > 0) ? top - k_1 : spare) * 64] = r1;
+        stack.lds[((h2 && k_2 > 0) ? top - k_2 : spare) * 64] = r2;
+        stack.lds[((h3 && k_3 > 0) ? top - k_3 : spare) * 64] = r3;
+    } else {
+        if (h0 && k_0 > 0) stack.put(top - k_0, r0);
+        if (h1 && k_1 > 0) stack.put(top - k_1, r1);
+        if (h2 && k_2 > 0) stack.put(top - k_2, r2);
+        if (h3 && k_3 > 0) stack.put(top - k_3, r3);
+    }
 }
 
 // One leaf reference: its 1..4 primitives in DFS order, then pop.

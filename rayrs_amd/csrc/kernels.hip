@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev r
 
 // ------------------------------------------------------------ launch glue
 
-static inline uint32_t lds_bytes_for(uint32_t stack_depth) { return 4u * 64u * stack_depth * 4u; }
+static inline uint32_t lds_bytes_for(uint32_t stack_depth) { return 4u * 64u * (stack_depth + 1u) * 4u; }  // + the spare entry
 
 hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream) {
     const uint64_t n = (uint64_t)rp.n_local_tiles * 64u;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const LaneStack stack{lds_stack + (size_t)wave * sc.stack_depth * 64u + lane, nullptr, sc.stack_depth, 0u};
+    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_depth + 1u) * 64u + lane, nullptr, sc.stack_depth, 0u};
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double t = 0.0;

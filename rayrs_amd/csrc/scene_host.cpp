@@ -456,18 +456,26 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     }
     f.compact = compact;
 
-    // ---- wide interior records
+    // ---- wide interior records.  The two kinds of slot whose box the reference never tests get
+    // boxes that make the kernel's ordinary slab test say the right thing without looking at
+    // the kind: a direct leaf (bvh.rs:297, :302) is all of space -- always entered, at entry
+    // parameter t0, ahead of every tested box -- and an unused slot is the inverted box
+    // [+inf, -inf], which no ray enters.
     const uint32_t n_wide = f.n_wide();
+    const double inf = std::numeric_limits<double>::infinity();
+    auto slot_bound = [&](uint32_t r, int ch, int k) {
+        const uint32_t kind = f.wide_ref[(size_t)r * 4 + ch] >> 30;
+        if (kind == REF_SINGLE) return (k & 1) ? inf : -inf;
+        if (kind == REF_NONE) return (k & 1) ? -inf : inf;
+        return f.wide_box[((size_t)r * 4 + ch) * 6 + k];
+    };
     if (compact) {
         f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F32), 0);
         Node4F32* nodes = reinterpret_cast<Node4F32*>(f.node_bytes.data());
         for (uint32_t r = 0; r < n_wide; r++)
             for (int ch = 0; ch < 4; ch++) {
                 nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
-                const uint32_t kind = nodes[r].ref[ch] >> 30;
-                const bool unused = kind == REF_SINGLE || kind == REF_NONE;
-                for (int k = 0; k < 6; k++)
-                    nodes[r].box[ch][k] = unused ? 0.f : (float)f.wide_box[((size_t)r * 4 + ch) * 6 + k];
+                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = (float)slot_bound(r, ch, k);
             }
     } else {
         f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F64), 0);
@@ -475,7 +483,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
         for (uint32_t r = 0; r < n_wide; r++)
             for (int ch = 0; ch < 4; ch++) {
                 nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
-                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = f.wide_box[((size_t)r * 4 + ch) * 6 + k];
+                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = slot_bound(r, ch, k);
             }
     }
 

@@ -337,11 +337,11 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // dynamic LDS: 4 stacks of stack_lds x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
-    const LaneStack stack{lds_dyn + (size_t)wave * sc.stack_lds * 64u + lane,
+    // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
+    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane,
                           wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)sc.stack_lds * 64u) + wave * WINDOW;
-    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)sc.stack_lds * 64u + 4u * WINDOW / 2u);
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u) + wave * WINDOW;
+    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u + 4u * WINDOW / 2u);
     {
         constexpr uint32_t G = COMPACT ? 8u : 16u;  // 16-byte granules per record
         const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
 // ----------------------------------------------------------- launch glue
 
 static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
-    return 4u * 64u * stack_lds * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
+    return 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
 }
 
 uint32_t wf_window_slots() { return WINDOW; }
