@@ -365,6 +365,9 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         else x = gsrc[9], y = gsrc[10], z = gsrc[11];
         h3 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e3);
     }
+    // keep the references' load with the boxes' (the compiler would otherwise sink it below the
+    // "any slot hit" branch, a second memory round trip per step)
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     // Direct leaves and unused slots need no special case here: their records carry the
     // all-of-space and the inverted box (scene_host.cpp), for which the slab test above says
     // "entered at t0" and "missed".  Boxes entered beyond the closest hit so far are skipped.
@@ -377,17 +380,13 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         trav_pop(stack, tv);
         return;
     }
-    const double far = __builtin_huge_val();
-    e0 = h0 ? e0 : far;
-    e1 = h1 ? e1 : far;
-    e2 = h2 ? e2 : far;
-    e3 = h3 ? e3 : far;
-    // rank of a hit slot = number of hit slots visited before it (nearer entry, then lower slot)
-    const int c01 = e1 < e0, c02 = e2 < e0, c03 = e3 < e0, c12 = e2 < e1, c13 = e3 < e1, c23 = e3 < e2;
-    const int k_0 = c01 + c02 + c03;
-    const int k_1 = 1 - c01 + c12 + c13;
-    const int k_2 = 2 - c02 - c12 + c23;
-    const int k_3 = 3 - c03 - c13 - c23;
+    // rank of a hit slot = number of hit slots visited before it (nearer entry, then lower slot);
+    // for a < b, slot a goes first unless e_b < e_a
+    const bool c01 = e1 < e0, c02 = e2 < e0, c03 = e3 < e0, c12 = e2 < e1, c13 = e3 < e1, c23 = e3 < e2;
+    const int k_0 = (int)(h1 && c01) + (int)(h2 && c02) + (int)(h3 && c03);
+    const int k_1 = (int)(h0 && !c01) + (int)(h2 && c12) + (int)(h3 && c13);
+    const int k_2 = (int)(h0 && !c02) + (int)(h1 && !c12) + (int)(h3 && c23);
+    const int k_3 = (int)(h0 && !c03) + (int)(h1 && !c13) + (int)(h2 && !c23);
     tv.cur = (h0 && k_0 == 0) ? r0 : (h1 && k_1 == 0) ? r1 : (h2 && k_2 == 0) ? r2 : r3;
     // rank k >= 1 goes to stack entry top - k; everything else to the lane's spare entry
     const int top = tv.sp + n - 1;
