@@ -187,6 +187,13 @@ def main():
             if k["launches"] == launches:
                 traffic = k["bytes_per_launch"]
                 traffic_src = "profiles/r01_final_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, calibrated)"
+        # FP64-VALU occupancy of the same kernel, from a PMC pass of the same command (scripts/valu_pass.sh)
+        valu_busy = None
+        vpath = os.path.join(ROOT, "profiles", "r01_final_valu.json")
+        if traffic is not None and os.path.exists(vpath):
+            vk = json.load(open(vpath))["kernels"]["wf_trav_kernel"]
+            if vk["launches"] == launches:
+                valu_busy = vk["valu_busy"]
         abytes = algorithmic_bytes(cst, info) / launches          # per launch
         avg_ms = sum(kernel_ms) / len(kernel_ms) / launches       # per launch, HIP events on the render stream
         achieved = abytes / (avg_ms * 1e-3) / 1e9
@@ -198,7 +205,16 @@ def main():
                     "bytes_per_ray": round(abytes * launches / max(cst["rays"], 1), 1),
                     "interior_visits_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
                     "prim_tests_per_ray": round((cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"])
-                                                / max(cst["rays"], 1), 2)}
+                                                / max(cst["rays"], 1), 2),
+                    # The algorithmic bytes are record fetches of an incoherent tree walk over a 97 MB scene:
+                    # LDS, L1, L2 and the Infinity Cache serve nearly all of them, which is how `achieved`
+                    # can pass the HBM peak.  What reaches HBM is `traffic`; what the kernel actually
+                    # runs out of is FP64 VALU issue (SURVEY.md 8(d)'s secondary ceiling).
+                    "hbm_achieved": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 2),
+                    "hbm_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "fp64_valu_busy": valu_busy,
+                    "fp64_valu_source": None if valu_busy is None else
+                    "profiles/r01_final_valu.json (rocprofv3 SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the kernel)"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
