@@ -358,7 +358,10 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     // runs dry first, through one atomic cursor (WfCtl::next_window), which evens out the
     // waves' finishing times.  All of the pool through the cursor costs a fifth of the waves'
     // time waiting for it: a single word takes about 90 atomics per microsecond on this chip.
+    // Once most slots have run out of work (the tail of a frame, long on a small tile share) the
+    // cursor's atomics are all a launch would wait for, and balance no longer matters: deal everything.
     const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t static_windows = ctl->live_slots < wf.np / 4u ? n_windows : rp.static_windows;
     uint32_t static_next = blockIdx.x * 4u + wave;       // wave-uniform
     uint32_t list_pos = 0, list_len = 0, list_base = 0;  // wave-uniform
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
@@ -394,10 +397,10 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
                     uint32_t w = static_next;
-                    if (w < rp.static_windows) {
+                    if (w < static_windows) {
                         static_next += n_waves;
                     } else {
-                        if (lane == 0) w = rp.static_windows + atomicAdd(&ctl->next_window, 1u);
+                        if (lane == 0) w = static_windows + atomicAdd(&ctl->next_window, 1u);
                         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
                     }
                     if (w >= n_windows) {
