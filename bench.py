@@ -61,7 +61,9 @@ def main():
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json configs[n-1]; 5 is the headline")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only)")
     ap.add_argument("--res", type=int, default=0, help="override resolution (development only)")
-    ap.add_argument("--sample-chunk", type=int, default=16)
+    ap.add_argument("--sample-chunk", type=int, default=4,
+                    help="samples summed per item (0 = the reference's single sum per pixel); small chunks keep the "
+                         "end of a frame, and of a tile share, short")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -181,10 +183,10 @@ def main():
         # in-process): profiles/r01_final_hbm_traffic.json, valid for the unreduced headline workload only
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-        if os.path.exists(tpath) and not reduced and args.config == 5 and world == 1 and args.sample_chunk == 16:
+        if os.path.exists(tpath) and not reduced and args.config == 5 and world == 1:
             tj = json.load(open(tpath))
             k = tj["kernels"]["wf_trav_kernel"]
-            if k["launches"] == launches:
+            if k["launches"] == launches and tj.get("sample_chunk") == args.sample_chunk:
                 traffic = k["bytes_per_launch"]
                 traffic_src = "profiles/r01_final_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, calibrated)"
         # FP64-VALU occupancy of the same kernel, from a PMC pass of the same command (scripts/valu_pass.sh)

@@ -178,19 +178,26 @@ RR_BIG double rr_cos(double x) {
     }
 }
 
-/* sin and cos of the same argument (one reduction). */
-RR_BIG void rr_sincos(double x, double* s, double* c) {
+/* sin and cos of the same argument (one reduction).  Returned by value: through pointers the
+ * results of this (non-inlined, on the device) function would travel through scratch memory. */
+typedef struct {
+    double s, c;
+} rr_sincos_t;
+
+RR_BIG rr_sincos_t rr_sincos(double x) {
     double r, t;
     int q;
     rr_rem_pio2(x, &r, &t, &q);
     double ks = rr_ksin(r, t);
     double kc = rr_kcos(r, t);
+    rr_sincos_t out;
     switch (q) {
-        case 0: *s = ks; *c = kc; break;
-        case 1: *s = kc; *c = -ks; break;
-        case 2: *s = -ks; *c = -kc; break;
-        default: *s = -kc; *c = ks; break;
+        case 0: out.s = ks; out.c = kc; break;
+        case 1: out.s = kc; out.c = -ks; break;
+        case 2: out.s = -ks; out.c = -kc; break;
+        default: out.s = -kc; out.c = ks; break;
     }
+    return out;
 }
 
 /* tan as a quotient of the two kernels.  tan(acos(0)) = tan(0x1.921fb54442d18p+0)
@@ -341,7 +348,7 @@ RR_BIG double rr_acos(double x) {
 
 /* ----------------------------------------------------------- atan / atan2 */
 
-RR_BIG double rr_atan(double x) {
+RR_FN double rr_atan_inl(double x) {
     const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
                  atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
     const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
@@ -395,13 +402,17 @@ RR_BIG double rr_atan(double x) {
     return sign ? -z : z;
 }
 
+/* the same as a real function for callers that want one (a nested call from rr_atan2 would make
+ * that function spill its return address to scratch on the device) */
+RR_BIG double rr_atan(double x) { return rr_atan_inl(x); }
+
 RR_BIG double rr_atan2(double y, double x) {
     const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
     if (rr_isnan(x) || rr_isnan(y)) return x + y;
     uint64_t ux = rr_f64_bits(x), uy = rr_f64_bits(y);
     uint32_t ix = (uint32_t)(ux >> 32), lx = (uint32_t)ux;
     uint32_t iy = (uint32_t)(uy >> 32), ly = (uint32_t)uy;
-    if (((ix - 0x3ff00000u) | lx) == 0) return rr_atan(y); /* x = 1.0 */
+    if (((ix - 0x3ff00000u) | lx) == 0) return rr_atan_inl(y); /* x = 1.0 */
     uint32_t m = ((iy >> 31) & 1u) | ((ix >> 30) & 2u);    /* 2*sign(x)+sign(y) */
     ix &= 0x7fffffffu;
     iy &= 0x7fffffffu;
@@ -437,7 +448,7 @@ RR_BIG double rr_atan2(double y, double x) {
     if ((m & 2) && iy + (64u << 20) < ix) /* |y/x| < 2**-64, x < 0 */
         z = 0.0;
     else
-        z = rr_atan(rr_fabs(y / x));
+        z = rr_atan_inl(rr_fabs(y / x));
     switch (m) {
         case 0: return z;
         case 1: return -z;

@@ -577,8 +577,8 @@ RR_DEV V3 beckmann_generate(double alpha2, V3 n, Rng& rng, double& value) {
     const double tan2theta = -alpha2 * rr_log(1.0 - rng.next());
     const double costheta = 1.0 / rr_sqrt(1.0 + tan2theta);
     const double sintheta = rr_sqrt(1.0 - costheta * costheta);
-    double sp, cp;
-    rr_sincos(phi, &sp, &cp);
+    const rr_sincos_t sc_phi = rr_sincos(phi);
+    const double sp = sc_phi.s, cp = sc_phi.c;
     const double x = cp * sintheta;
     const double y = sp * sintheta;
     const V3 h = v_add(v_add(v_scale(e1, x), v_scale(e2, y)), v_scale(n, costheta));
@@ -630,8 +630,8 @@ RR_DEV Scatter lambertian_scatter(V3 color_in, V3 n, Rng& rng) {  // :259-281, :
     const double u = rng.next();
     const double phi = 2.0 * RR_PI * rng.next();
     const double su = rr_sqrt(u);
-    double sp, cp;
-    rr_sincos(phi, &sp, &cp);
+    const rr_sincos_t sc_phi = rr_sincos(phi);
+    const double sp = sc_phi.s, cp = sc_phi.c;
     const double x = cp * su;
     const double y = sp * su;
     const double z = rr_sqrt(1.0 - u);

@@ -36,7 +36,9 @@ for k in agg:
     n = len({d for w, d in disp[k] if w == "fetch"})
     res[k] = {"launches": n, "fetch_KiB": agg[k].get("FETCH_SIZE", 0.0), "write_KiB": agg[k].get("WRITE_SIZE", 0.0),
               "bytes_per_launch": int((agg[k].get("FETCH_SIZE", 0.0) + agg[k].get("WRITE_SIZE", 0.0)) * 1024 / max(n, 1))}
-json.dump({"kernels": res}, open(out + "/hbm_traffic.json", "w"), indent=1)
+bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
+json.dump({"workload": bench["config"]["workload"], "sample_chunk": bench["config"]["sample_chunk"], "kernels": res},
+          open(out + "/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf $OUT/fetch $OUT/write $OUT/stats
