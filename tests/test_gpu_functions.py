@@ -94,7 +94,35 @@ def _rays(n, seed, spread=6.0):
     return np.ascontiguousarray(o), np.ascontiguousarray(d)
 
 
+def _object_soup():
+    """Mixed primitives, coincident centres (median fallback), and five-object splits whose
+    left side is a direct leaf: the wide records then hold all-of-space slots and unused ones."""
+    from rayrs_amd.api import Emission, Object
+    r = np.random.default_rng(4)
+    nr, dark = Material.NoReflect(), Emission.Dark()
+    objs = []
+    for i in range(300):
+        c = r.uniform(-2.5, 2.5, 3)
+        c[1] = abs(c[1])
+        if i % 3 == 0:
+            objs.append(Object.sphere(float(r.uniform(0.05, 0.4)), c, nr, dark))
+        elif i % 3 == 1:
+            objs.append(Object.plane(int(r.integers(0, 6)), c[0], c[0] + 0.5, c[1], c[1] + 0.7, c[2], nr, dark))
+        else:
+            objs.append(Object.triangle(c, c + r.uniform(-1, 1, 3), c + r.uniform(-1, 1, 3), nr, dark))
+    objs += [Object.sphere(0.3, (1.0, 1.0, 1.0), nr, dark) for _ in range(9)]
+    return None, objs, scenes.SAH_1000
+
+
+def _five_with_single_leaf():
+    from rayrs_amd.api import Emission, Object
+    objs = [Object.sphere(0.5, (float(x), 1.0, 0.0), Material.NoReflect(), Emission.Dark()) for x in (-2, 0.5, 1, 1.5, 2)]
+    return None, objs, scenes.SAH_1000
+
+
 SCENES = {
+    "object_soup": _object_soup,
+    "five_with_single_leaf": _five_with_single_leaf,
     "single_sphere": lambda: scenes.diffuse_single_sphere(),
     "sphere_row": lambda: scenes.cook_torrance_spheres_metallic(),
     "mesh_1280_light": lambda: scenes.mesh_scene(3, area_light=True),
@@ -115,6 +143,9 @@ def test_bvh_intersect_matches_reference_traversal(name):
     # against the reference's recursive, un-narrowed traversal (bvh.rs:391-415)
     rt, robj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
     assert (robj >= 0).sum() > 100
+    if name == "five_with_single_leaf":
+        kinds = scene.export_wide()[1] >> 30
+        assert (kinds == 2).any() and (kinds == 3).any()  # a direct leaf and an unused slot
     assert np.array_equal(obj, robj)
     assert np.array_equal(bits(t), bits(rt))
 

@@ -149,3 +149,24 @@ def test_draw_counts_per_material():
     assert draws(Material.CookTorranceGlass((1, 1, 1), 0.2, 1.45)) <= {2, 3}
     assert draws(Material.Plastic((0.5, 0.5, 0.5), (1, 1, 1), 0.2, 1.45)) == {3}
     assert draws(Material.NoReflect()) == {0}
+
+
+def test_sentinel_boxes_of_the_wide_records():
+    """The kernel's wide records give the two kinds of slot the reference never box-tests a
+    box instead of a special case (scene_host.cpp): all of space for a direct leaf, the inverted
+    box for an unused slot.  Under AxisAlignedBoundingBox::intersect (geometry.rs:458-513, as
+    restated by the oracle) the first is entered by every ray and the second by none -- for
+    axis-parallel directions (1/0 = inf) and negative ones too."""
+    import ctypes as C
+    import numpy as np
+    L = _oracle.lib()
+    inf = float("inf")
+    everything = (C.c_double * 6)(-inf, inf, -inf, inf, -inf, inf)
+    nothing = (C.c_double * 6)(inf, -inf, inf, -inf, inf, -inf)
+    r = np.random.default_rng(2)
+    dirs = [(1, 0, 0), (0, -1, 0), (0, 0, 1), (-1, -1, -1), (1e-300, 1, 0), (0.0, -0.0, 1.0)]
+    dirs += [tuple(v) for v in r.normal(size=(50, 3))]
+    for d in dirs:
+        for o in [(0, 0, 0), (3.5, -2e6, 7e-9), (-1e300, 1e300, 0)]:
+            assert L.orc_aabb_intersect(everything, _oracle.d3(o), _oracle.d3(d), 1e-6, 1e6) == 1
+            assert L.orc_aabb_intersect(nothing, _oracle.d3(o), _oracle.d3(d), 1e-6, 1e6) == 0
