@@ -46,6 +46,8 @@ if __name__ == "__main__":
         run(5, 1024, 1024, 128, chunk=16, count=True)
     if what == "u2":
         run(2, 1024, 1024, 128, chunk=16, count=True)
+    if what == "big4":
+        run(4, 2048, 2048, 128, chunk=4)
     if what == "big5":
         run(5, 2048, 2048, 64, chunk=16)
     if what == "shard8":
