@@ -15,11 +15,13 @@
 // does.  Every slot carries a one-byte state; a kernel takes a window of 512
 // consecutive slots, compacts the slots that are in its state into a list in LDS
 // (__ballot + popcount rank) and works through the list 64 at a time, so its waves
-// run with all lanes on the same code.  There are no global queues and no atomics
-// on the data path (a single-word atomic counter saturates near 90 updates/us on
-// this chip; the first version of this file, which pushed every slot through global
-// queues, spent most of its time there).  Kernel boundaries on one stream order the
-// state changes; no in-kernel cross-CU hand-off is needed.
+// run with all lanes on the same code.  There are no global queues: a single-word
+// atomic counter saturates near 90 updates/us on this chip, and the first version of
+// this file, which pushed every slot through global queues, spent most of its time
+// there.  What is left of atomics is one per 512-slot window for half of the
+// traversal kernel's windows (load balance) and one per 256 items for new work.
+// Kernel boundaries on one stream order the state changes; no in-kernel cross-CU
+// hand-off is needed.
 #include <hip/hip_runtime.h>
 
 #include "device_path.h"
