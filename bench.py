@@ -119,6 +119,11 @@ def main():
     info = scene.info()
     H, W = cam.y_pixels(), cam.x_pixels()
 
+    # items (pixel, sample chunk) are numbered in 32 bits and each keeps 24 bytes of partial sum:
+    # grow the chunk until a rank's share of the frame stays under 2^30 items (configs[3]: 16)
+    while args.sample_chunk and (H * W // world + 1) * -(-spp // args.sample_chunk) > (1 << 30):
+        args.sample_chunk *= 2
+
     dev = torch.device("cuda", local_rank)
     fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
