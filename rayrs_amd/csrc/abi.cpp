@@ -30,7 +30,6 @@ int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
-constexpr uint32_t MAX_STACK_DEPTH = 96;  // 4 waves * 64 lanes * 96 * 4 B = 96 KiB of LDS per workgroup (self-test kernel)
 constexpr uint32_t TRAV_STACK_LDS = 12;
 constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 
@@ -303,10 +302,6 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     s->n_objects = objs->list.objs.size();
     s->device = device;
     if (device >= 0) {
-        if (s->flat.wide_depth > MAX_STACK_DEPTH) {
-            delete s;
-            return RAYRS_UNSUPPORTED;
-        }
         st = scene_upload(s);
         if (st != RAYRS_OK) {
             scene_free_device(s);
@@ -711,9 +706,12 @@ int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, u
     ST_TRY(dt.alloc(n * 8));
     ST_TRY(dprim.alloc(n * 8));
     const SceneDev sc = make_scene_dev(scene);
+    DevBuf dspill;  // stack entries beyond the LDS part, one strip per thread of the launch
+    const uint64_t threads = (n + 255) / 256 * 256;
+    if (sc.stack_depth > sc.stack_lds) ST_TRY(dspill.alloc((size_t)(sc.stack_depth - sc.stack_lds) * threads * 4));
     if (n)
         HIP_TRY(launch_test_intersect(scene->flat.compact, sc, (const double*)dorg.p, (const double*)ddir.p, n,
-                                      (double*)dt.p, (long long*)dprim.p, nullptr));
+                                      (double*)dt.p, (long long*)dprim.p, (uint32_t*)dspill.p, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     ST_TRY(dt.download(t, n * 8));
     ST_TRY(dprim.download(object, n * 8));

@@ -12,7 +12,7 @@ hipError_t launch_test_math(int fn, const double* x, const double* y, uint64_t n
 hipError_t launch_test_rng(uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
                            uint64_t n, uint64_t* out, hipStream_t stream);
 hipError_t launch_test_intersect(bool compact, const SceneDev& sc, const double* o, const double* d, uint64_t n,
-                                 double* t_out, long long* prim_out, hipStream_t stream);
+                                 double* t_out, long long* prim_out, uint32_t* spill, hipStream_t stream);
 hipError_t launch_test_material(const SurfaceDev* surf, const double* normal, const double* view, const uint64_t* key,
                                 uint64_t n, int32_t* scattered, double* color, double* dir, uint32_t* draws,
                                 hipStream_t stream);

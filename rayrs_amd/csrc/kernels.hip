@@ -85,12 +85,14 @@ __global__ void test_rng_kernel(uint64_t seed, const uint64_t* pixel, const uint
 
 template <bool COMPACT>
 __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const double* o, const double* d, uint64_t n,
-                                                             double* t_out, long long* prim_out) {
+                                                             double* t_out, long long* prim_out, uint32_t* spill) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_depth + 1u) * 64u + lane, nullptr, sc.stack_depth, 0u};
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // sc.stack_lds entries of the stack in LDS, the rest in the strip `spill` (as in the traversal kernel)
+    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill + i, sc.stack_lds,
+                          gridDim.x * blockDim.x};
     if (i >= n) return;
     double t = 0.0;
     uint32_t prim = 0;
@@ -102,19 +104,19 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
 }
 
 hipError_t launch_test_intersect(bool compact, const SceneDev& sc, const double* o, const double* d, uint64_t n,
-                                 double* t_out, long long* prim_out, hipStream_t stream) {
-    const uint32_t lds = lds_bytes_for(sc.stack_depth);
+                                 double* t_out, long long* prim_out, uint32_t* spill, hipStream_t stream) {
+    const uint32_t lds = lds_bytes_for(sc.stack_lds);
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     if (compact) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&test_intersect_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(test_intersect_kernel<true>, dim3(blocks), dim3(256), lds, stream, sc, o, d, n, t_out,
-                           prim_out);
+                           prim_out, spill);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&test_intersect_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(test_intersect_kernel<false>, dim3(blocks), dim3(256), lds, stream, sc, o, d, n, t_out,
-                           prim_out);
+                           prim_out, spill);
     }
     return hipGetLastError();
 }

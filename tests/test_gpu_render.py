@@ -110,6 +110,32 @@ def test_traversal_stack_overflow_strip(monkeypatch):
         assert st[k] == ost[k], k
 
 
+def test_deep_chain_tree_beyond_lds():
+    """A tree that peels two objects per level (pairs of spheres at 1.5**k under the midpoint
+    heuristic; one-object sides would trigger the median fallback, bvh.rs:279-287) is 125 levels
+    deep: ten times what the traversal keeps in LDS and beyond any fixed-size stack.  The
+    reference recurses without a limit; so must this."""
+    from rayrs_amd.api import BvhHeuristic, Emission, Material, Object
+    objs = []
+    for k in range(250):
+        x = 1.5 ** k
+        for j in range(2):
+            objs.append(Object.sphere(0.25 * x if k > 3 else 0.2, (x * (1 + 0.01 * j), 1.0, 0.0),
+                                      Material.LambertianDiffuse((0.8, 0.8, 0.8)), Emission.Dark()))
+    cam_args = ((-3.0, 1.5, 4.0), (0.0, 1.0, 0.0), (20.0, 1.0, 0.0), 70.0, 64 / 254.0, 32 / 254.0, 100)
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e60, BvhHeuristic.Midpoint, HDRI, device=0)
+    assert scene.info()["wide_depth"] > 100
+    cam = rayrs_amd.Camera(*cam_args)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e60, BvhHeuristic.Midpoint, HDRI)
+    ocam = _oracle.OracleCamera(*cam_args)
+    img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    ref, ost = osc.render(ocam, 4, traversal=0)
+    assert_same_frame(img, ref)
+    assert st["rays"] == ost["rays"] and st["sphere_tests"] > st["rays"]
+    ref2, ost2 = osc.render(ocam, 4, traversal=2)
+    assert st["interior_visits"] == ost2["interior_visits"] and st["sphere_tests"] == ost2["sphere_tests"]
+
+
 def test_tile_sharding_is_exact():
     """Two 'ranks' rendering interleaved 8x8 tiles into zeroed buffers sum to the
     single-GPU frame exactly (x + 0): the multi-GPU reduce is order independent."""
