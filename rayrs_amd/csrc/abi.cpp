@@ -451,11 +451,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
-    // and drain are a fixed cost, so large pools win (measured: 1 M slots 1.0, 4 M 2.0,
-    // 16 M 2.4 Gray/s on a 1/8 shard of the headline frame) even when that leaves only
-    // one or two items per slot; 16 M slots are 3.1 GB of the 288 GB.
+    // and drain are a fixed cost, so large pools win even when that leaves only one or two
+    // items per slot -- up to the point where the hit and miss kernels, which touch two or
+    // three scattered lines per slot, lose more to the larger footprint.  Swept on the
+    // headline frame: 4 M slots 2.4, 8 M 2.9, 16 M 3.41, 32 M 3.56, 64 M 3.54, 128 M
+    // 3.45 Gray/s (on a one-eighth tile share 16 M and 32 M tie, 64 M loses 8 %).
+    // 32 M slots are 6.4 GB of the 288 GB.
     uint64_t np64 = rp.total_items;
-    if (np64 > (1ull << 24)) np64 = 1ull << 24;
+    if (np64 > (1ull << 25)) np64 = 1ull << 25;
     if (const char* env = getenv("RAYRS_POOL_SLOTS")) {
         const long long v = atoll(env);
         if (v > 0) np64 = (uint64_t)v;
