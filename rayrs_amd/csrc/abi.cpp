@@ -456,9 +456,16 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // three scattered lines per slot, lose more to the larger footprint.  Swept on the
     // headline frame: 4 M slots 2.4, 8 M 2.9, 16 M 3.41, 32 M 3.56, 64 M 3.54, 128 M
     // 3.45 Gray/s (on a one-eighth tile share 16 M and 32 M tie, 64 M loses 8 %).
-    // 32 M slots are 6.4 GB of the 288 GB.
+    // 32 M slots are 6.4 GB of the 288 GB.  A frame should also last some tens of rounds, or
+    // filling and draining the pool is all it does: at most one slot per 16 samples (on the
+    // 268 M-sample sphere-row frame 16 M slots give 4.9, 32 M 4.3 Gray/s).
     uint64_t np64 = rp.total_items;
     if (np64 > (1ull << 25)) np64 = 1ull << 25;
+    {
+        const uint64_t samples = n_local * 64ull * rp.spp;
+        const uint64_t by_work = samples / 16u > (1ull << 20) ? samples / 16u : (1ull << 20);
+        if (np64 > by_work) np64 = by_work;
+    }
     if (const char* env = getenv("RAYRS_POOL_SLOTS")) {
         const long long v = atoll(env);
         if (v > 0) np64 = (uint64_t)v;
