@@ -32,7 +32,7 @@ typedef enum {
     RAYRS_HIP_ERROR = -2,   /* a HIP runtime call failed (see rayrs_last_error) */
     RAYRS_OOM = -3,
     RAYRS_NO_DEVICE = -4,   /* scene was created host-only or no GPU present */
-    RAYRS_UNSUPPORTED = -5, /* more than 2^32 (pixel, sample chunk) items on a rank, max_bounces > 8000 */
+    RAYRS_UNSUPPORTED = -5, /* more than 2^32 (pixel, sample chunk) items on a rank, max_bounces > 8000, an image side > 65535 */
     RAYRS_IO_ERROR = -6     /* file missing or malformed (see rayrs_io_last_error) */
 } rayrs_status;
 

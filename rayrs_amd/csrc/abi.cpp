@@ -404,6 +404,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (!scene || !camera || !params || !out_device) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
+    if (camera->x_pixels > 65535u || camera->y_pixels > 65535u) return RAYRS_UNSUPPORTED;  // ItemSlot::pix is 16 + 16 bits
     if (params->max_bounces > 8000u) return RAYRS_UNSUPPORTED;  // bounce and draw counters are 16-bit in the pool
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
@@ -429,6 +430,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const uint64_t n_local = n_tiles > rp.tile_rank ? (n_tiles - rp.tile_rank + rp.tile_ranks - 1) / rp.tile_ranks : 0;
     rp.n_local_tiles = (uint32_t)n_local;
     rp.total_items = n_local * rp.nchunks * 64ull;
+    rp.inv_nchunks = 1.0 / (double)rp.nchunks;
+    rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = 52;
     rp.leaf_min = 24;

@@ -123,6 +123,7 @@ struct RenderDev {
     uint32_t n_local_tiles;
     uint32_t out_format;
     uint64_t total_items;  // n_local_tiles * nchunks * 64
+    double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t pad1;

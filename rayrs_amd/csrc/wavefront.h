@@ -36,7 +36,8 @@ struct ItemSlot {
     uint32_t s_cur;   // next sample of the item to start
     uint32_t s_end;
     uint32_t has_item;
-    uint64_t pad;
+    uint32_t pix;     // row << 16 | col of the item's pixel (image coordinates)
+    uint32_t pad;
 };
 static_assert(sizeof(ItemSlot) == 48, "ItemSlot");
 
