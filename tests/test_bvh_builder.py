@@ -172,3 +172,26 @@ def test_large_mesh_builder_agreement():
     owb, owr = orc.export_wide()
     assert np.array_equal(pwr, owr) and np.array_equal(pwb[(pwr >> 30) < 3], owb[(owr >> 30) < 3])
     check_fold(pb, pr, pwb, pwr, prod.info())
+
+
+def test_largest_boxes_lead_the_wide_records():
+    """scene_host.cpp front_largest: the 256 wide records with the largest boxes come first,
+    largest first, the others keep their depth-first order (the traversal kernel holds the
+    first of them in LDS)."""
+    cam, objs, heur = scenes.mesh_scene(5)
+    prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+    box, ref = prod.export_wide()
+    tested = (ref >> 30) < 2
+    lo = np.where(tested[:, :, None], box[:, :, 0::2], np.inf).min(axis=1)
+    hi = np.where(tested[:, :, None], box[:, :, 1::2], -np.inf).max(axis=1)
+    e = hi - lo
+    area = 2.0 * (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 0] * e[:, 2])
+    assert len(area) > 1000
+    front, rest = area[:256], area[256:]
+    assert np.all(front[:-1] >= front[1:])
+    assert front[-1] >= rest.max()
+    # behind the front, a record's children still follow it (depth-first order survives the move)
+    kids = ref[256:][(ref[256:] >> 30) == 0] & 0x3fffffff
+    owner = np.repeat(np.arange(256, len(ref)), 4).reshape(-1, 4)[(ref[256:] >> 30) == 0]
+    later = kids >= 256
+    assert np.all(kids[later] > owner[later])

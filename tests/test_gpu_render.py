@@ -136,6 +136,29 @@ def test_deep_chain_tree_beyond_lds():
     assert st["interior_visits"] == ost2["interior_visits"] and st["sphere_tests"] == ost2["sphere_tests"]
 
 
+def test_launch_limits_are_reported_not_rendered():
+    """What the path pool cannot number is refused with RAYRS_UNSUPPORTED (-5), never rendered
+    wrongly: an image side beyond 16 bits (ItemSlot::pix), more than 2^32 (pixel, chunk) items,
+    a bounce budget beyond the pool's 16-bit bounce/draw counters."""
+    from rayrs_amd import _ffi
+    cam_args, objs, heur = scenes.diffuse_single_sphere()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+
+    def status(cam, **kw):
+        try:
+            rayrs_amd.render_launch(scene, cam, rayrs_amd.make_params(**kw), 16, 0)  # refused before the buffer is touched
+        except _ffi.RayrsError as e:
+            return e.status
+        raise AssertionError("launch accepted")
+
+    wide = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 70000, 8))
+    assert status(wide, spp=1, max_bounces=4) == -5
+    big = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 8192, 8192))
+    assert status(big, spp=4096, max_bounces=4, sample_chunk=8) == -5  # 2^26 pixels * 512 chunks = 2^35 items
+    small = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 8, 8))
+    assert status(small, spp=1, max_bounces=9000) == -5
+
+
 def test_tile_sharding_is_exact():
     """Two 'ranks' rendering interleaved 8x8 tiles into zeroed buffers sum to the
     single-GPU frame exactly (x + 0): the multi-GPU reduce is order independent."""
