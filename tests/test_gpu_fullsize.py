@@ -65,6 +65,6 @@ def test_config4_frosted_glass_depth32_2048x2048_reduced_spp():
 
 
 def test_config5_1m_triangle_ply_mesh_2048x2048_1024spp(tmp_path):
-    scene, cam, img, st, _ = run_config(5, band_rows=2, chunk=16, tmp_path=tmp_path)
+    scene, cam, img, st, _ = run_config(5, band_rows=2, chunk=4, tmp_path=tmp_path)  # bench.py's chunking
     assert scene.info()["n_prims"] == 1310721
     assert st["rays"] > 7_000_000_000
