@@ -150,6 +150,42 @@ def test_bvh_intersect_matches_reference_traversal(name):
     assert np.array_equal(bits(t), bits(rt))
 
 
+def test_bvh_intersect_degenerate_rays_on_an_integer_grid():
+    """Origins on box planes, zero (and negative-zero) direction components, everything on an
+    integer grid: the slab test's inf/NaN cases (geometry.rs:458-513) as the rule, not the
+    exception.  GPU traversal over the folded records against the reference's recursion."""
+    from rayrs_amd.api import BvhHeuristic, Emission, Object
+    r = np.random.default_rng(11)
+    nr, dark = Material.NoReflect(), Emission.Dark()
+    objs = []
+    for i in range(400):
+        c = r.integers(-6, 7, 3).astype(float)
+        if i % 3 == 0:
+            objs.append(Object.sphere(float(r.integers(1, 3)) * 0.5, c, nr, dark))
+        elif i % 3 == 1:
+            objs.append(Object.plane(int(r.integers(0, 6)), c[0], c[0] + 2.0, c[1], c[1] + 1.0, c[2], nr, dark))
+        else:
+            objs.append(Object.triangle(c, c + r.integers(-2, 3, 3), c + r.integers(-2, 3, 3), nr, dark))
+    n = 4000
+    o = r.integers(-8, 9, (n, 3)).astype(float)
+    o[n // 2:] += r.integers(0, 2, (n - n // 2, 3)) * 0.5
+    d = r.integers(-2, 3, (n, 3)).astype(float)
+    d[(d == 0).all(axis=1)] = (1.0, 0.0, 0.0)
+    d[::7, 1] = -0.0
+    o, d = np.ascontiguousarray(o), np.ascontiguousarray(d)
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
+        scene = Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+        t = np.zeros(n)
+        obj = np.zeros(n, dtype=np.int64)
+        _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, n, t.ctypes.data,
+                                                 obj.ctypes.data), "rayrs_test_intersect")
+        rt, robj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
+        assert (robj >= 0).sum() > 500
+        assert np.array_equal(obj, robj)
+        assert np.array_equal(bits(t), bits(rt))
+
+
 MATERIALS = {
     "lambertian": Material.LambertianDiffuse((0.8, 0.7, 0.6)),
     "reflect": Material.Reflect((0.8, 0.8, 0.8)),

@@ -170,3 +170,37 @@ def test_sentinel_boxes_of_the_wide_records():
         for o in [(0, 0, 0), (3.5, -2e6, 7e-9), (-1e300, 1e300, 0)]:
             assert L.orc_aabb_intersect(everything, _oracle.d3(o), _oracle.d3(d), 1e-6, 1e6) == 1
             assert L.orc_aabb_intersect(nothing, _oracle.d3(o), _oracle.d3(d), 1e-6, 1e6) == 0
+
+
+def test_folded_walk_equals_reference_on_degenerate_rays():
+    """Rays built to hit the slab test's special cases -- origins exactly on box planes, direction
+    components exactly zero (1/0 = inf, 0 * inf = NaN, which f64::max/min ignore, geometry.rs:458-513)
+    -- through a scene on an integer grid, so that such coincidences are the rule.  The walk over
+    the folded four-slot records (what the kernel does) must find what the reference's recursion
+    finds: skipping a parent's box in favour of its child's is only sound if the slab test is
+    monotone in these cases too."""
+    r = np.random.default_rng(11)
+    nr, dark = Material.NoReflect(), Emission.Dark()
+    objs = []
+    for i in range(400):
+        c = r.integers(-6, 7, 3).astype(float)
+        if i % 3 == 0:
+            objs.append(Object.sphere(float(r.integers(1, 3)) * 0.5, c, nr, dark))
+        elif i % 3 == 1:
+            objs.append(Object.plane(int(r.integers(0, 6)), c[0], c[0] + 2.0, c[1], c[1] + 1.0, c[2], nr, dark))
+        else:
+            objs.append(Object.triangle(c, c + r.integers(-2, 3, 3), c + r.integers(-2, 3, 3), nr, dark))
+    n = 4000
+    o = r.integers(-8, 9, (n, 3)).astype(float)
+    o[n // 2:] += r.integers(0, 2, (n - n // 2, 3)) * 0.5
+    d = r.integers(-2, 3, (n, 3)).astype(float)
+    d[(d == 0).all(axis=1)] = (1.0, 0.0, 0.0)
+    d[::7, 1] = -0.0  # negative zero: 1/-0 = -inf
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, procedural.make_hdri(32, 16))
+        t0, obj0 = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
+        assert (obj0 >= 0).sum() > 500
+        for trav in (1, 2):
+            t, obj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=trav)
+            assert np.array_equal(obj, obj0), trav
+            assert np.array_equal(t.view(np.uint64), t0.view(np.uint64)), trav
