@@ -20,6 +20,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -823,7 +824,7 @@ struct orc_scene {
     uint32_t* prim_object;
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
-    uint32_t wide_cap;
+    int have_wide;      /* orc_set_wide was called */
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -1250,131 +1251,29 @@ static void flatten(orc_scene* s) {
     s->finfo.root_box[5] = s->root->box.zmax;
 }
 
-/* Two levels of the two-child records folded into one record of up to four slots.  A slot
- * carries the box whose test gates the reference's access to that subtree: a grandchild's
- * own box (boxes nest exactly, so passing it implies passing its parent's), or the parent's
- * box for a grandchild that is a direct leaf (bvh.rs:297, :302 do not test those), which is
- * then written as a one-primitive range.  Returns the wide reference of record `n`. */
-static uint32_t fold_wide(orc_scene* s, uint32_t n, uint32_t* stack_need) {
-    uint32_t rec = s->finfo.n_wide++;
-    uint32_t refs[4];
-    const double* boxes[4];
-    int ns = 0;
-    for (int c = 0; c < 2; c++) {
-        uint32_t r = s->child_ref[(size_t)n * 2 + c];
-        const double* bx = s->child_box + ((size_t)n * 2 + c) * 6;
-        if ((r >> 30) != REF_KIND_INTERIOR) {
-            refs[ns] = r;
-            boxes[ns++] = bx;
-            continue;
-        }
-        uint32_t m = r & 0x3fffffffu;
-        for (int g = 0; g < 2; g++) {
-            uint32_t rg = s->child_ref[(size_t)m * 2 + g];
-            if ((rg >> 30) == REF_KIND_SINGLE) {
-                refs[ns] = (REF_KIND_RANGE << 30) | (rg & 0x3fffffffu);
-                boxes[ns++] = bx;
-            } else {
-                refs[ns] = rg;
-                boxes[ns++] = s->child_box + ((size_t)m * 2 + g) * 6;
-            }
-        }
-    }
-    uint32_t below = 0;
-    for (int i = 0; i < 4; i++) {
-        uint32_t ref = REF_KIND_NONE << 30;
-        if (i < ns) {
-            ref = refs[i];
-            memcpy(s->wide_box + ((size_t)rec * 4 + i) * 6, boxes[i], 6 * sizeof(double));
-            if ((ref >> 30) == REF_KIND_INTERIOR) {
-                uint32_t need = 0;
-                ref = fold_wide(s, ref & 0x3fffffffu, &need);
-                if (need > below) below = need;
-            }
-        }
-        s->wide_ref[(size_t)rec * 4 + i] = ref;
-    }
-    *stack_need = (uint32_t)(ns - 1) + below;
-    return (REF_KIND_INTERIOR << 30) | rec;
-}
-
-/* The product renumbers the wide records: the ORC_WIDE_FRONT records with the largest boxes
- * first (largest first, ties by index), the rest behind them in their depth-first order
- * (scene_host.cpp front_largest; the kernel keeps the front ones in LDS).  Restated here so
- * that the two exports can be compared word for word. */
-#define ORC_WIDE_FRONT 256u
-
-static double wide_record_area(const orc_scene* s, uint32_t rec) {
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    int any = 0;
-    for (int i = 0; i < 4; i++) {
-        uint32_t kind = s->wide_ref[(size_t)rec * 4 + i] >> 30;
-        if (kind != REF_KIND_INTERIOR && kind != REF_KIND_RANGE) continue;
-        const double* b = s->wide_box + ((size_t)rec * 4 + i) * 6;
-        for (int a = 0; a < 3; a++) {
-            if (!any || b[2 * a] < lo[a]) lo[a] = b[2 * a];
-            if (!any || b[2 * a + 1] > hi[a]) hi[a] = b[2 * a + 1];
-        }
-        any = 1;
-    }
-    if (!any) return 0.0;
-    double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-    return 2.0 * (ex * ey + ey * ez + ex * ez);
-}
-
-static void front_largest(orc_scene* s) {
-    uint32_t n = s->finfo.n_wide;
-    uint32_t k = n < ORC_WIDE_FRONT ? n : ORC_WIDE_FRONT;
-    if (k == 0) return;
-    double* area = (double*)malloc((size_t)n * sizeof(double));
-    uint32_t* order = (uint32_t*)malloc((size_t)n * sizeof(uint32_t)); /* order[new] = old */
-    uint32_t* new_of = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
-    uint8_t* taken = (uint8_t*)calloc(n, 1);
-    for (uint32_t r = 0; r < n; r++) area[r] = wide_record_area(s, r);
-    for (uint32_t i = 0; i < k; i++) { /* selection: k passes, first strictly largest wins */
-        uint32_t best = 0xffffffffu;
-        for (uint32_t r = 0; r < n; r++)
-            if (!taken[r] && (best == 0xffffffffu || area[r] > area[best])) best = r;
-        taken[best] = 1;
-        order[i] = best;
-    }
-    uint32_t at = k;
-    for (uint32_t r = 0; r < n; r++)
-        if (!taken[r]) order[at++] = r;
-    for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
-    double* box = (double*)calloc((size_t)(n ? n : 1) * 24, sizeof(double));
-    uint32_t* ref = (uint32_t*)calloc((size_t)(n ? n : 1) * 4, sizeof(uint32_t));
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t old = order[i];
-        for (int c = 0; c < 4; c++) {
-            uint32_t r = s->wide_ref[(size_t)old * 4 + c];
-            if ((r >> 30) == REF_KIND_INTERIOR) r = (REF_KIND_INTERIOR << 30) | new_of[r & 0x3fffffffu];
-            ref[(size_t)i * 4 + c] = r;
-        }
-        memcpy(box + (size_t)i * 24, s->wide_box + (size_t)old * 24, 24 * sizeof(double));
-    }
-    s->finfo.wide_root_ref = (REF_KIND_INTERIOR << 30) | new_of[s->finfo.wide_root_ref & 0x3fffffffu];
+/* The tree the HIP traversal kernel walks is NOT built here: it is the product's own
+ * (rayrs_amd/csrc/scene_host.cpp build_walk_tree), handed over through
+ * rayrs_scene_export_wide and orc_set_wide so that isect_wide below makes the kernel's walk
+ * on the kernel's data.  What makes that tree legal -- every group of the reference's tree
+ * appears exactly once behind its exact gating box, every interior box contains what is
+ * below it -- is checked from the outside by tests/test_bvh_builder.py, and that the walk
+ * returns the reference's hits by comparing it with isect_reference (traversal 0). */
+int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
+                 const uint32_t* wide_ref) {
+    if (!s || !s->built) return -1;
     free(s->wide_box);
     free(s->wide_ref);
-    s->wide_box = box;
-    s->wide_ref = ref;
-    free(area);
-    free(order);
-    free(new_of);
-    free(taken);
-}
-
-static void flatten_wide(orc_scene* s) {
-    uint32_t cap = s->finfo.n_interior ? s->finfo.n_interior : 1;
-    s->wide_box = (double*)calloc((size_t)cap * 24, sizeof(double));
-    s->wide_ref = (uint32_t*)calloc((size_t)cap * 4, sizeof(uint32_t));
-    s->finfo.n_wide = 0;
-    s->finfo.wide_depth = 0;
-    if ((s->finfo.root_ref >> 30) == REF_KIND_INTERIOR)
-        s->finfo.wide_root_ref = fold_wide(s, s->finfo.root_ref & 0x3fffffffu, &s->finfo.wide_depth);
-    else
-        s->finfo.wide_root_ref = s->finfo.root_ref;
-    front_largest(s);
+    s->wide_box = (double*)malloc(((size_t)n_wide * 24 + 1) * sizeof(double));
+    s->wide_ref = (uint32_t*)malloc(((size_t)n_wide * 4 + 1) * sizeof(uint32_t));
+    if (n_wide) {
+        memcpy(s->wide_box, wide_box, (size_t)n_wide * 24 * sizeof(double));
+        memcpy(s->wide_ref, wide_ref, (size_t)n_wide * 4 * sizeof(uint32_t));
+    }
+    s->finfo.n_wide = n_wide;
+    s->finfo.wide_root_ref = wide_root_ref;
+    s->finfo.wide_depth = wide_depth;
+    s->have_wide = 1;
+    return 0;
 }
 
 /* Scene::new lib.rs:227-245, Bvh::build bvh.rs:199-210 */
@@ -1425,7 +1324,6 @@ int orc_scene_build(orc_scene* s, double z_near, double z_far, int heuristic, ui
     for (size_t i = 0; i < nt; i++) s->hdri[i] = rr_max(rr_min((double)hdri_rgb[i], 3.0), 0.0);
 
     flatten(s);
-    flatten_wide(s);
     s->built = 1;
     return 0;
 }
@@ -1445,7 +1343,7 @@ int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_re
 }
 
 int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide_ref) {
-    if (!s || !s->built) return -1;
+    if (!s || !s->built || !s->have_wide) return -1;
     memcpy(wide_box, s->wide_box, (size_t)s->finfo.n_wide * 24 * sizeof(double));
     memcpy(wide_ref, s->wide_ref, (size_t)s->finfo.n_wide * 4 * sizeof(uint32_t));
     return 0;
@@ -1504,6 +1402,12 @@ typedef struct {
     uint64_t interior_visits, tri_tests, sphere_tests, plane_tests;
 } trav_counters;
 
+/* Boxes entered beyond the closest hit so far are skipped -- beyond it by this relative margin:
+ * a primitive's computed t and the entry parameter of the box around it are rounded
+ * independently, so a hit an ulp in front of its own box must not be lost
+ * (rayrs_amd/csrc/device_path.h has the same constant; the counters only agree if both do). */
+#define TRAV_CULL_MARGIN (1.0 + 0x1p-40)
+
 /* The kernel's traversal, restated on the flattened tree: children tested at
  * the parent, near child first, far child pushed, boxes whose entry lies
  * beyond the closest hit skipped.  Returns the reference's answer: closest
@@ -1533,7 +1437,7 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
                 } else {
                     hit[c] = aabb_intersect_entry(s->child_box + ((size_t)rec * 2 + c) * 6, ray, inv, tmin, tmax,
                                                   &ent[c]);
-                    if (hit[c] && ent[c] > best_t) hit[c] = 0;
+                    if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) hit[c] = 0;
                 }
             }
             uint32_t r0 = s->child_ref[(size_t)rec * 2], r1 = s->child_ref[(size_t)rec * 2 + 1];
@@ -1588,17 +1492,25 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
 static uint64_t* g_visit_hist = NULL;
 void orc_set_visit_histogram(uint64_t* hist) { g_visit_hist = hist; }
 
-/* The same on the folded records (the walk the HIP traversal kernel makes): up to four
- * boxes per record, the hit slots entered nearest first (ties by slot), the rest pushed
- * farthest first. */
+/* The walk the HIP traversal kernel makes, on the four-slot records of the product's walk tree
+ * (orc_set_wide): up to four boxes per record, the hit slots entered nearest first (ties by
+ * slot), the rest pushed farthest first.  Every leaf slot is a group of the reference's tree
+ * behind its gating box, so the primitives tested are a subset of those the reference reaches
+ * that contains the closest hit. */
 static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
+    if (!s->have_wide) {
+        fprintf(stderr, "oracle: traversal 2 needs the product's walk tree (orc_set_wide)\n");
+        abort();
+    }
     isect_t best = {0, 0.0, -1};
     uint32_t best_prim = 0xffffffffu;
     double best_t = tmax;
     v3 inv = V(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
     double entry;
     if (!aabb_intersect_entry(s->finfo.root_box, ray, inv, tmin, tmax, &entry)) return best;
-    uint32_t stack[512];
+    uint32_t stack_fixed[512];
+    uint32_t* stack = stack_fixed;
+    if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
     int sp = 0;
     uint32_t cur = s->finfo.wide_root_ref;
     for (;;) {
@@ -1621,7 +1533,7 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                     ent[c] = tmin;
                 } else if (kind != REF_KIND_NONE) {
                     hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
-                    if (hit[c] && ent[c] > best_t) hit[c] = 0;
+                    if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) hit[c] = 0;
                 }
                 n += hit[c];
             }
@@ -1669,6 +1581,7 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
         if (sp == 0) break;
         cur = stack[--sp];
     }
+    if (stack != stack_fixed) free(stack);
     return best;
 }
 

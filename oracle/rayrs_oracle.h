@@ -119,8 +119,9 @@ int orc_camera_new(const double origin[3], const double up[3], const double look
 /* The block loop of main.rs:57-101 with the build-defined RNG.
  * traversal: 0 = recursive reference traversal (bvh.rs:391-415),
  *            1 = ordered traversal with closest-hit culling on the two-child records,
- *            2 = the same on the folded four-slot records (the kernel's walk: same
- *                visit order, so its counters equal the kernel's).
+ *            2 = the same on the four-slot records of the product's walk tree, which must have
+ *                been handed over with orc_set_wide (the kernel's walk on the kernel's data:
+ *                same visit order, so its counters equal the kernel's).
  * sample_chunk: 0 or >= spp = one sequential sum per pixel (main.rs:67-79);
  * otherwise per-chunk sums added in chunk order (see include/rayrs_hip.h).
  * rows [row0,row1) of the image are rendered (whole image: 0,height); the
@@ -171,7 +172,7 @@ typedef struct {
     uint32_t root_ref;
     uint32_t depth; /* max number of stack entries the ordered traversal can need */
     double root_box[6];
-    uint32_t n_wide;        /* four-slot records (two levels folded) */
+    uint32_t n_wide;        /* four-slot records of the product's walk tree (0 until orc_set_wide) */
     uint32_t wide_root_ref;
     uint32_t wide_depth;    /* stack entries the wide traversal can need */
     uint32_t reserved;
@@ -186,6 +187,10 @@ int orc_flatten_info(const orc_scene* s, orc_flat_info* info);
  * wide traversal (hist: n_wide + 64 counters, NULL switches it off; single-threaded renders only) */
 void orc_set_visit_histogram(uint64_t* hist);
 int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide_ref);
+/* Hands the oracle the four-slot records of the product's walk tree (rayrs_scene_export_wide):
+ * traversal 2 walks them.  The oracle does not build that tree itself. */
+int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
+                 const uint32_t* wide_ref);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

@@ -239,6 +239,7 @@ RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 // fetched whole, with loads that do not depend on its contents, before anything
 // is decided from it.
 constexpr uint32_t TRAV_DONE = 0xffffffffu;
+constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-40;  // see trav_interior_step; t > t0 >= 0 (lib.rs:234)
 
 // A lane's traversal stack.  Entry k lives in LDS at lds[k * 64] while k < cap; deeper
 // entries, which only the worst-case visit order of a deep tree reaches, go to a per-lane
@@ -368,13 +369,17 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // keep the references' load with the boxes' (the compiler would otherwise sink it below the
     // "any slot hit" branch, a second memory round trip per step)
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-    // Direct leaves and unused slots need no special case here: their records carry the
-    // all-of-space and the inverted box (scene_host.cpp), for which the slab test above says
-    // "entered at t0" and "missed".  Boxes entered beyond the closest hit so far are skipped.
-    h0 = h0 && !(e0 > tv.best_t);
-    h1 = h1 && !(e1 > tv.best_t);
-    h2 = h2 && !(e2 > tv.best_t);
-    h3 = h3 && !(e3 > tv.best_t);
+    // Unused slots need no special case here: they carry the inverted box (scene_host.cpp), for
+    // which the slab test above says "missed".  Boxes entered beyond the closest hit so far are
+    // skipped -- beyond it by a margin of 2^-40 relative: a primitive's computed t and the entry
+    // parameter of the box around it are rounded independently, so a hit an ulp or two in front
+    // of its own box must not be lost to a farther one (every primitive that is tested is judged
+    // by the reference's rule, so a wider margin only costs visits, never the answer).
+    const double cull = tv.best_t * TRAV_CULL_MARGIN;
+    h0 = h0 && !(e0 > cull);
+    h1 = h1 && !(e1 > cull);
+    h2 = h2 && !(e2 > cull);
+    h3 = h3 && !(e3 > cull);
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (n == 0) {
         trav_pop(stack, tv);

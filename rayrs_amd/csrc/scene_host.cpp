@@ -280,11 +280,6 @@ struct Builder {
 
 inline bool f32_exact(double v) { return (double)(float)v == v; }
 
-// Folds two levels of the binary tree into one wide record (layout.h).  Returns the wide
-// reference that replaces binary interior record `n`; *stack_need is the number of stack
-// entries a traversal below this record can have pending.
-uint32_t fold_wide(FlatScene& f, uint32_t n, uint32_t* stack_need);
-
 // Surface area of the box around a wide record's tested slots.
 double record_area(const FlatScene& f, uint32_t rec) {
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -307,9 +302,8 @@ double record_area(const FlatScene& f, uint32_t rec) {
 // Renumbers the wide records so that the WIDE_FRONT records with the largest boxes come
 // first, largest first (ties: lower index first); the others keep their depth-first order
 // behind them.  A ray meets a box with probability proportional to its surface area, so
-// these are the records nearly every query reads -- in the benchmark scenes the floor
-// plane's 50 x 50 box rides down a chain of eight of them -- and the traversal kernel keeps
-// the first of them in LDS (wavefront.hip) instead of asking the vector L1 for them.
+// these are the records most queries read, and the traversal kernel keeps the first of them
+// in LDS (wavefront.hip) instead of asking the vector L1 for them.
 void front_largest(FlatScene& f) {
     const uint32_t n = f.n_wide();
     const uint32_t k = n < WIDE_FRONT ? n : WIDE_FRONT;
@@ -343,47 +337,247 @@ void front_largest(FlatScene& f) {
     f.wide_root_ref = (REF_INTERIOR << 30) | new_of[f.wide_root_ref & 0x3fffffffu];
 }
 
-uint32_t fold_wide(FlatScene& f, uint32_t n, uint32_t* stack_need) {
-    const uint32_t rec = f.n_wide();
-    f.wide_ref.resize(f.wide_ref.size() + 4, REF_NONE << 30);
-    f.wide_box.resize(f.wide_box.size() + 24, 0.0);
-    struct Slot {
-        uint32_t ref;
-        const double* box;
-    } slots[4];
-    int ns = 0;
+// ------------------------------------------------------------ the walk tree
+//
+// What decides the reference's answer is, per primitive, ONE box: a primitive is reached by
+// BvhTree::intersect (bvh.rs:391-415) iff every box on its root path passes the slab test,
+// those boxes nest exactly (a Node's box is the min/max of everything below it) and every
+// operation of the slab test is monotone in the bounds (NaN-ignoring max/min included), so
+// passing the innermost of them -- the box of the primitive's parent Node, its *gating box* --
+// implies passing all the others.  The closest hit is then the smallest accepted t, the
+// first primitive in depth-first order on exact ties (bvh.rs:62), whatever order the
+// primitives are visited in.  So the kernels need not walk the reference's topology: they
+// walk a tree built here for traversal speed whose leaf slots are the reference's *groups*
+// (the 1..4 leaves that share a parent Node, contiguous in depth-first order) behind their
+// exact gating boxes, and whose interior boxes are unions of those, i.e. supersets -- a ray
+// that misses a superset misses every gating box inside it, so skipping the subtree skips
+// nothing the reference reaches.  On the benchmark scenes this removes the chain of sixteen
+// levels down which the reference carries the 50 x 50 floor (every query used to read all
+// eight folded records of it) and halves the records a query visits.
+
+struct WalkGroup {
+    double box[6];
+    uint32_t ref;  // REF_RANGE: first primitive << 2 | count - 1
+};
+
+// The groups of the two-child tree in depth-first order.  `gate` is the box of record n itself.
+void collect_groups(const FlatScene& f, uint32_t n, const double* gate, std::vector<WalkGroup>& out) {
     for (int c = 0; c < 2; c++) {
         const uint32_t r = f.child_ref[(size_t)n * 2 + c];
         const double* box = &f.child_box[((size_t)n * 2 + c) * 6];
-        if ((r >> 30) == REF_INTERIOR) {
-            const uint32_t m = r & 0x3fffffffu;
-            for (int g = 0; g < 2; g++) {
-                const uint32_t rg = f.child_ref[(size_t)m * 2 + g];
-                if ((rg >> 30) == REF_SINGLE)  // reached whenever m's box is hit: a one-primitive range behind m's box
-                    slots[ns++] = {(REF_RANGE << 30) | (rg & 0x3fffffffu), box};
-                else
-                    slots[ns++] = {rg, &f.child_box[((size_t)m * 2 + g) * 6]};
-            }
+        const uint32_t kind = r >> 30;
+        if (kind == REF_INTERIOR) {
+            collect_groups(f, r & 0x3fffffffu, box, out);
         } else {
-            slots[ns++] = {r, box};  // a range behind its box, or a direct leaf (no box test)
+            WalkGroup g;
+            // a direct leaf has no box of its own in the reference (bvh.rs:297, :302): what gates it
+            // is the box of the Node it hangs under
+            const double* gb = kind == REF_SINGLE ? gate : box;
+            for (int k = 0; k < 6; k++) g.box[k] = gb[k];
+            g.ref = (REF_RANGE << 30) | (r & 0x3fffffffu);
+            out.push_back(g);
         }
+    }
+}
+
+struct WalkNode {  // binary tree over the groups
+    double box[6];
+    int32_t left, right;  // -1: leaf
+    uint32_t ref;         // leaf: the group's reference
+};
+
+inline double box_area(const double* b) {
+    const double x = b[1] - b[0], y = b[3] - b[2], z = b[5] - b[4];
+    return 2.0 * (x * y + y * z + x * z);
+}
+inline void box_merge(double* a, const double* b) {
+    for (int k = 0; k < 6; k += 2) {
+        if (b[k] < a[k]) a[k] = b[k];
+        if (b[k + 1] > a[k + 1]) a[k + 1] = b[k + 1];
+    }
+}
+
+// Top-down binned surface-area-heuristic build (32 bins on each axis of the centroid bounds);
+// every group ends in a leaf of its own.
+struct WalkBuilder {
+    const std::vector<WalkGroup>& groups;
+    std::vector<WalkNode> nodes;
+    std::vector<uint32_t> idx;
+    std::vector<double> cen[3];
+    static constexpr int BINS = 32;
+
+    explicit WalkBuilder(const std::vector<WalkGroup>& g) : groups(g) {
+        const size_t n = g.size();
+        idx.resize(n);
+        for (auto& c : cen) c.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            idx[i] = (uint32_t)i;
+            for (int a = 0; a < 3; a++) cen[a][i] = 0.5 * g[i].box[2 * a] + 0.5 * g[i].box[2 * a + 1];
+        }
+        nodes.reserve(2 * n);
+    }
+
+    int32_t build() {
+        struct Work {
+            int32_t node;
+            size_t lo, hi;
+        };
+        std::vector<Work> todo;
+        nodes.push_back(WalkNode());
+        todo.push_back({0, 0, groups.size()});
+        while (!todo.empty()) {
+            const Work w = todo.back();
+            todo.pop_back();
+            double box[6];
+            for (int k = 0; k < 6; k++) box[k] = groups[idx[w.lo]].box[k];
+            for (size_t i = w.lo + 1; i < w.hi; i++) box_merge(box, groups[idx[i]].box);
+            for (int k = 0; k < 6; k++) nodes[w.node].box[k] = box[k];
+            if (w.hi - w.lo == 1) {
+                nodes[w.node].left = nodes[w.node].right = -1;
+                nodes[w.node].ref = groups[idx[w.lo]].ref;
+                continue;
+            }
+            const size_t mid = split(w.lo, w.hi);
+            const int32_t l = (int32_t)nodes.size();
+            nodes.push_back(WalkNode());
+            nodes.push_back(WalkNode());
+            nodes[w.node].left = l, nodes[w.node].right = l + 1, nodes[w.node].ref = 0;
+            todo.push_back({l + 1, mid, w.hi});
+            todo.push_back({l, w.lo, mid});
+        }
+        return 0;
+    }
+
+    // Partitions idx[lo, hi) and returns the split position (lo < mid < hi).
+    size_t split(size_t lo, size_t hi) {
+        const size_t n = hi - lo;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = 0;
+        double best_lo = 0, best_scale = 0;
+        for (int a = 0; a < 3; a++) {
+            double cmin = cen[a][idx[lo]], cmax = cmin;
+            for (size_t i = lo + 1; i < hi; i++) {
+                const double c = cen[a][idx[i]];
+                if (c < cmin) cmin = c;
+                if (c > cmax) cmax = c;
+            }
+            if (!(cmax > cmin)) continue;
+            const double scale = (double)BINS / (cmax - cmin);
+            double bbox[BINS][6];
+            uint32_t count[BINS];
+            for (int b = 0; b < BINS; b++) count[b] = 0;
+            for (size_t i = lo; i < hi; i++) {
+                int b = (int)((cen[a][idx[i]] - cmin) * scale);
+                if (b < 0) b = 0;
+                if (b >= BINS) b = BINS - 1;
+                const double* gb = groups[idx[i]].box;
+                if (count[b]++ == 0) {
+                    for (int k = 0; k < 6; k++) bbox[b][k] = gb[k];
+                } else {
+                    box_merge(bbox[b], gb);
+                }
+            }
+            double right_area[BINS];
+            uint32_t right_count[BINS];
+            double acc[6];
+            uint32_t cnt = 0;
+            bool any = false;
+            for (int b = BINS - 1; b > 0; b--) {
+                if (count[b]) {
+                    if (!any) {
+                        for (int k = 0; k < 6; k++) acc[k] = bbox[b][k];
+                        any = true;
+                    } else {
+                        box_merge(acc, bbox[b]);
+                    }
+                    cnt += count[b];
+                }
+                right_area[b] = any ? box_area(acc) : 0.0;
+                right_count[b] = cnt;
+            }
+            any = false, cnt = 0;
+            for (int b = 0; b < BINS - 1; b++) {  // split between bin b and b + 1
+                if (count[b]) {
+                    if (!any) {
+                        for (int k = 0; k < 6; k++) acc[k] = bbox[b][k];
+                        any = true;
+                    } else {
+                        box_merge(acc, bbox[b]);
+                    }
+                    cnt += count[b];
+                }
+                if (cnt == 0 || right_count[b + 1] == 0) continue;
+                const double cost = box_area(acc) * (double)cnt + right_area[b + 1] * (double)right_count[b + 1];
+                if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = b, best_lo = cmin, best_scale = scale;
+            }
+        }
+        if (best_axis < 0) return lo + n / 2;  // coincident centroids: any split will do
+        const std::vector<double>& c = cen[best_axis];
+        auto left_side = [&](uint32_t g) {
+            int b = (int)((c[g] - best_lo) * best_scale);
+            if (b < 0) b = 0;
+            if (b >= BINS) b = BINS - 1;
+            return b <= best_bin;
+        };
+        const auto it = std::stable_partition(idx.begin() + (std::ptrdiff_t)lo, idx.begin() + (std::ptrdiff_t)hi, left_side);
+        const size_t mid = (size_t)(it - idx.begin());
+        return (mid == lo || mid == hi) ? lo + n / 2 : mid;
+    }
+};
+
+// One record of up to four slots per call: the node's two children, then twice the interior
+// slot with the largest box replaced by its two children.  Returns the record's reference;
+// *stack_need is the number of stack entries a traversal below it can have pending.
+uint32_t emit_wide(FlatScene& f, const std::vector<WalkNode>& nodes, int32_t n, uint32_t* stack_need) {
+    const uint32_t rec = f.n_wide();
+    f.wide_ref.resize(f.wide_ref.size() + 4, REF_NONE << 30);
+    f.wide_box.resize(f.wide_box.size() + 24, 0.0);
+    int32_t slots[4] = {nodes[n].left, nodes[n].right, -1, -1};
+    int ns = 2;
+    while (ns < 4) {
+        int pick = -1;
+        double pick_area = -1.0;
+        for (int i = 0; i < ns; i++) {
+            if (nodes[slots[i]].left < 0) continue;
+            const double a = box_area(nodes[slots[i]].box);
+            if (a > pick_area) pick_area = a, pick = i;
+        }
+        if (pick < 0) break;
+        const int32_t open = slots[pick];
+        slots[pick] = nodes[open].left;
+        slots[ns++] = nodes[open].right;
     }
     uint32_t below = 0;
     for (int i = 0; i < ns; i++) {
-        uint32_t ref = slots[i].ref;
-        const double* box = slots[i].box;  // taken before the recursion may reallocate wide_box, not child_box
-        double bx[6];
-        for (int k = 0; k < 6; k++) bx[k] = box[k];
-        if ((ref >> 30) == REF_INTERIOR) {
+        const WalkNode& c = nodes[slots[i]];
+        uint32_t ref = c.ref;
+        if (c.left >= 0) {
             uint32_t need = 0;
-            ref = fold_wide(f, ref & 0x3fffffffu, &need);
+            ref = emit_wide(f, nodes, slots[i], &need);
             if (need > below) below = need;
         }
         f.wide_ref[(size_t)rec * 4 + i] = ref;
-        for (int k = 0; k < 6; k++) f.wide_box[((size_t)rec * 4 + i) * 6 + k] = bx[k];
+        for (int k = 0; k < 6; k++) f.wide_box[((size_t)rec * 4 + i) * 6 + k] = c.box[k];
     }
     *stack_need = (uint32_t)(ns - 1) + below;
     return (REF_INTERIOR << 30) | rec;
+}
+
+void build_walk_tree(FlatScene& f) {
+    f.wide_box.clear();
+    f.wide_ref.clear();
+    f.wide_depth = 0;
+    if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
+        f.wide_root_ref = f.root_ref;
+        return;
+    }
+    std::vector<WalkGroup> groups;
+    collect_groups(f, f.root_ref & 0x3fffffffu, f.root_box, groups);
+    WalkBuilder b(groups);
+    b.build();
+    f.wide_box.reserve(groups.size() * 12);
+    f.wide_ref.reserve(groups.size() * 2);
+    f.wide_root_ref = emit_wide(f, b.nodes, 0, &f.wide_depth);
 }
 
 void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
@@ -421,15 +615,8 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     f.root_box[0] = root.xmin, f.root_box[1] = root.xmax, f.root_box[2] = root.ymin;
     f.root_box[3] = root.ymax, f.root_box[4] = root.zmin, f.root_box[5] = root.zmax;
 
-    // ---- fold two levels into one record
-    if ((f.root_ref >> 30) == REF_INTERIOR) {
-        f.wide_box.reserve((size_t)f.n_interior() * 16);
-        f.wide_ref.reserve((size_t)f.n_interior() * 3);
-        f.wide_root_ref = fold_wide(f, f.root_ref & 0x3fffffffu, &f.wide_depth);
-    } else {
-        f.wide_root_ref = f.root_ref;
-        f.wide_depth = 0;
-    }
+    // ---- the tree the kernels walk
+    build_walk_tree(f);
 
     front_largest(f);
 
@@ -437,7 +624,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     bool compact = true;
     for (size_t r = 0; r < f.wide_ref.size() && compact; r++) {
         const uint32_t kind = f.wide_ref[r] >> 30;
-        if (kind == REF_SINGLE || kind == REF_NONE) continue;  // box never read
+        if (kind == REF_NONE) continue;  // box never read
         for (int k = 0; k < 6; k++)
             if (!f32_exact(f.wide_box[r * 6 + k])) {
                 compact = false;
@@ -456,16 +643,12 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     }
     f.compact = compact;
 
-    // ---- wide interior records.  The two kinds of slot whose box the reference never tests get
-    // boxes that make the kernel's ordinary slab test say the right thing without looking at
-    // the kind: a direct leaf (bvh.rs:297, :302) is all of space -- always entered, at entry
-    // parameter t0, ahead of every tested box -- and an unused slot is the inverted box
-    // [+inf, -inf], which no ray enters.
+    // ---- wide interior records.  An unused slot gets the inverted box [+inf, -inf], which no
+    // ray enters, so that the kernel's slab test says the right thing without looking at the kind.
     const uint32_t n_wide = f.n_wide();
     const double inf = std::numeric_limits<double>::infinity();
     auto slot_bound = [&](uint32_t r, int ch, int k) {
         const uint32_t kind = f.wide_ref[(size_t)r * 4 + ch] >> 30;
-        if (kind == REF_SINGLE) return (k & 1) ? inf : -inf;
         if (kind == REF_NONE) return (k & 1) ? -inf : inf;
         return f.wide_box[((size_t)r * 4 + ch) * 6 + k];
     };

@@ -91,6 +91,7 @@ def lib():
     L.orc_flatten_info.argtypes = [vp, C.POINTER(OrcFlatInfo)]
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
+    L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.orc_set_math_mode.argtypes = [C.c_int]
     L.orc_set_math_mode.restype = None
     _lib = L
@@ -194,6 +195,17 @@ class OracleScene:
         return {"n_interior": i.n_interior, "n_prims": i.n_prims, "root_ref": i.root_ref, "depth": i.depth,
                 "root_box": list(i.root_box), "n_wide": i.n_wide, "wide_root_ref": i.wide_root_ref,
                 "wide_depth": i.wide_depth}
+
+    def use_walk_tree(self, product_scene):
+        """Take the four-slot records the kernels walk from the product (a rayrs_amd.Scene, host-only
+        or on a device): traversal=2 then makes the kernel's walk on the kernel's data."""
+        info = product_scene.info()
+        box, ref = product_scene.export_wide()
+        box = np.ascontiguousarray(box)
+        ref = np.ascontiguousarray(ref)
+        assert self._L.orc_set_wide(self._h, info["n_wide"], info["wide_root_ref"], info["wide_depth"],
+                                    box.ctypes.data, ref.ctypes.data) == 0
+        return self
 
     def export_wide(self):
         i = self.flat_info()
