@@ -64,14 +64,17 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only)")
     ap.add_argument("--res", type=int, default=0, help="override resolution (development only)")
     ap.add_argument("--sample-chunk", type=int, default=4,
-                    help="samples summed per item (0 = the reference's single sum per pixel); small chunks keep the "
-                         "end of a frame, and of a tile share, short")
+                    help="smallest sample chunk to use (the library doubles it until the whole frame has at most "
+                         "2^30 items); small chunks keep the end of a frame, and of a tile share, short")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
                     "rehearsing the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device of every rank (rehearsal only)")
+    ap.add_argument("--no-build", action="store_true",
+                    help="do not run make: required under rocprofv3 (a profiled process must not spawn the compiler); "
+                         "fails if the library is older than its sources")
     args = ap.parse_args()
 
     import numpy as np
@@ -85,7 +88,9 @@ def main():
         local_rank = args.device
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if rank == 0:
+    if args.no_build:
+        graft.check_built()
+    elif rank == 0:
         graft.build()
 
     use_dist = world > 1
@@ -121,10 +126,9 @@ def main():
     info = scene.info()
     H, W = cam.y_pixels(), cam.x_pixels()
 
-    # items (pixel, sample chunk) are numbered in 32 bits and each keeps 24 bytes of partial sum:
-    # grow the chunk until a rank's share of the frame stays under 2^30 items (configs[3]: 16)
-    while args.sample_chunk and (H * W // world + 1) * -(-spp // args.sample_chunk) > (1 << 30):
-        args.sample_chunk *= 2
+    # a pixel's samples are summed in chunks; the chunk comes from the WHOLE frame (rayrs_frame_sample_chunk:
+    # at most 2^30 (pixel, chunk) items), never from the rank count, so every N renders the same bits
+    args.sample_chunk = rayrs_amd.frame_sample_chunk(W, H, spp, args.sample_chunk)
 
     dev = torch.device("cuda", local_rank)
     fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -171,7 +175,11 @@ def main():
         total_rays, max_elapsed = float(r.item()), float(e.item())
     else:
         total_rays, max_elapsed = float(rays), elapsed
-    checksum = float(fb.double().sum().item()) if rank == 0 else 0.0
+    checksum, fb_sha = 0.0, None
+    if rank == 0:  # the assembled frame: identical bits for every rank count (tests/test_gpu_multi_process.py)
+        import hashlib
+        checksum = float(fb.double().sum().item())
+        fb_sha = hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest()
 
     roofline = None
     if not args.no_roofline:
@@ -281,6 +289,7 @@ def main():
             },
             "rays_per_step": int(total_rays / args.steps),
             "framebuffer_checksum": checksum,
+            "framebuffer_sha256": fb_sha,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

@@ -33,7 +33,8 @@ typedef enum {
     RAYRS_OOM = -3,
     RAYRS_NO_DEVICE = -4,   /* scene was created host-only or no GPU present */
     RAYRS_UNSUPPORTED = -5, /* more than 2^32 (pixel, sample chunk) items on a rank, max_bounces > 8000, an image side > 65535 */
-    RAYRS_IO_ERROR = -6     /* file missing or malformed (see rayrs_io_last_error) */
+    RAYRS_IO_ERROR = -6,    /* file missing or malformed (see rayrs_io_last_error) */
+    RAYRS_RCCL_ERROR = -7   /* the RCCL library could not be loaded, or one of its calls failed (rayrs_render_multi) */
 } rayrs_status;
 
 const char* rayrs_strerror(int status);
@@ -148,6 +149,11 @@ typedef struct {
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
+/* The same scene (BVH, records, materials, HDRI, tuning) uploaded to another HIP device without
+ * building it again: what rayrs_render_multi wants one of per GPU.  `scene` may be host-only. */
+int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scene** out);
+/* HIP device of the scene, -1 for a host-only scene. */
+int rayrs_scene_device(const rayrs_scene* scene);
 /* child_box: n_interior*2*6 f64, child_ref: n_interior*2 u32, prim_object:
  * n_prims u32 (index of the object, in insertion order, at each DFS slot).
  * ref = kind<<30 | payload; kind 0 = interior record (payload = index),
@@ -221,17 +227,66 @@ typedef struct {
     uint64_t refill_ticks;
 } rayrs_render_stats;
 
+/* The sample chunk a frame is rendered with when the caller has no reason to choose another:
+ * the smallest `requested` * 2^k (requested = 0 means 4) for which the WHOLE frame -- all of its
+ * 8x8 tiles, whoever renders them -- has at most 2^30 (pixel, chunk) items.  It depends on the
+ * frame only, never on the number of GPUs that share it, so that every rank count sums a pixel's
+ * samples in the same order and produces the same bits.  (Each rank keeps 24 bytes of partial
+ * sum per item; a rank refuses more than 2^32 items.) */
+uint32_t rayrs_frame_sample_chunk(uint32_t x_pixels, uint32_t y_pixels, uint32_t spp, uint32_t requested);
+
 /* Renders into a HOST buffer of y_pixels*x_pixels*3 elements (row-major,
  * origin upper left, RGB).  Synchronous. */
 int rayrs_render(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params, void* out_host,
                  rayrs_render_stats* stats);
 
-/* Enqueues the render on `hip_stream` (a hipStream_t, NULL = default stream)
- * writing a DEVICE buffer of the same shape; returns without synchronising. */
+/* Enqueues the render on `hip_stream` (a hipStream_t, NULL = default stream) writing a DEVICE
+ * buffer of the same shape.  The number of path rounds is data dependent (a frame ends when the
+ * last path does), so rounds are enqueued in batches and the call reads the live-path count of
+ * batch b back while batch b+1 is already queued: it returns once the LAST batch is enqueued --
+ * the GPU is never idle waiting for the host, but the call itself lasts about as long as the
+ * frame minus its last batch.  The resolve pass and everything the caller enqueues on the stream
+ * afterwards (an RCCL reduce, a copy) is ordered behind the render without a host wait. */
 int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
                         void* out_device, void* hip_stream);
 /* Waits for the last rayrs_render_launch on this scene and returns its counters. */
 int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats);
+
+/* The same block loop over several GPUs of one node, inside the library (the reference does all of
+ * its parallelism -- rayon over image blocks, main.rs:57-101 -- inside the product too).  scenes[i]
+ * are n handles of the same scene on the devices to use (rayrs_scene_clone_to_device); rank i renders
+ * the 8x8 tiles t with t % n == i from its own host thread on its own stream into a zeroed
+ * framebuffer on its device, and one RCCL reduce (sum, over xGMI) to scenes[0]'s device assembles
+ * the frame, which is copied to out_host.  A pixel is non-zero on exactly one rank, so the frame
+ * equals the one-GPU frame bit for bit.  params->tile_rank / tile_ranks are ignored.  Handles on the
+ * same device are allowed (rehearsal on one GPU): their buffers are summed on that device first.
+ * RCCL is loaded at the first call; RAYRS_RCCL_ERROR if that or a collective fails.  stats: counters
+ * summed over the ranks, times = the slowest rank's. */
+int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camera* camera,
+                       const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats);
+
+/* ---- tuning: how the kernels are scheduled, never what they compute.  0 = the built-in default.
+ * (Round 1 read these from RAYRS_* environment variables; a library must not.) */
+typedef struct {
+    uint32_t pool_slots;    /* paths in flight (default: min(items, 32 Mi, samples / 16)) */
+    uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
+    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (24) */
+    uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
+    uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
+    uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
+                               0xffffffff = none */
+    uint32_t reserved[2];
+} rayrs_tuning;
+/* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
+int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
+
+/* ---- layout of the structs above as THIS library was compiled, for bindings in other languages
+ * to check theirs against (tests/test_abi.py does it for rayrs_amd/_ffi.py, and INTEGRATION.md's
+ * #[repr(C)] structs carry the same numbers).  Writes up to `cap` words to `out` and returns the
+ * number of words the full table has: for each struct, in the order rayrs_material,
+ * rayrs_emission, rayrs_camera, rayrs_scene_info_t, rayrs_render_params, rayrs_render_stats,
+ * rayrs_tuning: sizeof, number of fields, then offsetof of every field in declaration order. */
+uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);
 
 /* ---- device self-test hooks (used by tests/ to check single functions
  *      of the hot path on the GPU against the oracle) ---- */

@@ -17,9 +17,10 @@ SYMBOLS = [
     "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
     "rayrs_object_from_spheres", "rayrs_object_box_geom",
     "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
-    "rayrs_scene_export_wide",
+    "rayrs_scene_export_wide", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
     "rayrs_camera_new",
-    "rayrs_render", "rayrs_render_launch", "rayrs_render_finish",
+    "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
+    "rayrs_abi_layout",
     "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
     "rayrs_test_background",
     "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
@@ -72,6 +73,15 @@ class RenderStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Tuning(C.Structure):
+    _fields_ = [("pool_slots", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
+                ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+# the order rayrs_abi_layout() reports the public structs in
+ABI_STRUCTS = [MaterialDesc, EmissionDesc, CameraDesc, SceneInfo, RenderParams, RenderStats, Tuning]
+
 _lib = None
 
 
@@ -110,6 +120,15 @@ def lib():
     L.rayrs_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
+    L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rayrs_scene_device.argtypes = [vp]
+    L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    L.rayrs_frame_sample_chunk.argtypes = [C.c_uint32] * 4
+    L.rayrs_frame_sample_chunk.restype = C.c_uint32
+    L.rayrs_abi_layout.argtypes = [vp, C.c_uint32]
+    L.rayrs_abi_layout.restype = C.c_uint32
+    L.rayrs_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp,
+                                     C.POINTER(RenderStats)]
     L.rayrs_camera_new.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                    C.POINTER(CameraDesc)]
     L.rayrs_render.argtypes = [vp, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp, C.POINTER(RenderStats)]

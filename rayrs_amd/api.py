@@ -290,6 +290,29 @@ class Scene:
         finally:
             L.rayrs_objects_destroy(objs)
 
+    @classmethod
+    def _from_handle(cls, L, h, device):
+        self = cls.__new__(cls)
+        self._L, self._h, self.device = L, h, int(device)
+        return self
+
+    def clone_to_device(self, device: int) -> "Scene":
+        """The same scene uploaded to another HIP device without building the BVH again
+        (one per GPU for render_multi)."""
+        h = C.c_void_p()
+        _ffi.check(self._L.rayrs_scene_clone_to_device(self._h, int(device), C.byref(h)), "rayrs_scene_clone_to_device")
+        return Scene._from_handle(self._L, h, device)
+
+    def set_tuning(self, **kw):
+        """Scheduling knobs of the kernels (include/rayrs_hip.h rayrs_tuning); 0 = default.  They
+        never change what is computed."""
+        t = _ffi.Tuning()
+        for k, v in kw.items():
+            if k not in dict(_ffi.Tuning._fields_) or k == "reserved":
+                raise ValueError(f"unknown tuning field {k}")
+            setattr(t, k, int(v))
+        _ffi.check(self._L.rayrs_scene_set_tuning(self._h, C.byref(t)), "rayrs_scene_set_tuning")
+
     def info(self) -> dict:
         i = _ffi.SceneInfo()
         _ffi.check(self._L.rayrs_scene_info(self._h, C.byref(i)), "rayrs_scene_info")
@@ -327,6 +350,13 @@ class Scene:
             pass
 
 
+def frame_sample_chunk(width: int, height: int, spp: int, requested: int = 4) -> int:
+    """The sample chunk bench.py, the CLI and the full-size tests render a frame with: decided
+    from the whole frame (never from the number of GPUs sharing it), so every rank count sums a
+    pixel's samples in the same order.  0 = one sequential sum (the reference's order)."""
+    return int(_ffi.lib().rayrs_frame_sample_chunk(int(width), int(height), int(spp), int(requested)))
+
+
 def make_params(spp, max_bounces=50, seed=0x5EED, sample_chunk=0, tile_rank=0, tile_ranks=1, out_f64=False,
                 count_work=False) -> _ffi.RenderParams:
     p = _ffi.RenderParams()
@@ -356,6 +386,22 @@ def render(scene: Scene, camera: Camera, spp: int, max_bounces: int = 50, seed: 
     st = _ffi.RenderStats()
     _ffi.check(L.rayrs_render(scene._h, C.byref(camera.desc), C.byref(p), out.ctypes.data, C.byref(st)),
                "rayrs_render")
+    return out, st.as_dict()
+
+
+def render_multi(scene_list, camera: Camera, spp: int, max_bounces: int = 50, seed: int = 0x5EED,
+                 sample_chunk: int = 0, out_f64: bool = False):
+    """The block loop of rayrs/src/main.rs:57-101 over several GPUs inside the library: scene i
+    renders the tiles t % n == i on its own host thread and stream, one RCCL reduce of the
+    framebuffers assembles the frame on the first scene's device.  Returns (image, summed stats)."""
+    L = scene_list[0]._L
+    H, W = camera.y_pixels(), camera.x_pixels()
+    out = np.zeros((H, W, 3), dtype=np.float64 if out_f64 else np.float32)
+    p = make_params(spp, max_bounces, seed, sample_chunk, 0, 1, out_f64, False)
+    st = _ffi.RenderStats()
+    handles = (C.c_void_p * len(scene_list))(*[s._h for s in scene_list])
+    _ffi.check(L.rayrs_render_multi(handles, len(scene_list), C.byref(camera.desc), C.byref(p), out.ctypes.data,
+                                    C.byref(st)), "rayrs_render_multi")
     return out, st.as_dict()
 
 

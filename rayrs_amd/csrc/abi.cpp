@@ -2,77 +2,36 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/rayrs_hip.h"
 #include "kernels.h"
 #include "scene_host.hpp"
+#include "scene_internal.hpp"
 #include "wavefront.h"
 
 using namespace rayrs;
 
 namespace {
-
 thread_local std::string g_last_error;
+constexpr uint32_t TRAV_STACK_LDS = 12;
+constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
+}  // namespace
 
+namespace rayrs {
+void set_last_error(const std::string& text) { g_last_error = text; }
 int hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return e == hipErrorOutOfMemory ? RAYRS_OOM : RAYRS_HIP_ERROR;
 }
-
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t _e = (expr);                        \
-        if (_e != hipSuccess) return hip_fail(_e, #expr); \
-    } while (0)
-
-constexpr uint32_t TRAV_STACK_LDS = 12;
-constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
-
-}  // namespace
-
-struct rayrs_objects {
-    ObjectList list;
-};
-
-struct rayrs_scene {
-    FlatScene flat;
-    std::vector<SurfaceDev> surfaces;
-    uint64_t n_objects = 0;
-    int device = -1;
-    void* d_nodes = nullptr;
-    void* d_prims = nullptr;
-    SurfaceDev* d_surfaces = nullptr;
-    float* d_hdri = nullptr;
-    Counters* d_counters = nullptr;
-    double* d_partial = nullptr;
-    size_t partial_items = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    hipStream_t last_stream = nullptr;
-    bool pending = false;
-    bool last_count = false;
-    int cu_count = 0;
-    int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
-    uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
-    uint32_t hot_records = 0;    // leading wide records kept in LDS
-    uint32_t* d_stack_spill = nullptr;
-    size_t stack_spill_words = 0;
-    uint64_t device_bytes = 0;
-    // path pool and queues of the wavefront pipeline
-    WfDev wf = {};
-    void* wf_block = nullptr;    // one allocation holding the slot records and the state bytes
-    unsigned long long* d_wave_items = nullptr;  // per-wave reserved item ranges
-    uint32_t wave_items_cap = 0;
-    uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
-    hipEvent_t ev_batch[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
-    uint32_t rounds = 0;
-    uint32_t timed_rounds = 0;
-};
+}  // namespace rayrs
 
 static void push_triangle(ObjectList& l, Vec3 p1, Vec3 p2, Vec3 p3, uint32_t surf) {
     Object o;
@@ -114,6 +73,7 @@ const char* rayrs_strerror(int status) {
         case RAYRS_NO_DEVICE: return "no HIP device for this scene";
         case RAYRS_UNSUPPORTED: return "unsupported (size or depth limit)";
         case RAYRS_IO_ERROR: return "file missing or malformed";
+        case RAYRS_RCCL_ERROR: return "RCCL unavailable or failed";
         default: return "unknown status";
     }
 }
@@ -123,9 +83,11 @@ const char* rayrs_last_error(void) { return g_last_error.c_str(); }
 // ------------------------------------------------------------- Vec<Object>
 
 int rayrs_objects_create(rayrs_objects** out) {
+    RAYRS_GUARDED({
     if (!out) return RAYRS_INVALID_ARG;
     *out = new (std::nothrow) rayrs_objects();
     return *out ? RAYRS_OK : RAYRS_OOM;
+    })
 }
 
 void rayrs_objects_destroy(rayrs_objects* objs) { delete objs; }
@@ -134,6 +96,7 @@ uint64_t rayrs_objects_len(const rayrs_objects* objs) { return objs ? objs->list
 
 int rayrs_object_sphere(rayrs_objects* objs, double radius, const double origin[3], const rayrs_material* mat,
                         const rayrs_emission* emission) {
+    RAYRS_GUARDED({
     if (!objs || !origin) return RAYRS_INVALID_ARG;
     if (!(radius > 0.)) return RAYRS_INVALID_ARG;  // geometry.rs:97
     const int surf = objs->list.add_surface(mat, emission);
@@ -146,10 +109,12 @@ int rayrs_object_sphere(rayrs_objects* objs, double radius, const double origin[
     o.surface = (uint32_t)surf;
     objs->list.objs.push_back(o);
     return RAYRS_OK;
+    })
 }
 
 int rayrs_object_plane(rayrs_objects* objs, int axis, double umin, double umax, double vmin, double vmax, double pos,
                        const rayrs_material* mat, const rayrs_emission* emission) {
+    RAYRS_GUARDED({
     if (!objs) return RAYRS_INVALID_ARG;
     if (!(umin < umax && vmin < vmax)) return RAYRS_INVALID_ARG;  // geometry.rs:205-212
     if (axis < 0 || axis > 5) return RAYRS_INVALID_ARG;
@@ -163,25 +128,32 @@ int rayrs_object_plane(rayrs_objects* objs, int axis, double umin, double umax, 
     o.surface = (uint32_t)surf;
     objs->list.objs.push_back(o);
     return RAYRS_OK;
+    })
 }
 
 int rayrs_object_triangle(rayrs_objects* objs, const double p1[3], const double p2[3], const double p3[3],
                           const rayrs_material* mat, const rayrs_emission* emission) {
+    RAYRS_GUARDED({
     if (!objs || !p1 || !p2 || !p3) return RAYRS_INVALID_ARG;
     const int surf = objs->list.add_surface(mat, emission);
     if (surf < 0) return surf;
     push_triangle(objs->list, {p1[0], p1[1], p1[2]}, {p2[0], p2[1], p2[2]}, {p3[0], p3[1], p3[2]}, (uint32_t)surf);
     return RAYRS_OK;
+    })
 }
 
 int rayrs_object_from_triangles_f32(rayrs_objects* objs, const float* verts, uint32_t nverts, const uint32_t* idx,
                                     uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission) {
+    RAYRS_GUARDED({
     return from_triangles<float>(objs, verts, nverts, idx, ntris, mat, emission);
+    })
 }
 
 int rayrs_object_from_triangles_f64(rayrs_objects* objs, const double* verts, uint32_t nverts, const uint32_t* idx,
                                     uint32_t ntris, const rayrs_material* mat, const rayrs_emission* emission) {
+    RAYRS_GUARDED({
     return from_triangles<double>(objs, verts, nverts, idx, ntris, mat, emission);
+    })
 }
 
 int rayrs_object_from_spheres(rayrs_objects* objs, double radius, const double* centers, uint32_t n,
@@ -215,7 +187,7 @@ int rayrs_object_box_geom(rayrs_objects* objs, const double ll[3], const double 
 
 // ------------------------------------------------------------------- Scene
 
-static void scene_free_device(rayrs_scene* s) {
+extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     if (s->device < 0) return;
     (void)hipSetDevice(s->device);
     if (s->pending && s->last_stream) (void)hipStreamSynchronize(s->last_stream);
@@ -244,7 +216,27 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
     delete scene;
 }
 
-static int scene_upload(rayrs_scene* s) {
+// Sizes the traversal workgroup's LDS from the tree and the scene's tuning, and asks the runtime how
+// many such workgroups fit a CU.  A workgroup's LDS: the first stack_lds entries of each lane's stack
+// (deeper entries overflow to HBM; on the 1M-triangle scene 99.4 % of visits happen with at most 7
+// pending), 4 KiB of window lists, and the hot_records largest wide records.  13 + 4 + 14 KiB lets
+// five workgroups (the kernel's launch bound) share a CU's 160 KiB.
+static int scene_configure_traversal(rayrs_scene* s) {
+    const FlatScene& f = s->flat;
+    const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
+    uint32_t want = s->tuning.stack_lds ? s->tuning.stack_lds : TRAV_STACK_LDS;
+    s->stack_lds = want < depth ? want : depth;
+    const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
+    uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
+    if (s->tuning.hot_records == 0xffffffffu) hot = 0;
+    else if (s->tuning.hot_records) hot = s->tuning.hot_records < WIDE_FRONT ? s->tuning.hot_records : WIDE_FRONT;
+    s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
+    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
+    if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    return RAYRS_OK;
+}
+
+extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -263,24 +255,10 @@ static int scene_upload(rayrs_scene* s) {
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_rgba.size() * sizeof(float);
-    // A traversal workgroup's LDS: the first stack_lds entries of each lane's stack (deeper
-    // entries overflow to HBM; measured on the 1M-triangle scene 99.9 % of visits happen with
-    // at most 10 pending), 4 KiB of window lists, and the hot_records largest wide records.
-    // 13 + 4 + 14 KiB lets five workgroups (the kernel's launch bound) share a CU's 160 KiB.
-    const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
-    s->stack_lds = depth < TRAV_STACK_LDS ? depth : TRAV_STACK_LDS;
-    if (const char* env = getenv("RAYRS_STACK_LDS")) {
-        const int v = atoi(env);
-        if (v >= 1 && (uint32_t)v <= depth) s->stack_lds = (uint32_t)v;
+    {
+        const int st = scene_configure_traversal(s);
+        if (st != RAYRS_OK) return st;
     }
-    uint32_t hot = TRAV_HOT_BYTES / (f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u);
-    if (const char* env = getenv("RAYRS_HOT_RECORDS")) {
-        const int v = atoi(env);
-        if (v >= 0 && (uint32_t)v <= WIDE_FRONT) hot = (uint32_t)v;
-    }
-    s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
-    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
-    if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
     HIP_TRY(hipMalloc((void**)&s->wf.ctl, sizeof(WfCtl)));
     HIP_TRY(hipHostMalloc((void**)&s->h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
     for (auto& e : s->ev_batch) HIP_TRY(hipEventCreate(&e));
@@ -289,28 +267,25 @@ static int scene_upload(rayrs_scene* s) {
 
 int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int heuristic, uint32_t splits,
                     uint32_t hdri_w, uint32_t hdri_h, const float* hdri_rgb, int device, rayrs_scene** out) {
+    RAYRS_GUARDED({
     if (!objs || !out) return RAYRS_INVALID_ARG;
     *out = nullptr;
-    rayrs_scene* s = new (std::nothrow) rayrs_scene();
-    if (!s) return RAYRS_OOM;
+    std::unique_ptr<rayrs_scene> s(new rayrs_scene());
     int st = build_flat_scene(objs->list, z_near, z_far, heuristic, splits, hdri_w, hdri_h, hdri_rgb, &s->flat);
-    if (st != RAYRS_OK) {
-        delete s;
-        return st;
-    }
+    if (st != RAYRS_OK) return st;
     s->surfaces = objs->list.surfaces;
     s->n_objects = objs->list.objs.size();
     s->device = device;
     if (device >= 0) {
-        st = scene_upload(s);
+        st = scene_upload(s.get());
         if (st != RAYRS_OK) {
-            scene_free_device(s);
-            delete s;
+            scene_free_device(s.get());
             return st;
         }
     }
-    *out = s;
+    *out = s.release();
     return RAYRS_OK;
+    })
 }
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
@@ -351,6 +326,101 @@ int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t
     if (wide_box && !f.wide_box.empty()) std::memcpy(wide_box, f.wide_box.data(), f.wide_box.size() * 8);
     if (wide_ref && !f.wide_ref.empty()) std::memcpy(wide_ref, f.wide_ref.data(), f.wide_ref.size() * 4);
     return RAYRS_OK;
+}
+
+int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scene** out) {
+    RAYRS_GUARDED({
+        if (!scene || !out || device < 0) return RAYRS_INVALID_ARG;
+        *out = nullptr;
+        std::unique_ptr<rayrs_scene> s(new rayrs_scene());
+        s->flat = scene->flat;
+        s->surfaces = scene->surfaces;
+        s->n_objects = scene->n_objects;
+        s->tuning = scene->tuning;
+        s->device = device;
+        const int st = scene_upload(s.get());
+        if (st != RAYRS_OK) {
+            scene_free_device(s.get());
+            return st;
+        }
+        *out = s.release();
+        return RAYRS_OK;
+    })
+}
+
+int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device : -1; }
+
+int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
+    if (!scene || !tuning) return RAYRS_INVALID_ARG;
+    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u) return RAYRS_INVALID_ARG;
+    if (scene->device >= 0) {
+        HIP_TRY(hipSetDevice(scene->device));
+        if (scene->pending && scene->last_stream) {
+            HIP_TRY(hipStreamSynchronize(scene->last_stream));
+            scene->pending = false;
+        }
+    }
+    scene->tuning = *tuning;
+    if (scene->device >= 0) return scene_configure_traversal(scene);
+    return RAYRS_OK;
+}
+
+uint32_t rayrs_frame_sample_chunk(uint32_t x_pixels, uint32_t y_pixels, uint32_t spp, uint32_t requested) {
+    if (spp == 0) return 0;
+    uint64_t chunk = requested ? requested : 4u;
+    const uint64_t pixels = (uint64_t)((x_pixels + 7u) / 8u) * ((y_pixels + 7u) / 8u) * 64u;  // whole 8x8 tiles
+    while (chunk < spp && pixels * ((spp + chunk - 1) / chunk) > (1ull << 30)) chunk *= 2;
+    return chunk >= spp ? 0u : (uint32_t)chunk;  // 0 = one sequential sum per pixel (the reference's order)
+}
+
+uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
+    std::vector<uint32_t> t;
+#define RAYRS_STRUCT(T, N) t.push_back((uint32_t)sizeof(T)), t.push_back(N)
+#define RAYRS_FIELD(T, F) t.push_back((uint32_t)offsetof(T, F))
+    RAYRS_STRUCT(rayrs_material, 7);
+    RAYRS_FIELD(rayrs_material, kind), RAYRS_FIELD(rayrs_material, metallic), RAYRS_FIELD(rayrs_material, color);
+    RAYRS_FIELD(rayrs_material, spec_color), RAYRS_FIELD(rayrs_material, alpha), RAYRS_FIELD(rayrs_material, ior);
+    RAYRS_FIELD(rayrs_material, r0);
+    RAYRS_STRUCT(rayrs_emission, 4);
+    RAYRS_FIELD(rayrs_emission, emissive), RAYRS_FIELD(rayrs_emission, pad), RAYRS_FIELD(rayrs_emission, strength);
+    RAYRS_FIELD(rayrs_emission, color);
+    RAYRS_STRUCT(rayrs_camera, 9);
+    RAYRS_FIELD(rayrs_camera, origin), RAYRS_FIELD(rayrs_camera, e_x), RAYRS_FIELD(rayrs_camera, e_y);
+    RAYRS_FIELD(rayrs_camera, z), RAYRS_FIELD(rayrs_camera, width), RAYRS_FIELD(rayrs_camera, height);
+    RAYRS_FIELD(rayrs_camera, ppc), RAYRS_FIELD(rayrs_camera, x_pixels), RAYRS_FIELD(rayrs_camera, y_pixels);
+    RAYRS_STRUCT(rayrs_scene_info_t, 16);
+    RAYRS_FIELD(rayrs_scene_info_t, n_objects), RAYRS_FIELD(rayrs_scene_info_t, n_interior);
+    RAYRS_FIELD(rayrs_scene_info_t, n_prims), RAYRS_FIELD(rayrs_scene_info_t, root_ref);
+    RAYRS_FIELD(rayrs_scene_info_t, depth), RAYRS_FIELD(rayrs_scene_info_t, compact);
+    RAYRS_FIELD(rayrs_scene_info_t, n_surfaces), RAYRS_FIELD(rayrs_scene_info_t, node_bytes);
+    RAYRS_FIELD(rayrs_scene_info_t, prim_bytes), RAYRS_FIELD(rayrs_scene_info_t, device_bytes);
+    RAYRS_FIELD(rayrs_scene_info_t, root_box), RAYRS_FIELD(rayrs_scene_info_t, build_seconds);
+    RAYRS_FIELD(rayrs_scene_info_t, n_wide), RAYRS_FIELD(rayrs_scene_info_t, wide_root_ref);
+    RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, reserved);
+    RAYRS_STRUCT(rayrs_render_params, 8);
+    RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
+    RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
+    RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
+    RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
+    RAYRS_STRUCT(rayrs_render_stats, 20);
+    RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
+    RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
+    RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
+    RAYRS_FIELD(rayrs_render_stats, sphere_tests), RAYRS_FIELD(rayrs_render_stats, plane_tests);
+    RAYRS_FIELD(rayrs_render_stats, escaped_paths), RAYRS_FIELD(rayrs_render_stats, step_wave);
+    RAYRS_FIELD(rayrs_render_stats, step_lane), RAYRS_FIELD(rayrs_render_stats, inner_wave);
+    RAYRS_FIELD(rayrs_render_stats, leaf_wave), RAYRS_FIELD(rayrs_render_stats, interior_ticks);
+    RAYRS_FIELD(rayrs_render_stats, leaf_ticks), RAYRS_FIELD(rayrs_render_stats, kernel_ms);
+    RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
+    RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
+    RAYRS_STRUCT(rayrs_tuning, 7);
+    RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
+    RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
+    RAYRS_FIELD(rayrs_tuning, reserved);
+#undef RAYRS_STRUCT
+#undef RAYRS_FIELD
+    for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
+    return (uint32_t)t.size();
 }
 
 // ------------------------------------------------------------------ Camera
@@ -401,6 +471,7 @@ static CameraDev make_camera_dev(const rayrs_camera* c) {
 
 int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
                         void* out_device, void* hip_stream) {
+    RAYRS_GUARDED({
     if (!scene || !camera || !params || !out_device) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
@@ -433,10 +504,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_nchunks = 1.0 / (double)rp.nchunks;
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
-    rp.refill_min = 52;
-    rp.leaf_min = 24;
-    if (const char* env = getenv("RAYRS_REFILL_MIN")) rp.refill_min = (uint32_t)atoi(env);
-    if (const char* env = getenv("RAYRS_LEAF_MIN")) rp.leaf_min = (uint32_t)atoi(env);
+    rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
+    rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 24u;
     rp.out_format = params->out_format;
     rp.out = out_device;
     rp.counters = scene->d_counters;
@@ -469,10 +538,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         const uint64_t by_work = samples / 16u > (1ull << 20) ? samples / 16u : (1ull << 20);
         if (np64 > by_work) np64 = by_work;
     }
-    if (const char* env = getenv("RAYRS_POOL_SLOTS")) {
-        const long long v = atoll(env);
-        if (v > 0) np64 = (uint64_t)v;
-    }
+    if (scene->tuning.pool_slots) np64 = scene->tuning.pool_slots;
     if (np64 > rp.total_items) np64 = rp.total_items;
     const uint32_t live = (uint32_t)np64;
     np64 = (np64 + 1023ull) & ~1023ull;  // whole windows
@@ -497,8 +563,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->blocks_per_cu;
     {
         // whole round-robin rounds covering about static_pct % of the pool's windows
-        uint32_t static_pct = 50;
-        if (const char* env = getenv("RAYRS_STATIC_PCT")) static_pct = (uint32_t)atoi(env);
+        uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
         if (static_pct > 100) static_pct = 100;
         const uint64_t n_windows = np / wf_window_slots(), n_waves = (uint64_t)trav_blocks * 4u;
         rp.static_windows = (uint32_t)(n_windows * static_pct / 100u / n_waves * n_waves);
@@ -539,12 +604,15 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         HIP_TRY(wf_launch_gen(cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
         // Rounds are enqueued in batches; the live-slot count of batch b is read
         // back while batch b+1 is already queued, so the GPU never waits for the host.
-        constexpr uint32_t BATCH = 16;
+        // Rounds behind the frame's last one find live_slots == 0 and return at once; batches shrink from
+        // 16 rounds to 4 once fewer than an eighth of the slots have work, so that at most 7 such rounds
+        // (about 21 launches of a few microseconds) are queued after the end.
         constexpr uint32_t MAX_TIMED = 8192;
-        scene->h_live[0] = scene->h_live[1] = 1;
+        scene->h_live[0] = scene->h_live[1] = live;
         uint32_t it = 0;
+        uint32_t batch = 16;
         for (uint32_t b = 0;; b++) {
-            for (uint32_t k = 0; k < BATCH; k++, it++) {
+            for (uint32_t k = 0; k < batch; k++, it++) {
                 const bool timed = it < MAX_TIMED;
                 if (timed) {
                     while (scene->ev_trav.size() < 2 * (size_t)(it + 1)) {
@@ -567,7 +635,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             HIP_TRY(hipEventRecord(scene->ev_batch[b & 1u], stream));
             if (b > 0) {
                 HIP_TRY(hipEventSynchronize(scene->ev_batch[(b - 1u) & 1u]));
-                if (scene->h_live[(b - 1u) & 1u] == 0u) break;
+                const uint32_t seen = scene->h_live[(b - 1u) & 1u];
+                if (seen == 0u) break;
+                batch = (uint64_t)seen * 8u < np ? 4u : 16u;
             }
             if (it > (1u << 26)) {
                 g_last_error = "path rounds did not terminate";
@@ -583,6 +653,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     scene->pending = true;
     scene->last_count = count;
     return RAYRS_OK;
+    })
 }
 
 int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
@@ -736,6 +807,7 @@ int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, u
 int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
                         const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
                         uint32_t* draws) {
+    RAYRS_GUARDED({
     if (!mat || !normal || !view || !key || !scattered || !color || !dir || !draws) return RAYRS_INVALID_ARG;
     ObjectList tmp;
     const int surf = tmp.add_surface(mat, nullptr);
@@ -759,6 +831,7 @@ int rayrs_test_material(int device, const rayrs_material* mat, const double* nor
     ST_TRY(dc.download(color, n * 24));
     ST_TRY(dd.download(dir, n * 24));
     return ddr.download(draws, n * 4);
+    })
 }
 
 int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb) {

@@ -7,6 +7,7 @@
 namespace rayrs {
 
 hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream);
+hipError_t launch_accumulate(void* dst, const void* src, size_t n, bool f64, hipStream_t stream);
 
 hipError_t launch_test_math(int fn, const double* x, const double* y, uint64_t n, double* out, hipStream_t stream);
 hipError_t launch_test_rng(uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,

@@ -42,6 +42,24 @@ __global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev r
     }
 }
 
+// dst += src, element by element (rayrs_render_multi: ranks rehearsed on one device; every element is
+// non-zero in at most one of the two, so the sum is exact)
+template <typename T>
+__global__ void __launch_bounds__(256) accumulate_kernel(T* dst, const T* src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+hipError_t launch_accumulate(void* dst, const void* src, size_t n, bool f64, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (f64)
+        hipLaunchKernelGGL(accumulate_kernel<double>, dim3(blocks), dim3(256), 0, stream, (double*)dst, (const double*)src, n);
+    else
+        hipLaunchKernelGGL(accumulate_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)dst, (const float*)src, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------ launch glue
 
 static inline uint32_t lds_bytes_for(uint32_t stack_depth) { return 4u * 64u * (stack_depth + 1u) * 4u; }  // + the spare entry

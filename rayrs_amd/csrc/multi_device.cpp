@@ -1,0 +1,224 @@
+// multi_device.cpp -- rayrs_render_multi: the block loop of rayrs/src/main.rs:57-101 over the GPUs
+// of one node, inside the library.
+//
+// The reference spreads 16x16 image blocks over rayon's worker threads (main.rs:61) and joins the
+// blocks into one image (main.rs:101).  Here the workers are GPUs: scene i renders the 8x8 tiles
+// t with t % n == i (paths never communicate and the RNG is keyed by (pixel, sample), so the
+// partition does not change a pixel), each from its own host thread on its own stream into a
+// zeroed full-size framebuffer on its device, and one RCCL reduce (sum, root = the first scene's
+// device) over xGMI assembles the frame: a pixel is non-zero on exactly one rank, x + 0 is exact,
+// so the result does not depend on the reduction order and equals the one-GPU frame bit for bit.
+//
+// RCCL is loaded with dlopen on first use -- a host that renders on one GPU never needs it -- and
+// every failure of it comes back as RAYRS_RCCL_ERROR.  Ranks that share a device (rehearsing on
+// one GPU) are first summed on that device by a small kernel, then the distinct devices reduce.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "kernels.h"
+#include "scene_internal.hpp"
+
+using namespace rayrs;
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    // one communicator set per device list, kept for the life of the process (creating one takes ~1 s)
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;
+};
+
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+
+bool rccl_load(Rccl& r) {
+    if (r.handle) return true;
+    if (!r.error.empty()) return false;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        r.error = std::string("dlopen(librccl.so.1): ") + dlerror();
+        return false;
+    }
+    auto sym = [&](const char* name) {
+        void* p = dlsym(r.handle, name);
+        if (!p && r.error.empty()) r.error = std::string("librccl has no ") + name;
+        return p;
+    };
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.error.empty()) {
+        dlclose(r.handle);
+        r.handle = nullptr;
+        return false;
+    }
+    return true;
+}
+
+int rccl_fail(Rccl& r, ncclResult_t e, const char* what) {
+    set_last_error(std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error"));
+    return RAYRS_RCCL_ERROR;
+}
+
+#define RCCL_TRY(expr)                                             \
+    do {                                                           \
+        ncclResult_t _e = (expr);                                  \
+        if (_e != ncclSuccess) return rccl_fail(g_rccl, _e, #expr); \
+    } while (0)
+
+// Sum of the framebuffers of the distinct devices into bufs[0] (on devs[0]); one stream per device.
+int rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*>& bufs, const std::vector<hipStream_t>& streams,
+                         size_t count, bool f64) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!rccl_load(g_rccl)) {
+        set_last_error(g_rccl.error);
+        return RAYRS_RCCL_ERROR;
+    }
+    auto it = g_rccl.comms.find(devs);
+    if (it == g_rccl.comms.end()) {
+        std::vector<ncclComm_t> c(devs.size());
+        RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data()));
+        it = g_rccl.comms.emplace(devs, c).first;
+    }
+    const std::vector<ncclComm_t>& comms = it->second;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 0; i < devs.size(); i++) {
+        HIP_TRY(hipSetDevice(devs[i]));
+        const ncclResult_t e = g_rccl.Reduce(bufs[i], bufs[i], count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, 0, comms[i],
+                                             streams[i]);
+        if (e != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return rccl_fail(g_rccl, e, "ncclReduce");
+        }
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    for (size_t i = 0; i < devs.size(); i++) {
+        HIP_TRY(hipSetDevice(devs[i]));
+        HIP_TRY(hipStreamSynchronize(streams[i]));
+    }
+    return RAYRS_OK;
+}
+
+struct Rank {
+    rayrs_scene* scene = nullptr;
+    void* d_out = nullptr;
+    hipStream_t stream = nullptr;
+    rayrs_render_stats stats = {};
+    int status = RAYRS_OK;
+    std::string error;
+};
+
+void render_rank(Rank& r, const rayrs_camera* camera, rayrs_render_params params, size_t bytes) {
+    auto fail = [&](int st) {
+        r.status = st;
+        r.error = rayrs_last_error();  // this thread's text
+    };
+    hipError_t e = hipSetDevice(r.scene->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&r.d_out, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(r.d_out, 0, bytes, r.stream);  // the tiles of the other ranks stay exact zeros
+    if (e != hipSuccess) return fail(hip_fail(e, "rayrs_render_multi: device setup"));
+    int st = rayrs_render_launch(r.scene, camera, &params, r.d_out, r.stream);
+    if (st == RAYRS_OK) st = rayrs_render_finish(r.scene, &r.stats);
+    if (st != RAYRS_OK) fail(st);
+}
+
+}  // namespace
+
+extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camera* camera,
+                                  const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats) {
+    RAYRS_GUARDED({
+        if (!scenes || n == 0 || !camera || !params || !out_host) return RAYRS_INVALID_ARG;
+        for (uint32_t i = 0; i < n; i++) {
+            if (!scenes[i]) return RAYRS_INVALID_ARG;
+            if (scenes[i]->device < 0) return RAYRS_NO_DEVICE;
+            for (uint32_t j = 0; j < i; j++)
+                if (scenes[j] == scenes[i]) return RAYRS_INVALID_ARG;  // one render in flight per scene handle
+        }
+        const bool f64 = params->out_format == RAYRS_OUT_F64;
+        const size_t count = (size_t)camera->x_pixels * camera->y_pixels * 3;
+        const size_t bytes = count * (f64 ? 8 : 4);
+
+        // ---- every rank renders its tiles on its own host thread and stream
+        std::vector<Rank> ranks(n);
+        std::vector<std::thread> threads;
+        for (uint32_t i = 0; i < n; i++) {
+            ranks[i].scene = scenes[i];
+            rayrs_render_params p = *params;
+            p.tile_rank = i;
+            p.tile_ranks = n;
+            threads.emplace_back(render_rank, std::ref(ranks[i]), camera, p, bytes);
+        }
+        for (auto& t : threads) t.join();
+        int st = RAYRS_OK;
+        for (auto& r : ranks)
+            if (r.status != RAYRS_OK && st == RAYRS_OK) {
+                st = r.status;
+                set_last_error(r.error);
+            }
+
+        // ---- ranks that share a device are summed there; then one RCCL reduce over the distinct devices
+        std::vector<int> devs;
+        std::vector<void*> bufs;
+        std::vector<hipStream_t> streams;
+        if (st == RAYRS_OK) {
+            for (uint32_t i = 0; i < n && st == RAYRS_OK; i++) {
+                const int dev = ranks[i].scene->device;
+                const auto at = std::find(devs.begin(), devs.end(), dev);
+                if (at == devs.end()) {
+                    devs.push_back(dev), bufs.push_back(ranks[i].d_out), streams.push_back(ranks[i].stream);
+                } else {
+                    const size_t k = (size_t)(at - devs.begin());
+                    hipError_t e = hipSetDevice(dev);
+                    if (e == hipSuccess) e = launch_accumulate(bufs[k], ranks[i].d_out, count, f64, streams[k]);
+                    if (e == hipSuccess) e = hipStreamSynchronize(streams[k]);
+                    if (e != hipSuccess) st = hip_fail(e, "rayrs_render_multi: same-device sum");
+                }
+            }
+        }
+        if (st == RAYRS_OK && n > 1) st = rccl_reduce_to_first(devs, bufs, streams, count, f64);
+        if (st == RAYRS_OK) {
+            hipError_t e = hipSetDevice(devs[0]);
+            if (e == hipSuccess) e = hipMemcpy(out_host, bufs[0], bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) st = hip_fail(e, "rayrs_render_multi: hipMemcpy(out D2H)");
+        }
+        if (st == RAYRS_OK && stats) {
+            *stats = ranks[0].stats;  // times of rank 0; counters summed over the ranks
+            for (uint32_t i = 1; i < n; i++) {
+                const rayrs_render_stats& s = ranks[i].stats;
+                stats->rays += s.rays, stats->paths += s.paths, stats->nan_pixels += s.nan_pixels;
+                stats->neg_pixels += s.neg_pixels, stats->escaped_paths += s.escaped_paths;
+                stats->interior_visits += s.interior_visits, stats->tri_tests += s.tri_tests;
+                stats->sphere_tests += s.sphere_tests, stats->plane_tests += s.plane_tests;
+                if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
+                if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
+                if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;
+            }
+        }
+        for (auto& r : ranks) {
+            if (r.scene->device >= 0) (void)hipSetDevice(r.scene->device);
+            if (r.d_out) (void)hipFree(r.d_out);
+            if (r.stream) (void)hipStreamDestroy(r.stream);
+        }
+        return st;
+    })
+}

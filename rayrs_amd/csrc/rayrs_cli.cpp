@@ -1,6 +1,12 @@
 // rayrs_cli.cpp -- the reference's command line (rayrs/src/main.rs) on top of the C ABI:
 //
 //     rayrs hdri_path [spp] [--scene NAME] [--seed N] [--device N] [--max-bounces N]
+//                           [--gpus N | --devices a,b,...]
+//
+// --gpus N renders on HIP devices 0..N-1 at once (--devices names them; a device may be named more than
+// once to rehearse on fewer GPUs): image tiles interleaved over the devices, one RCCL reduce of the
+// framebuffer (rayrs_render_multi) -- the counterpart of the reference's rayon block loop, which also
+// lives inside the binary.
 //
 // Same positional arguments and defaults as main.rs:125-138 (spp defaults to 2000 and a spp
 // that does not parse silently becomes 2000), same default scene (material_test, main.rs:201),
@@ -111,6 +117,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 0x5EED;
     int device = 0;
     uint32_t max_bounces = 50;  // main.rs:77
+    std::vector<int> devices;
     int i = 2;
     if (i < argc && argv[i][0] != '-') {
         char* end = nullptr;
@@ -124,6 +131,21 @@ int main(int argc, char** argv) {
         else if (opt == "--seed") seed = std::strtoull(argv[i + 1], nullptr, 0);
         else if (opt == "--device") device = std::atoi(argv[i + 1]);
         else if (opt == "--max-bounces") max_bounces = (uint32_t)std::atoi(argv[i + 1]);
+        else if (opt == "--gpus") {
+            devices.clear();
+            for (int d = 0; d < std::atoi(argv[i + 1]); d++) devices.push_back(d);
+        } else if (opt == "--devices") {
+            devices.clear();
+            for (const char* p = argv[i + 1]; *p;) {
+                char* end = nullptr;
+                devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) {
+                    std::fprintf(stderr, "bad device list %s\n", argv[i + 1]);
+                    return 1;
+                }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else {
             std::fprintf(stderr, "unknown option %s\n", opt.c_str());
             return 1;
@@ -153,11 +175,18 @@ int main(int argc, char** argv) {
         if ((st = rayrs_object_sphere(objs, 1., origin, &def.spheres[(size_t)k], &dark)) != RAYRS_OK)
             return fail("sphere", st);
     }
+    if (devices.empty()) devices.push_back(device);
     rayrs_scene* scene = nullptr;
-    st = rayrs_scene_new(objs, 0.000001, 1000000., RAYRS_BVH_SAH, 1000, hw, hh, hdri, device, &scene);  // main.rs:52
+    st = rayrs_scene_new(objs, 0.000001, 1000000., RAYRS_BVH_SAH, 1000, hw, hh, hdri, devices[0], &scene);  // main.rs:52
     rayrs_objects_destroy(objs);
     rayrs_buffer_free(hdri);
     if (st != RAYRS_OK) return fail("scene", st);
+    std::vector<rayrs_scene*> scenes{scene};  // one handle per device; the BVH is built once
+    for (size_t d = 1; d < devices.size(); d++) {
+        rayrs_scene* clone = nullptr;
+        if ((st = rayrs_scene_clone_to_device(scene, devices[d], &clone)) != RAYRS_OK) return fail("scene clone", st);
+        scenes.push_back(clone);
+    }
 
     rayrs_camera cam;
     const double up[3] = {0., 1., 0.};
@@ -176,7 +205,10 @@ int main(int argc, char** argv) {
     std::vector<float> rgb((size_t)cam.x_pixels * cam.y_pixels * 3, 0.f);
     rayrs_render_stats stats;
     const auto t0 = std::chrono::steady_clock::now();
-    st = rayrs_render(scene, &cam, &params, rgb.data(), &stats);
+    if (scenes.size() == 1)
+        st = rayrs_render(scene, &cam, &params, rgb.data(), &stats);
+    else
+        st = rayrs_render_multi(scenes.data(), (uint32_t)scenes.size(), &cam, &params, rgb.data(), &stats);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (st != RAYRS_OK) return fail("render", st);
     if (stats.nan_pixels) std::fprintf(stderr, "NaN pixel detected\n");       // main.rs:81-83
@@ -193,6 +225,6 @@ int main(int argc, char** argv) {
         return fail("png", st);
     if ((st = rayrs_hdr_save((scene_name + ".hdr").c_str(), rgb.data(), cam.x_pixels, cam.y_pixels)) != RAYRS_OK)
         return fail("hdr", st);
-    rayrs_scene_destroy(scene);
+    for (rayrs_scene* sc : scenes) rayrs_scene_destroy(sc);
     return 0;
 }

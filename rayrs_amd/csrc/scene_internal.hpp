@@ -1,0 +1,82 @@
+// scene_internal.hpp -- the handles behind include/rayrs_hip.h, shared by abi.cpp and multi_device.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rayrs_hip.h"
+#include "scene_host.hpp"
+#include "wavefront.h"
+
+struct rayrs_objects {
+    rayrs::ObjectList list;
+};
+
+struct rayrs_scene {
+    rayrs::FlatScene flat;
+    std::vector<rayrs::SurfaceDev> surfaces;
+    uint64_t n_objects = 0;
+    int device = -1;
+    void* d_nodes = nullptr;
+    void* d_prims = nullptr;
+    rayrs::SurfaceDev* d_surfaces = nullptr;
+    float* d_hdri = nullptr;
+    rayrs::Counters* d_counters = nullptr;
+    double* d_partial = nullptr;
+    size_t partial_items = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    bool last_count = false;
+    int cu_count = 0;
+    int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
+    uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
+    uint32_t hot_records = 0;    // leading wide records kept in LDS
+    uint32_t* d_stack_spill = nullptr;
+    size_t stack_spill_words = 0;
+    uint64_t device_bytes = 0;
+    // path pool and queues of the wavefront pipeline
+    rayrs::WfDev wf = {};
+    void* wf_block = nullptr;    // one allocation holding the slot records and the state bytes
+    unsigned long long* d_wave_items = nullptr;  // per-wave reserved item ranges
+    uint32_t wave_items_cap = 0;
+    uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
+    uint32_t rounds = 0;
+    uint32_t timed_rounds = 0;
+    rayrs_tuning tuning = {};  // zeros = defaults (rayrs_scene_set_tuning)
+};
+
+
+namespace rayrs {
+// thread-local text behind rayrs_last_error()
+void set_last_error(const std::string& text);
+int hip_fail(hipError_t e, const char* what);
+// uploads s->flat to s->device and sizes the traversal kernel's LDS (abi.cpp)
+int scene_upload(rayrs_scene* s);
+void scene_free_device(rayrs_scene* s);
+}  // namespace rayrs
+
+#define HIP_TRY(expr)                                       \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return rayrs::hip_fail(_e, #expr); \
+    } while (0)
+
+// No exception may cross the C boundary (a std::bad_alloc from a vector would otherwise end the host process).
+#define RAYRS_GUARDED(...)                                   \
+    try {                                                    \
+        __VA_ARGS__                                          \
+    } catch (const std::bad_alloc&) {                        \
+        rayrs::set_last_error("out of host memory");         \
+        return RAYRS_OOM;                                    \
+    } catch (const std::exception& e) {                      \
+        rayrs::set_last_error(e.what());                     \
+        return RAYRS_INVALID_ARG;                            \
+    } catch (...) {                                          \
+        rayrs::set_last_error("unknown exception");          \
+        return RAYRS_INVALID_ARG;                            \
+    }

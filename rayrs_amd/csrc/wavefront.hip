@@ -348,6 +348,7 @@ template <bool COMPACT, bool COUNT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
+    if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
@@ -525,6 +526,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
     // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
     __shared__ SurfaceDev s_surf[HIT_SURFACES_LDS];
+    if (wf.ctl->live_slots == 0u) return;
     const uint32_t n_surf_lds = sc.n_surfaces < HIT_SURFACES_LDS ? sc.n_surfaces : HIT_SURFACES_LDS;
     for (uint32_t i = threadIdx.x; i < n_surf_lds * (uint32_t)(sizeof(SurfaceDev) / 4); i += 256u)
         reinterpret_cast<uint32_t*>(s_surf)[i] = reinterpret_cast<const uint32_t*>(sc.surfaces)[i];
@@ -631,6 +633,7 @@ RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 
 
 __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
+    if (wf.ctl->live_slots == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;

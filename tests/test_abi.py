@@ -115,3 +115,62 @@ def test_box_geom_keeps_the_reference_face_order():
     faces = Object.box_geom((0, 1, 2), (3, 4, 5), NR, DARK)
     assert [f.axis for f in faces] == [Axis.X, Axis.XRev, Axis.ZRev, Axis.Z, Axis.YRev, Axis.Y]
     assert faces[4].pos == 1.0 and faces[5].pos == 1.0
+
+
+def test_ctypes_structs_have_the_c_layout():
+    """rayrs_abi_layout() reports sizeof / offsetof of every public struct as the library was compiled;
+    rayrs_amd/_ffi.py's ctypes mirrors must agree field for field (INTEGRATION.md's #[repr(C)] structs are
+    written from the same table)."""
+    L = _ffi.lib()
+    n = L.rayrs_abi_layout(None, 0)
+    table = (C.c_uint32 * n)()
+    assert L.rayrs_abi_layout(table, n) == n
+    table, pos = list(table), 0
+    for st in _ffi.ABI_STRUCTS:
+        size, nfields = table[pos], table[pos + 1]
+        offsets = table[pos + 2:pos + 2 + nfields]
+        pos += 2 + nfields
+        assert C.sizeof(st) == size, st.__name__
+        assert len(st._fields_) == nfields, st.__name__
+        assert [getattr(st, name).offset for name, _ in st._fields_] == offsets, st.__name__
+    assert pos == n
+
+
+def test_integration_md_quotes_the_struct_sizes():
+    L = _ffi.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for st, cname in zip(_ffi.ABI_STRUCTS, ["rayrs_material", "rayrs_emission", "rayrs_camera", "rayrs_scene_info_t",
+                                            "rayrs_render_params", "rayrs_render_stats", "rayrs_tuning"]):
+        assert re.search(rf"{cname}\W+{C.sizeof(st)} bytes", text), f"INTEGRATION.md: {cname} is {C.sizeof(st)} bytes"
+
+
+def test_frame_sample_chunk_depends_on_the_frame_only():
+    """The chunk rule (rayrs_frame_sample_chunk): smallest requested * 2^k with at most 2^30 (pixel, chunk)
+    items in the WHOLE frame -- the same for every rank count."""
+    f = rayrs_amd.frame_sample_chunk
+    assert f(2048, 2048, 1024) == 4      # configs[4]: exactly 2^30 items
+    assert f(2048, 2048, 4096) == 16     # configs[3]
+    assert f(1024, 1024, 512) == 4 and f(1024, 1024, 256) == 4 and f(256, 256, 64) == 4
+    assert f(2049, 2048, 1024) == 8      # one more tile column tips it over
+    assert f(64, 64, 4) == 0 and f(64, 64, 3) == 0   # chunk >= spp: one sequential sum, the reference's order
+    assert f(64, 64, 64, requested=16) == 16
+    for w, h, spp in ((2048, 2048, 1024), (4096, 4096, 4096), (333, 77, 100000)):
+        c = f(w, h, spp) or spp
+        assert ((w + 7) // 8) * ((h + 7) // 8) * 64 * -(-spp // c) <= 1 << 30
+
+
+def test_tuning_is_validated_and_needs_no_gpu():
+    cam_args, objs, heur = scenes.diffuse_single_sphere()
+    sc = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+    sc.set_tuning(stack_lds=2, refill_min=40)
+    with pytest.raises(_ffi.RayrsError):
+        sc.set_tuning(static_pct=101)
+    with pytest.raises(ValueError):
+        sc.set_tuning(no_such_knob=1)
+
+
+def test_no_environment_variable_reaches_the_product():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rayrs_amd", "csrc")):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".hpp")):
+                assert "getenv" not in open(os.path.join(dirpath, f)).read(), f

@@ -40,9 +40,11 @@ def test_oracle_material_vectors(name):
 def test_oracle_intersections_and_frame(name):
     cam_args, objs, heur = G.SCENES[name]()
     o, d = G.rays(256, 11)
+    import rayrs_amd
+    prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)  # host only: the tree the kernels walk
     for builder in (0, 1):  # literal reference builder and the swept one
-        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI, builder=builder)
-        for trav in (0, 1, 2):  # recursive reference traversal, the ordered one, the folded one
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI, builder=builder).use_walk_tree(prod)
+        for trav in (0, 1, 2):  # recursive reference traversal, the ordered one, the kernel's walk
             t, obj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=trav)
             assert np.array_equal(obj, GOLD[f"isect/{name}/obj"])
             assert np.array_equal(bits(t), bits(GOLD[f"isect/{name}/t"]))

@@ -46,3 +46,18 @@ def test_cli_usage_and_spp_fallback(tmp_path):
     assert r.returncode == 1 and "Usage: rayrs hdri_path [spp]" in r.stderr  # main.rs:126-128
     r = subprocess.run([CLI, str(tmp_path / "nope.hdr")], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def test_cli_on_two_logical_gpus_writes_the_same_image(tmp_path):
+    """--devices 0,0: rayrs_render_multi through the command line (--gpus N names devices 0..N-1)."""
+    hdri = procedural.make_hdri(64, 32)
+    io.save_hdr(tmp_path / "env.hdr", hdri)
+    outs = []
+    for extra in ([], ["--devices", "0,0"]):
+        d = tmp_path / ("multi" if extra else "single")
+        d.mkdir()
+        r = subprocess.run([CLI, str(tmp_path / "env.hdr"), "4", "--scene", "diffuse_single_sphere", "--seed", "5"]
+                           + extra, cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append((d / "diffuse_single_sphere.png").read_bytes())
+    assert outs[0] == outs[1]

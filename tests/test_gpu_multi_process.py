@@ -1,0 +1,40 @@
+"""The N > 1 code that runs on an 8-GPU node, rehearsed on one GPU: bench.py itself under
+torch.distributed.run with two ranks (tile_rank = RANK, the framebuffer reduce, the rank-0 line),
+both ranks on HIP device 0 and the reduce through gloo -- RCCL cannot put two ranks on one device.
+The assembled frame must be the single-process frame, bit for bit (sha256 of the f32 framebuffer),
+with the same ray count and the same sample chunk."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--config", "5", "--res", "256", "--spp", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+          "--no-roofline", "--no-build"]
+
+
+def run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_with_n_ranks_assembles_the_single_rank_frame(world):
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
+    port = 29600 + (os.getpid() % 1000) + world
+    many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world),
+                "--backend", "gloo", "--device", "0"] + COMMON)
+    assert one["n_gpus"] == 1 and many["n_gpus"] == world
+    assert many["framebuffer_sha256"] == one["framebuffer_sha256"]
+    assert many["framebuffer_checksum"] == one["framebuffer_checksum"]
+    assert many["rays_per_step"] == one["rays_per_step"]
+    assert many["config"]["sample_chunk"] == one["config"]["sample_chunk"]
+    assert many["scaling"] == "strong" and many["value"] > 0

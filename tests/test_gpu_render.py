@@ -90,21 +90,21 @@ def test_work_counters_match_oracle_ordered_traversal():
     roofline line can be computed on either side."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 48, 32, 4)
     img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    ref, ost = osc.render(ocam, 4, traversal=2)  # the walk over the folded four-slot records
+    ref, ost = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)  # the kernel's walk on the kernel's records
     assert_same_frame(img, ref)
     for k in ("rays", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "escaped_paths"):
         assert st[k] == ost[k], k
 
 
-def test_traversal_stack_overflow_strip(monkeypatch):
+def test_traversal_stack_overflow_strip():
     """The traversal keeps the first entries of a lane's stack in LDS and the rest in an HBM
     strip (device_path.h LaneStack).  With only two entries in LDS nearly every query uses the
     strip; the frame and the work counters must not change."""
-    monkeypatch.setenv("RAYRS_STACK_LDS", "2")
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 64, 48, 4)
+    scene.set_tuning(stack_lds=2)
     assert scene.info()["wide_depth"] > 8
     img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    ref, ost = osc.render(ocam, 4, traversal=2)
+    ref, ost = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
     assert_same_frame(img, ref)
     for k in ("rays", "interior_visits", "tri_tests", "plane_tests"):
         assert st[k] == ost[k], k
@@ -132,7 +132,7 @@ def test_deep_chain_tree_beyond_lds():
     ref, ost = osc.render(ocam, 4, traversal=0)
     assert_same_frame(img, ref)
     assert st["rays"] == ost["rays"] and st["sphere_tests"] > st["rays"]
-    ref2, ost2 = osc.render(ocam, 4, traversal=2)
+    ref2, ost2 = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
     assert st["interior_visits"] == ost2["interior_visits"] and st["sphere_tests"] == ost2["sphere_tests"]
 
 
@@ -161,14 +161,19 @@ def test_launch_limits_are_reported_not_rendered():
 
 def test_tile_sharding_is_exact():
     """Two 'ranks' rendering interleaved 8x8 tiles into zeroed buffers sum to the
-    single-GPU frame exactly (x + 0): the multi-GPU reduce is order independent."""
-    scene, cam, osc, ocam = both(scenes.material_test, 96, 24, 6)
+    single-GPU frame exactly (x + 0): the multi-GPU reduce is order independent.  The pixels a
+    rank writes are exactly rayrs_amd.tiles.tile_mask(rank) -- on a ragged image too."""
+    from rayrs_amd import tiles
+    scene, cam, osc, ocam = both(scenes.material_test, 93, 21, 6)
     full, st = rayrs_amd.render(scene, cam, 6, out_f64=False)
     parts = []
     rays = 0
     for r in range(3):
-        p, s = rayrs_amd.render(scene, cam, 6, tile_rank=r, tile_ranks=3, out_f64=False)
-        parts.append(p)
+        canvas = np.full((21, 93, 3), -7.0, dtype=np.float32)  # untouched pixels keep the caller's values
+        p, s = rayrs_amd.render(scene, cam, 6, tile_rank=r, tile_ranks=3, out_f64=False, out=canvas)
+        assert np.array_equal((p != -7.0).all(axis=2), tiles.tile_mask(93, 21, r, 3))
+        assert np.array_equal((p != -7.0).any(axis=2), tiles.tile_mask(93, 21, r, 3))
+        parts.append(np.where(p == -7.0, np.float32(0), p))
         rays += s["rays"]
     assert rays == st["rays"]
     # disjoint support
@@ -184,3 +189,50 @@ def test_seed_changes_image_and_same_seed_repeats():
     c, _ = rayrs_amd.render(scene, cam, 4, seed=2, out_f64=True)
     assert np.array_equal(a, b)
     assert not np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_render_multi_on_logical_ranks_equals_the_single_device_frame(n):
+    """rayrs_render_multi (the block loop over several GPUs inside the library): n handles of the same
+    scene, here all on device 0, one host thread and stream each, tiles t % n == rank, the buffers
+    summed -- ranks sharing a device by the accumulate kernel, the distinct devices by one RCCL
+    reduce (a one-rank communicator here).  The frame must equal the single-handle frame bit for bit."""
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 77, 45, 6)
+    full, st = rayrs_amd.render(scene, cam, 6, sample_chunk=4, out_f64=False)
+    clones = [scene] + [scene.clone_to_device(0) for _ in range(n - 1)]
+    img, mst = rayrs_amd.render_multi(clones, cam, 6, sample_chunk=4)
+    assert np.array_equal(img, full)
+    assert mst["rays"] == st["rays"] and mst["paths"] == st["paths"] == 77 * 45 * 6
+    img64, _ = rayrs_amd.render_multi(clones, cam, 6, sample_chunk=4, out_f64=True)
+    ref, _ = osc.render(ocam, 6, sample_chunk=4)
+    assert_same_frame(img64, ref)
+
+
+def test_render_multi_rejects_bad_handles():
+    from rayrs_amd import _ffi
+    scene, cam, osc, ocam = both(scenes.diffuse_single_sphere, 16, 16, 1)
+    with pytest.raises(_ffi.RayrsError) as e:
+        rayrs_amd.render_multi([scene, scene], cam, 1)   # the same handle twice: one render in flight per handle
+    assert e.value.status == -1
+    host_only = rayrs_amd.Scene(scenes.diffuse_single_sphere()[1], 1e-6, 1e6, scenes.SAH_1000, HDRI, device=-1)
+    with pytest.raises(_ffi.RayrsError) as e:
+        rayrs_amd.render_multi([scene, host_only], cam, 1)
+    assert e.value.status == -4
+
+
+def test_glass_on_a_triangle_mesh():
+    """test_scenes.rs:165-168 (glass_suzanne; the asset is not in the repository): a dielectric on
+    triangles -- constant geometric normals, entering/exiting decided by the sign of n.v alone, back
+    faces never culled (geometry.rs:359-379), paths bouncing inside the closed mesh."""
+    glass = lambda: scenes.mesh_scene(3, rayrs_amd.Material.Glass((0.8, 0.8, 0.8), 1.45))
+    scene, cam, osc, ocam = both(glass, 64, 48, 8)
+    img, st = rayrs_amd.render(scene, cam, 8, 50, out_f64=True)
+    ref, ost = osc.render(ocam, 8, 50, traversal=0)
+    assert st["rays"] == ost["rays"] and st["rays"] > 3 * 64 * 48 * 8 // 2  # refraction chains: many queries per path
+    assert_same_frame(img, ref)
+    frosted = lambda: scenes.mesh_scene(3, rayrs_amd.Material.CookTorranceGlass((1, 1, 1), 0.05, 1.45))
+    scene, cam, osc, ocam = both(frosted, 48, 32, 4)
+    img, st = rayrs_amd.render(scene, cam, 4, 50, out_f64=True)
+    ref, ost = osc.render(ocam, 4, 50, traversal=0)
+    assert st["rays"] == ost["rays"]
+    assert_same_frame(img, ref)

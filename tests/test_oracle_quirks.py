@@ -6,6 +6,7 @@ import math
 import numpy as np
 
 import _oracle
+import rayrs_amd
 from rayrs_amd import procedural
 from rayrs_amd.api import Axis, BvhHeuristic, Emission, Fresnel, Material, Object
 
@@ -197,7 +198,9 @@ def test_folded_walk_equals_reference_on_degenerate_rays():
     d[(d == 0).all(axis=1)] = (1.0, 0.0, 0.0)
     d[::7, 1] = -0.0  # negative zero: 1/-0 = -inf
     for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
-        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, procedural.make_hdri(32, 16))
+        hdri = procedural.make_hdri(32, 16)
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, hdri)
+        osc.use_walk_tree(rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=-1))  # the product's tree, host only
         t0, obj0 = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
         assert (obj0 >= 0).sum() > 500
         for trav in (1, 2):

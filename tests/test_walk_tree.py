@@ -1,0 +1,117 @@
+"""The tree the kernels walk (rayrs_amd/csrc/scene_host.cpp build_walk_tree) returns the
+reference's hits.  CPU only: the product builds the tree host-side (device = -1), the oracle walks
+it with the kernel's rules (traversal 2: nearest slot first, boxes beyond the closest hit culled)
+and is compared with its restatement of the reference's recursion (traversal 0, bvh.rs:391-415),
+bit for bit, on the cases where a different topology could show: degenerate rays, unhittable flat
+boxes, direct leaves, coincident and abutting primitives (equal-t ties, bvh.rs:62)."""
+import numpy as np
+import pytest
+
+import _oracle
+import rayrs_amd
+from rayrs_amd import procedural, scenes
+from rayrs_amd.api import Axis, BvhHeuristic, Emission, Material, Object
+
+HDRI = procedural.make_hdri(32, 16)
+NR, DARK = Material.NoReflect(), Emission.Dark()
+
+
+def both_walks(objs, heur, o, d, t0=1e-6, t1=1e6):
+    prod = rayrs_amd.Scene(objs, t0, t1, heur, HDRI, device=-1)
+    osc = _oracle.OracleScene(objs, t0, t1, heur, HDRI).use_walk_tree(prod)
+    rt, robj = osc.intersect_many(o, d, t0, t1, traversal=0)
+    wt, wobj = osc.intersect_many(o, d, t0, t1, traversal=2)
+    assert np.array_equal(wobj, robj)
+    assert np.array_equal(wt.view(np.uint64), rt.view(np.uint64))
+    return robj
+
+
+def random_rays(n, seed, spread=6.0):
+    r = np.random.default_rng(seed)
+    o = r.uniform(-spread, spread, (n, 3))
+    d = r.normal(size=(n, 3))
+    return o, d
+
+
+def test_box_geom_coincident_faces():
+    """Object::box_geom puts BOTH Y faces at lower_left.y (lib.rs:486-505): two rectangles in the same
+    plane, every ray through them gets two equal t.  The first in depth-first order must win."""
+    objs = Object.box_geom((-1.0, 0.5, -1.0), (1.0, 2.0, 1.0), NR, DARK)
+    objs += Object.box_geom((1.0, 0.5, -1.0), (3.0, 2.0, 1.0), NR, DARK)  # abutting box: shared X face
+    objs.append(Object.plane(Axis.Y, -25.0, 25.0, -25.0, 25.0, 0.5, NR, DARK))  # floor in the same plane again
+    o, d = random_rays(3000, 5, 4.0)
+    o[:1000, 1] = np.abs(o[:1000, 1]) + 2.5
+    d[:1000] = (0.0, -1.0, 0.0)
+    d[:500, 0] = np.random.default_rng(6).uniform(-0.3, 0.3, 500)
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Sah(3), BvhHeuristic.Midpoint):
+        hit = both_walks(objs, heur, o, d)
+        assert (hit >= 0).sum() > 150
+
+
+def test_mesh_resting_on_the_floor_and_duplicated():
+    """Triangles lying in the floor's plane, and the same mesh twice (every hit is an exact tie)."""
+    verts, idx = procedural.blob_mesh(2)
+    v = verts.astype(np.float64)
+    v[:, 1] = np.maximum(v[:, 1] - v[:, 1].min(), 0.0)  # lowest vertices in the plane y = 0
+    flat = v.copy()
+    flat[:, 1] = 0.0                                    # a copy squashed into the floor's plane
+    objs = [Object.plane(Axis.Y, -25.0, 25.0, -25.0, 25.0, 0.0, NR, DARK)]
+    objs += Object.from_triangles(v, idx, NR, DARK)
+    objs += Object.from_triangles(v, idx, NR, DARK)
+    objs += Object.from_triangles(flat, idx, NR, DARK)
+    o, d = random_rays(3000, 9, 3.0)
+    o[:, 1] = np.abs(o[:, 1]) + 0.1
+    d[:, 1] = -np.abs(d[:, 1])
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
+        hit = both_walks(objs, heur, o, d)
+        assert (hit >= 0).sum() > 300
+
+
+def test_unhittable_flat_boxes_stay_unhittable():
+    """A bottom Node of coplanar axis-aligned rectangles has a zero-thickness box, which the slab test
+    never passes (tmax <= tmin, geometry.rs:458-513): the reference cannot hit those rectangles, and
+    neither may the walk tree, whose interior boxes around them are not flat."""
+    objs = [Object.plane(Axis.Y, float(i), float(i) + 0.9, 0.0, 1.0, 0.0, NR, DARK) for i in range(4)]
+    objs += [Object.sphere(0.4, (float(i), 2.0, 0.5), NR, DARK) for i in range(6)]
+    o = np.array([[0.5 + i * 0.01, 5.0, 0.5] for i in range(300)])
+    d = np.tile(np.array([0.0, -1.0, 0.0]), (300, 1))
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
+        prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+        osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI).use_walk_tree(prod)
+        rt, robj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
+        wt, wobj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=2)
+        assert np.array_equal(wobj, robj) and np.array_equal(wt.view(np.uint64), rt.view(np.uint64))
+
+
+@pytest.mark.parametrize("level", [3, 5])
+def test_mesh_scene_frames_and_counters(level):
+    """Whole frames through both walks; the walk tree must also be the cheaper one."""
+    cam_args, objs, heur = scenes.mesh_scene(level, area_light=True)
+    cam_args = scenes.camera_for_resolution(cam_args, 48, 32)
+    prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI).use_walk_tree(prod)
+    ocam = _oracle.OracleCamera(*cam_args)
+    ref, rs = osc.render(ocam, 4, 50, traversal=0)
+    bin_, bs = osc.render(ocam, 4, 50, traversal=1)   # ordered walk of the reference's own two-child records
+    walk, ws = osc.render(ocam, 4, 50, traversal=2)
+    assert np.array_equal(ref.view(np.uint64), walk.view(np.uint64)) and rs["rays"] == ws["rays"]
+    assert np.array_equal(ref.view(np.uint64), bin_.view(np.uint64))
+    assert ws["interior_visits"] * 2 < bs["interior_visits"]  # four-slot records of a better tree: fewer visits
+
+
+def test_deep_reference_tree_gives_a_shallow_walk_tree():
+    """250 levels of two spheres each in the reference's tree (tests/test_gpu_render.py's chain);
+    the walk tree over the same groups is built by surface area, not by the reference's splits."""
+    objs = []
+    for k in range(250):
+        x = 1.5 ** k
+        for j in range(2):
+            objs.append(Object.sphere(0.25 * x if k > 3 else 0.2, (x * (1 + 0.01 * j), 1.0, 0.0), NR, DARK))
+    prod = rayrs_amd.Scene(objs, 1e-6, 1e60, BvhHeuristic.Midpoint, HDRI, device=-1)
+    info = prod.info()
+    assert info["depth"] > 100
+    r = np.random.default_rng(3)
+    o = np.tile(np.array([-3.0, 1.5, 4.0]), (500, 1))
+    d = np.stack([np.abs(r.normal(size=500)) + 0.2, r.normal(size=500) * 0.05, -np.abs(r.normal(size=500)) * 0.3], 1)
+    hit = both_walks(objs, BvhHeuristic.Midpoint, o, d, 1e-6, 1e60)
+    assert (hit >= 0).sum() > 100
