@@ -115,6 +115,39 @@ static inline double pow5(double x) {
     return x * (x2 * x2);
 }
 
+/* The helpers above through one exported entry point, for the reference's own vector tests
+ * (vecmath.rs:812-893, doc tests :339 and geometry.rs:672) re-expressed in
+ * tests/test_oracle_reference_tests.py.  op: 0 a+b  1 a-b  2 a*b (componentwise)  3 a*s  4 cross(a,b)
+ * 5 powf(a, s) (f64::powf is the platform pow, vecmath.rs:368-376)  6 clip(a, s, t) = min(max).max(min),
+ * :389-397  7 unit(a)  8 a / s (Div<f64>: multiply by the reciprocal, :690-698)
+ * 9 a /= s (DivAssign<f64>: true division, :708-714).  Scalars: orc_vec_scalar, op 0 dot(a,b)  1 mag2(a). */
+void orc_vec_op(int op, const double a[3], const double b[3], double s, double t, double out[3]) {
+    v3 x = v_from(a), y = b ? v_from(b) : V(0, 0, 0), r = V(0, 0, 0);
+    switch (op) {
+        case 0: r = v_add(x, y); break;
+        case 1: r = v_sub(x, y); break;
+        case 2: r = v_mul(x, y); break;
+        case 3: r = v_scale(x, s); break;
+        case 4: r = v_cross(x, y); break;
+        case 5: r = V(pow(x.x, s), pow(x.y, s), pow(x.z, s)); break;
+        case 6: r = V(rr_max(rr_min(x.x, t), s), rr_max(rr_min(x.y, t), s), rr_max(rr_min(x.z, t), s)); break;
+        case 7: r = v_unit(x); break;
+        case 8: r = v_div(x, s); break;
+        case 9: r = v_div_assign(x, s); break;
+        default: break;
+    }
+    v_to(r, out);
+}
+double orc_vec_scalar(int op, const double a[3], const double b[3]) {
+    return op == 0 ? v_dot(v_from(a), v_from(b)) : v_mag2(v_from(a));
+}
+void orc_orthonormal_basis(const double n[3], double e1[3], double e2[3]) { /* vecmath.rs:341-352 */
+    v3 a, b;
+    v_onb(v_from(n), &a, &b);
+    v_to(a, e1);
+    v_to(b, e2);
+}
+
 /* ------------------------------------------------------ RNG draw stream */
 
 typedef struct {
@@ -394,6 +427,11 @@ static inline aabb_t aabb_expand(aabb_t a, aabb_t o) {
     r.zmin = rr_min(a.zmin, o.zmin);
     r.zmax = rr_max(a.zmax, o.zmax);
     return r;
+}
+void orc_aabb_expand(const double a[6], const double b[6], double out[6]) {
+    aabb_t x = {a[0], a[1], a[2], a[3], a[4], a[5]}, y = {b[0], b[1], b[2], b[3], b[4], b[5]};
+    aabb_t r = aabb_expand(x, y);
+    out[0] = r.xmin, out[1] = r.xmax, out[2] = r.ymin, out[3] = r.ymax, out[4] = r.zmin, out[5] = r.zmax;
 }
 /* center, geometry.rs:577-582 */
 static inline v3 aabb_center(aabb_t b) {

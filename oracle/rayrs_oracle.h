@@ -135,6 +135,13 @@ int orc_render(const orc_scene* s, const orc_camera* c, uint32_t spp, uint32_t m
 double orc_math(int fn, double x, double y); /* 0 sin 1 cos 2 tan 3 log 4 exp 5 acos 6 atan2(x=y_arg,y=x_arg) 7 sqrt */
 uint64_t orc_rng_bits(uint64_t seed, uint64_t pixel, uint64_t sample, uint32_t draw);
 
+/* vecmath.rs helpers (see rayrs_oracle.c for the op codes) */
+void orc_vec_op(int op, const double a[3], const double b[3], double s, double t, double out[3]);
+double orc_vec_scalar(int op, const double a[3], const double b[3]);
+void orc_orthonormal_basis(const double n[3], double e1[3], double e2[3]);
+/* AxisAlignedBoundingBox::expand (geometry.rs:674-683) of two boxes */
+void orc_aabb_expand(const double a[6], const double b[6], double out[6]);
+
 int orc_aabb_intersect(const double box[6] /* xmin,xmax,ymin,ymax,zmin,zmax */, const double o[3], const double d[3],
                        double tmin, double tmax);
 /* returns 1 and *t if Some(t) */

@@ -92,6 +92,14 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
+    L.orc_vec_op.restype = None
+    L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
+    L.orc_vec_scalar.restype = C.c_double
+    L.orc_orthonormal_basis.argtypes = [dp, dp, dp]
+    L.orc_orthonormal_basis.restype = None
+    L.orc_aabb_expand.argtypes = [dp, dp, dp]
+    L.orc_aabb_expand.restype = None
     L.orc_set_math_mode.argtypes = [C.c_int]
     L.orc_set_math_mode.restype = None
     _lib = L
@@ -304,3 +312,33 @@ def math_fn(fn, x, y=None):
 
 def rng_bits(seed, pixel, sample, draw):
     return lib().orc_rng_bits(int(seed), int(pixel), int(sample), int(draw))
+
+
+VEC_OPS = {"add": 0, "sub": 1, "mul": 2, "scale": 3, "cross": 4, "powf": 5, "clip": 6, "unit": 7, "div": 8,
+           "div_assign": 9}
+
+
+def vec_op(name, a, b=(0.0, 0.0, 0.0), s=0.0, t=0.0):
+    out = (C.c_double * 3)()
+    lib().orc_vec_op(VEC_OPS[name], d3(a), d3(b), float(s), float(t), out)
+    return tuple(out)
+
+
+def vec_dot(a, b):
+    return lib().orc_vec_scalar(0, d3(a), d3(b))
+
+
+def vec_mag2(a):
+    return lib().orc_vec_scalar(1, d3(a), d3(a))
+
+
+def orthonormal_basis(n):
+    e1, e2 = (C.c_double * 3)(), (C.c_double * 3)()
+    lib().orc_orthonormal_basis(d3(n), e1, e2)
+    return tuple(e1), tuple(e2)
+
+
+def aabb_expand(a, b):
+    out = (C.c_double * 6)()
+    lib().orc_aabb_expand((C.c_double * 6)(*a), (C.c_double * 6)(*b), out)
+    return list(out)

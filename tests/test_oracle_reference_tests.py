@@ -176,3 +176,69 @@ def test_triangle_normal_matches_disabled_bvh_test_debug_string():
     n = (C.c_double * 3)()
     L.orc_triangle_normal(_oracle.d3((-1., -1., -0.5)), _oracle.d3((-0.5, -1., -1.)), _oracle.d3((1., 1., -1.5)), n)
     assert list(n) == [0.6666666666666666, -0.3333333333333333, 0.6666666666666666]
+
+
+# ---- vecmath.rs:812-893: the reference's eleven vector tests, same operands, same `==`
+
+def test_vec_add():  # :817-822
+    assert _oracle.vec_op("add", (1., 2., 3.), (2., 4., 6.)) == (3., 6., 9.)
+
+
+def test_vec_sub():  # :825-830
+    assert _oracle.vec_op("sub", (4., 3., 2.), (1., 1., 1.)) == (3., 2., 1.)
+
+
+def test_vec_mul():  # :833-838
+    assert _oracle.vec_op("mul", (1., 4., 8.), (2., 2., 2.)) == (2., 8., 16.)
+
+
+def test_vec_scalar_mul_both_orders():  # :841-853 (3. * v and v * 3.: one implementation, vecmath.rs:620-650)
+    assert _oracle.vec_op("scale", (1., 2., 3.), s=3.) == (3., 6., 9.)
+
+
+def test_vec_dot():  # :856-859
+    assert _oracle.vec_dot((1., 2., 3.), (1., 2., 3.)) == 14.
+
+
+def test_vec_cross1():  # :862-867
+    assert _oracle.vec_op("cross", (1., 0., 0.), (0., 1., 0.)) == (0., 0., 1.)
+
+
+def test_vec_cross2():  # :870-875
+    assert _oracle.vec_op("cross", (1., 0., 0.), (0., 0., 1.)) == (0., -1., 0.)
+
+
+def test_vec_mag2():  # :878-881
+    assert _oracle.vec_mag2((1., 2., 3.)) == 14.
+
+
+def test_vec_pow():  # :884-887
+    assert _oracle.vec_op("powf", (1., 2., 3.), s=2.) == (1., 4., 9.)
+
+
+def test_vec_clip():  # :890-893
+    assert _oracle.vec_op("clip", (-1., 2., 0.5), s=0., t=1.) == (0., 1., 0.5)
+
+
+def test_div_multiplies_by_the_reciprocal_but_div_assign_divides():  # vecmath.rs:690-714
+    a = (1., 7., 49.)
+    assert _oracle.vec_op("div", a, s=49.) == tuple(x * (1. / 49.) for x in a)
+    assert _oracle.vec_op("div_assign", a, s=49.) == tuple(x / 49. for x in a)
+    assert _oracle.vec_op("div", a, s=49.) != _oracle.vec_op("div_assign", a, s=49.)  # 49 * (1/49) != 1
+
+
+def test_orthonormal_basis_doc_test():  # vecmath.rs:333-339: x.cross(y) == z for z = unit_z
+    z = (0., 0., 1.)
+    x, y = _oracle.orthonormal_basis(z)
+    assert _oracle.vec_op("cross", x, y) == z
+    for n in ((1., 0., 0.), (0., 1., 0.), (0., -1., 0.)):   # both branches of :343-347
+        e1, e2 = _oracle.orthonormal_basis(n)
+        assert abs(_oracle.vec_dot(e1, n)) < 1e-15 and abs(_oracle.vec_dot(e2, n)) < 1e-15
+        assert max(abs(a - b) for a, b in zip(_oracle.vec_op("cross", e1, e2), n)) < 1e-15
+
+
+def test_aabb_expand_equals_from_object_list_doc_test():  # geometry.rs:655-673
+    objs = [Object.sphere(1., (-1., 0., 0.), NOREFLECT, DARK), Object.sphere(1., (1., 0., 0.), NOREFLECT, DARK)]
+    boxes = [_oracle.OracleScene([o], 1e-6, 1e6, BvhHeuristic.Midpoint, HDRI).bbox()[0] for o in objs]
+    both = _oracle.OracleScene(objs, 1e-6, 1e6, BvhHeuristic.Midpoint, HDRI).bbox()[0]
+    assert _oracle.aabb_expand(boxes[0], boxes[1]) == both == [-2., 2., -1., 1., -1., 1.]
