@@ -12,14 +12,21 @@ rank t % N), the scene is replicated, total work is fixed: strong scaling.
 upload and file I/O excluded -- the region the reference times, main.rs:59-100).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline     -- algorithmic bytes of the traversal kernel per launch (from the
-                  kernel's own counters on the flattened layout) / its average
-                  HIP-event duration, against the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed
-                  traversal over a pointer tree, rayrs-lib's algorithm) timed on
-                  this box's host cores on a bounded band of the same frame.
+  roofline     -- the dominant kernel (wf_trav_kernel) against the ceiling that binds it, FP64 vector
+                  issue: useful f64 lane-operations per launch (the kernel's own work counters x the
+                  operation model below) / its HIP-event duration / (256 CU x 4 SIMD x 16 lanes x
+                  2.4 GHz).  Beside it: algorithmic bytes and, from the PMC passes of
+                  scripts/profile_round.sh when they were taken on THIS source tree, fabric traffic and
+                  VALU occupancy;
+  ray_shares   -- what the frame's BVH queries hit (floor / mesh / nothing ...);
+  cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed traversal over a pointer
+                  tree, rayrs-lib's algorithm) timed on this box's host cores on a bounded band of the
+                  same frame;
+  secondary    -- (headline config, N = 1) the same scene from a camera the mesh fills.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +38,29 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# FP64 vector peak in lane-operations: 256 CUs x 4 SIMDs x 16 f64 lanes per clock x 2.4 GHz (the guide's
+# chip table; MI355X's 78.6 TFLOP/s datasheet figure is this x 2 for fused multiply-adds, which the
+# reference's arithmetic -- compiled without contraction on both sides -- never uses).
+F64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+
+# f64-rate vector instructions one lane needs per unit of traversal work, counted in the kernel source
+# (rayrs_amd/csrc/device_path.h) at full lane utilisation; DESIGN.md section 5 derives each number.
+# Everything else the kernel issues -- idle lanes of a partly filled wave, ballots, refills, address and
+# stack arithmetic, 32-bit selects -- is overhead against this.
+OPS_RECORD_COMPACT = 111   # 4 slots x (6 cvt + 6 sub + 6 mul + 6 min/max) + 4 + 4 compares + 1 mul (cull) + 6 (rank)
+OPS_RECORD_F64 = 87        # the same without the 24 f32 -> f64 conversions
+OPS_TRIANGLE_COMPACT = 98  # 9 cvt + 9 sub + 2 cross (18) + 4 dot (20) + 3 div x 11 + 1 add + 8 compares
+OPS_TRIANGLE_F64 = 89
+OPS_SPHERE = 66            # geometry.rs:106-132: 3 sub, 3 dot, sqrt (10), 2 div x 11, 12 others
+OPS_PLANE = 26             # geometry.rs:229-271: 1 div x 11, 1 sub, 3 mul, 3 add, 8 compares
+OPS_RAY = 54               # 1/d (3 div x 11) + the root box test (21)
+
+
+def useful_f64_ops(stats, info):
+    rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
+    tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
+    return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
+            + stats["plane_tests"] * OPS_PLANE + stats["rays"] * OPS_RAY)
 
 
 def algorithmic_bytes(stats, info):
@@ -41,6 +71,37 @@ def algorithmic_bytes(stats, info):
     return (stats["interior_visits"] * info["node_bytes"]
             + (stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"]) * info["prim_bytes"]
             + stats["rays"] * (48 + 12 + 2))
+
+
+def source_hash():
+    """sha256 over the sources the library is built from: PMC profiles are only valid for the tree they
+    were collected on (scripts/profile_round.sh stamps them with this)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "rayrs_amd", "csrc", "*.hip"))
+                   + glob.glob(os.path.join(ROOT, "rayrs_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "rayrs_amd", "csrc", "*.hpp"))
+                   + glob.glob(os.path.join(ROOT, "rayrs_amd", "csrc", "*.cpp"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        if f.endswith("rayrs_cli.cpp"):
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def find_pmc_profile(workload_key):
+    """The newest profiles/*_pmc.json taken on this source tree for this workload, or None."""
+    want = source_hash()
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if j.get("source_hash") == want and j.get("workload_key") == workload_key:
+            best = (os.path.relpath(path, ROOT), j)
+    return best
 
 
 def effective_cores():
@@ -55,6 +116,26 @@ def effective_cores():
     return n
 
 
+def surface_names(config, n_surfaces):
+    """Names of the (Material, Emission) rows in insertion order, from rayrs_amd/scenes.py's construction."""
+    if config in (3, 5):
+        names = ["floor", "mesh", "light"]
+    else:
+        names = ["floor"] + [f"sphere{i}" for i in range(7)]
+    return names[:n_surfaces] if n_surfaces <= len(names) else names + ["other"] * (n_surfaces - len(names))
+
+
+def ray_shares(cst, config, n_surfaces):
+    names = surface_names(config, min(n_surfaces, 8))
+    rays = max(cst["rays"], 1)
+    out = {}
+    for k, name in enumerate(names):
+        key = name if not name.startswith("sphere") else "spheres"
+        out[key] = out.get(key, 0.0) + cst["surface_hits"][k] / rays
+    out["nothing"] = (cst["rays"] - sum(cst["surface_hits"])) / rays
+    return {k: round(v, 4) for k, v in out.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,11 +144,14 @@ def main():
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json configs[n-1]; 5 is the headline")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only)")
     ap.add_argument("--res", type=int, default=0, help="override resolution (development only)")
+    ap.add_argument("--camera", default="reference", choices=["reference", "close"],
+                    help="'close' = the mesh-filling camera of the secondary line (mesh configs only)")
     ap.add_argument("--sample-chunk", type=int, default=4,
                     help="smallest sample chunk to use (the library doubles it until the whole frame has at most "
                          "2^30 items); small chunks keep the end of a frame, and of a tile share, short")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
                     "rehearsing the N>1 path on a box with fewer GPUs than ranks")
@@ -116,122 +200,155 @@ def main():
     reduced = False
     if args.spp:
         spp, reduced = args.spp, True
+    W0 = H0 = {1: 256, 2: 1024, 3: 1024, 4: 2048, 5: 2048}[args.config]
     if args.res:
-        cam_args, reduced = scenes.camera_for_resolution(cam_args, args.res, args.res), True
+        W0 = H0 = args.res
+        reduced = True
+    if args.camera == "close":
+        if args.config not in (3, 5):
+            raise SystemExit("--camera close is for the mesh configurations (3, 5)")
+        cam_args = scenes.MESH_CLOSE_CAM
+    cam_args = scenes.camera_for_resolution(cam_args, W0, H0)
     hdri = procedural.make_hdri(1024, 512)
     t0 = time.time()
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=local_rank)
     build_s = time.time() - t0
-    cam = rayrs_amd.Camera(*cam_args)
     info = scene.info()
-    H, W = cam.y_pixels(), cam.x_pixels()
-
-    # a pixel's samples are summed in chunks; the chunk comes from the WHOLE frame (rayrs_frame_sample_chunk:
-    # at most 2^30 (pixel, chunk) items), never from the rank count, so every N renders the same bits
-    args.sample_chunk = rayrs_amd.frame_sample_chunk(W, H, spp, args.sample_chunk)
-
     dev = torch.device("cuda", local_rank)
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    params = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=args.sample_chunk, tile_rank=rank,
-                                   tile_ranks=world)
 
-    def step():
-        fb.zero_()
-        rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
-        if use_dist and args.backend == "nccl":
-            tiles.reduce_framebuffer(fb, dst=0)       # RCCL over xGMI, ordered after the render on this stream
-        st = rayrs_amd.render_finish(scene)
-        if use_dist and args.backend != "nccl":       # rehearsal: reduce through host memory
-            host = fb.cpu()
-            tiles.reduce_framebuffer(host, dst=0)
-            fb.copy_(host)
-        return st
+    def workload_key(W, H, chunk, camera=None):
+        return f"config{args.config}_{camera or args.camera}_{W}x{H}_{spp}spp_chunk{chunk}_world{world}"
 
-    def fence():
+    def measure(cam_args, steps, warmup, want_roofline):
+        """Times `steps` frames from this camera; returns the pieces of the JSON line."""
+        cam = rayrs_amd.Camera(*cam_args)
+        H, W = cam.y_pixels(), cam.x_pixels()
+        # a pixel's samples are summed in chunks; the chunk comes from the WHOLE frame (rayrs_frame_sample_chunk:
+        # at most 2^30 (pixel, chunk) items), never from the rank count, so every N renders the same bits
+        chunk = rayrs_amd.frame_sample_chunk(W, H, spp, args.sample_chunk)
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        params = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
+                                       tile_ranks=world)
+
+        def step():
+            fb.zero_()
+            rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
+            if use_dist and args.backend == "nccl":
+                tiles.reduce_framebuffer(fb, dst=0)       # RCCL over xGMI, ordered after the render on this stream
+            st = rayrs_amd.render_finish(scene)
+            if use_dist and args.backend != "nccl":       # rehearsal: reduce through host memory
+                host = fb.cpu()
+                tiles.reduce_framebuffer(host, dst=0)
+                fb.copy_(host)
+            return st
+
+        def fence():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        st = None
+        for _ in range(warmup):
+            st = step()
+        fence()
+        t_begin = time.perf_counter()
+        rays = 0
+        kernel_ms = []
+        for _ in range(steps):
+            st = step()
+            rays += st["rays"]
+            kernel_ms.append(st["kernel_ms"])
+        fence()
+        elapsed = time.perf_counter() - t_begin
+
+        tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            r = tot[:1].clone()
+            e = tot[1:].clone()
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            total_rays, max_elapsed = float(r.item()), float(e.item())
+        else:
+            total_rays, max_elapsed = float(rays), elapsed
+        checksum, fb_sha = 0.0, None
+        if rank == 0:  # the assembled frame: identical bits for every rank count (tests/test_gpu_multi_process.py)
+            checksum = float(fb.double().sum().item())
+            fb_sha = hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t_begin = time.perf_counter()
-    rays = 0
-    kernel_ms = []
-    for _ in range(args.steps):
-        st = step()
-        rays += st["rays"]
-        kernel_ms.append(st["kernel_ms"])
-    fence()
-    elapsed = time.perf_counter() - t_begin
+        roofline, shares = None, None
+        if want_roofline:
+            # same launch once more with the work counters compiled in (untimed): the work of a launch is a
+            # pure function of (scene, seed), so the counts apply to the timed launches exactly
+            pc = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
+                                       tile_ranks=world, count_work=True)
+            fb2 = torch.zeros_like(fb)
+            rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
+            cst = rayrs_amd.render_finish(scene)
+            assert cst["rays"] == st["rays"], "counting launch traced a different frame"
+            shares = ray_shares(cst, args.config, info["n_surfaces"])
+            launches = st["kernel_launches"]                          # traversal launches = path rounds
+            step_ms = max_elapsed / steps * 1e3
+            trav_ms = sum(kernel_ms) / len(kernel_ms)                 # per step, HIP events on the render stream
+            avg_ms = trav_ms / launches
+            ops = useful_f64_ops(cst, info)
+            achieved = ops / (trav_ms * 1e-3) / 1e12
+            abytes = algorithmic_bytes(cst, info)
+            prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
+            pmc = find_pmc_profile(workload_key(W, H, chunk))
+            traffic = fabric_gbs = valu_busy = valu_per_ray = pmc_src = None
+            if pmc is not None:
+                pmc_src, pj = pmc
+                k = pj["kernels"].get("wf_trav_kernel")
+                if k and k["launches"] == launches:
+                    traffic = int(k["fabric_bytes"] / launches)
+                    fabric_gbs = round(k["fabric_bytes"] / (trav_ms * 1e-3) / 1e9, 1)
+                    valu_busy = k.get("valu_busy")
+                    valu_per_ray = round(k["valu_wave_instructions"] / max(cst["rays"], 1), 2)
+            roofline = {
+                "bound": "fp64_valu", "achieved": round(achieved, 3), "peak": round(F64_PEAK_TOPS, 2),
+                "unit": "TFLOP/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
+                "kernel": "wf_trav_kernel", "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
+                "kernel_share_of_step": round(trav_ms / step_ms, 3),
+                "definition": "useful f64 lane-operations of the traversal kernel (its own record / primitive / ray "
+                              "counters x the per-unit operation counts of bench.py) / its HIP-event time / "
+                              "(256 CU x 4 SIMD x 16 lanes x 2.4 GHz); no FMA: the reference's arithmetic is unfused",
+                "useful_f64_ops_per_launch": int(ops / launches), "useful_f64_ops_per_ray": round(ops / max(cst["rays"], 1), 1),
+                "records_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
+                "prim_tests_per_ray": round(prims / max(cst["rays"], 1), 2),
+                "lane_utilisation": {"interior": round(cst["step_lane"] / max(cst["step_wave"], 1), 3),
+                                     "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)},
+                # SURVEY.md 8(d)'s figure: record fetches of an incoherent walk over a 97 MB scene, served by
+                # LDS / L1 / L2 / Infinity Cache -- it can exceed the HBM peak and bounds nothing; kept for comparison
+                "algorithmic_bytes_per_launch": int(abytes / launches),
+                "algorithmic_bytes_per_ray": round(abytes / max(cst["rays"], 1), 1),
+                "algorithmic_GBps": round(abytes / (trav_ms * 1e-3) / 1e9, 1),
+                # from the PMC passes of scripts/profile_round.sh, only when taken on this very source tree and
+                # workload: bytes between L2 and the fabric (32 B x TCC_EA0_RDREQ_DRAM_32B + WRREQ_WRITE_DRAM_32B,
+                # Infinity-Cache hits included; calibrated exact on 64/128/192-byte records, profiles/) and the
+                # share of SIMD cycles with a vector instruction issued (SQ_INSTS_VALU x 4 cycles)
+                "fabric_GBps": fabric_gbs,
+                "fabric_frac_of_hbm_peak": None if fabric_gbs is None else round(fabric_gbs / HBM_PEAK_GBS, 4),
+                "fp64_valu_busy": valu_busy, "valu_wave_instructions_per_ray": valu_per_ray, "pmc_source": pmc_src,
+            }
+        return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6,
+                "ms_per_step": max_elapsed / steps * 1e3, "rays_per_step": int(total_rays / steps),
+                "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares}
 
-    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if use_dist:
-        r = tot[:1].clone()
-        e = tot[1:].clone()
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        total_rays, max_elapsed = float(r.item()), float(e.item())
-    else:
-        total_rays, max_elapsed = float(rays), elapsed
-    checksum, fb_sha = 0.0, None
-    if rank == 0:  # the assembled frame: identical bits for every rank count (tests/test_gpu_multi_process.py)
-        import hashlib
-        checksum = float(fb.double().sum().item())
-        fb_sha = hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest()
+    main_run = measure(cam_args, args.steps, args.warmup, not args.no_roofline)
+    W, H, chunk = main_run["W"], main_run["H"], main_run["chunk"]
 
-    roofline = None
-    if not args.no_roofline:
-        # same launch once more with the traversal counters compiled in (untimed):
-        # the work of a launch is a pure function of (scene, seed), so the counts
-        # apply to the timed launches exactly
-        pc = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=args.sample_chunk, tile_rank=rank,
-                                   tile_ranks=world, count_work=True)
-        fb2 = torch.zeros_like(fb)
-        rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
-        cst = rayrs_amd.render_finish(scene)
-        assert cst["rays"] == st["rays"], "counting launch traced a different frame"
-        # the dominant kernel is the traversal kernel, launched once per path round
-        launches = st["kernel_launches"]
-        # HBM bytes per launch come from PMC passes of this same command (they cannot be collected
-        # in-process): profiles/r01_final_hbm_traffic.json, valid for the unreduced headline workload only
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-        if os.path.exists(tpath) and not reduced and args.config == 5 and world == 1:
-            tj = json.load(open(tpath))
-            k = tj["kernels"]["wf_trav_kernel"]
-            if k["launches"] == launches and tj.get("sample_chunk") == args.sample_chunk:
-                traffic = k["bytes_per_launch"]
-                traffic_src = "profiles/r01_final_hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, calibrated)"
-        # FP64-VALU occupancy of the same kernel, from a PMC pass of the same command (scripts/valu_pass.sh)
-        valu_busy = None
-        vpath = os.path.join(ROOT, "profiles", "r01_final_valu.json")
-        if traffic is not None and os.path.exists(vpath):
-            vk = json.load(open(vpath))["kernels"]["wf_trav_kernel"]
-            if vk["launches"] == launches:
-                valu_busy = vk["valu_busy"]
-        abytes = algorithmic_bytes(cst, info) / launches          # per launch
-        avg_ms = sum(kernel_ms) / len(kernel_ms) / launches       # per launch, HIP events on the render stream
-        achieved = abytes / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "wf_trav_kernel", "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
-                    "kernel_share_of_step": round(sum(kernel_ms) / len(kernel_ms) / (max_elapsed / args.steps * 1e3), 3),
-                    "algorithmic_bytes_per_launch": int(abytes),
-                    "bytes_per_ray": round(abytes * launches / max(cst["rays"], 1), 1),
-                    "interior_visits_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
-                    "prim_tests_per_ray": round((cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"])
-                                                / max(cst["rays"], 1), 2),
-                    # The algorithmic bytes are record fetches of an incoherent tree walk over a 97 MB scene:
-                    # LDS, L1, L2 and the Infinity Cache serve nearly all of them, which is how `achieved`
-                    # can pass the HBM peak.  What reaches HBM is `traffic`; what the kernel actually
-                    # runs out of is FP64 VALU issue (SURVEY.md 8(d)'s secondary ceiling).
-                    "hbm_achieved": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 2),
-                    "hbm_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "fp64_valu_busy": valu_busy,
-                    "fp64_valu_source": None if valu_busy is None else
-                    "profiles/r01_final_valu.json (rocprofv3 SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the kernel)"}
+    secondary = None
+    if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_secondary
+            and not args.no_roofline):
+        close = scenes.camera_for_resolution(scenes.MESH_CLOSE_CAM, W0, H0)
+        sec = measure(close, 1, 1, True)
+        secondary = {"workload": "the same scene and settings from a camera the mesh fills (scenes.MESH_CLOSE_CAM)",
+                     "value": round(sec["value"], 2), "unit": "Mray/s", "ms_per_step": round(sec["ms_per_step"], 2),
+                     "rays_per_step": sec["rays_per_step"], "ray_shares": sec["shares"],
+                     "records_per_ray": sec["roofline"]["records_per_ray"],
+                     "prim_tests_per_ray": sec["roofline"]["prim_tests_per_ray"],
+                     "roofline_frac": sec["roofline"]["frac"]}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -262,36 +379,48 @@ def main():
                                   f"{cst2['seconds']:.2f} s (oracle BVH build {obuild:.1f} s not timed)"}
 
     if rank == 0:
-        value = total_rays / max_elapsed / 1e6
-        n_tri = info["n_prims"]
+        n_prims = info["n_prims"]
+        what = {1: "floor + 1 diffuse sphere", 2: "floor + 7 Cook-Torrance metallic spheres",
+                3: f"floor + {n_prims - 2}-triangle PLY mesh + area light",
+                4: "floor + 7 Cook-Torrance frosted-glass spheres",
+                5: f"floor + {n_prims - 1}-triangle PLY mesh"}[args.config]
         line = {
-            "metric": "Mray/s (primary+secondary) on 1M-tri scene @1024spp",
-            "value": round(value, 2),
+            "metric": "Mray/s (primary+secondary) on 1M-tri scene @1024spp" if args.config == 5 else
+                      f"Mray/s (primary+secondary), BASELINE.json configs[{args.config - 1}]",
+            "value": round(main_run["value"], 2),
             "unit": "Mray/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(max_elapsed / args.steps * 1e3, 2),
+            "ms_per_step": round(main_run["ms_per_step"], 2),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[{args.config - 1}]: floor + {n_tri - 1 if args.config == 5 else n_tri}-primitive "
-                            f"procedural mesh scene, {W}x{H}, {spp} spp, max {max_bounces} bounces, SAH(1000) BVH, "
-                            f"1024x512 procedural HDRI" + (" [REDUCED: development run]" if reduced else ""),
-                "resolution": [W, H], "spp": spp, "max_bounces": max_bounces, "primitives": n_tri,
-                "sample_chunk": args.sample_chunk, "parallelism": f"8x8 image tiles interleaved over {world} GPU(s), "
-                                                                 f"scene replicated, one RCCL reduce of the f32x3 framebuffer",
+                "workload": f"configs[{args.config - 1}]: {what}, {W}x{H}, {spp} spp, max {max_bounces} bounces, "
+                            f"SAH(1000) BVH, 1024x512 procedural HDRI, "
+                            + ("the reference's obj_scene camera (test_scenes.rs:91-99)" if args.config in (3, 5)
+                               and args.camera == "reference" else f"camera: {args.camera}")
+                            + (" [REDUCED: development run]" if reduced else ""),
+                "resolution": [W, H], "spp": spp, "max_bounces": max_bounces, "primitives": n_prims,
+                "sample_chunk": chunk, "parallelism": f"8x8 image tiles interleaved over {world} GPU(s), "
+                                                      f"scene replicated, one RCCL reduce of the f32x3 framebuffer",
                 "layout": "compact f32 records" if info["compact"] else "f64 records",
-                "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"], "scene_build_s": round(build_s, 2),
+                "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"], "scene_bytes": info["device_bytes"],
+                "scene_build_s": round(build_s, 2), "source_hash": source_hash(),
+                "workload_key": workload_key(W, H, chunk),
             },
-            "rays_per_step": int(total_rays / args.steps),
-            "framebuffer_checksum": checksum,
-            "framebuffer_sha256": fb_sha,
-            "roofline": roofline,
+            "rays_per_step": main_run["rays_per_step"],
+            "framebuffer_checksum": main_run["checksum"],
+            "framebuffer_sha256": main_run["sha"],
+            # what the BVH queries of the frame found: the headline camera is the reference's own framing, from
+            # which most queries end on the floor rectangle, not in the mesh -- see `secondary`
+            "ray_shares": main_run["shares"],
+            "roofline": main_run["roofline"],
             "cpu_baseline": cpu_baseline,
+            "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
 

@@ -225,6 +225,10 @@ typedef struct {
     uint64_t kernel_launches; /* launches of the traversal kernel (= path rounds) */
     double trace_ms;        /* all path rounds (gen + traversal + hit + miss kernels) */
     uint64_t refill_ticks;
+    /* closest hits by surface (count_work only): surface_hits[k] = BVH queries whose closest hit carries
+     * the k-th distinct (Material, Emission) pair in object insertion order, pairs 7 and up together;
+     * rays - sum(surface_hits) = queries that found nothing (Scene::background) */
+    uint64_t surface_hits[8];
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:

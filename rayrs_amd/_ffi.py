@@ -67,10 +67,13 @@ class RenderStats(C.Structure):
                 ("step_wave", C.c_uint64), ("step_lane", C.c_uint64), ("inner_wave", C.c_uint64),
                 ("leaf_wave", C.c_uint64), ("interior_ticks", C.c_uint64), ("leaf_ticks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
-                ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64)]
+                ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
+                ("surface_hits", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["surface_hits"] = list(self.surface_hits)
+        return d
 
 
 class Tuning(C.Structure):

@@ -402,7 +402,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 20);
+    RAYRS_STRUCT(rayrs_render_stats, 21);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -413,6 +413,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, leaf_ticks), RAYRS_FIELD(rayrs_render_stats, kernel_ms);
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
+    RAYRS_FIELD(rayrs_render_stats, surface_hits);
     RAYRS_STRUCT(rayrs_tuning, 7);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
@@ -506,6 +507,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
     rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 24u;
+    rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;
     rp.counters = scene->d_counters;
@@ -679,6 +681,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->step_wave = c.step_wave, stats->step_lane = c.step_lane, stats->inner_wave = c.inner_wave;
         stats->leaf_wave = c.leaf_wave, stats->interior_ticks = c.interior_ticks, stats->leaf_ticks = c.leaf_ticks;
         stats->refill_ticks = c.refill_ticks;
+        for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;

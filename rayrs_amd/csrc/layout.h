@@ -112,6 +112,7 @@ struct Counters {
     // phase by a wave x 64, *_lane the lanes that were active in it
     unsigned long long step_wave, step_lane, inner_wave, leaf_wave;
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
+    unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
 };
 
 struct RenderDev {
@@ -126,7 +127,7 @@ struct RenderDev {
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
-    uint32_t pad1;
+    uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // total_items * 3
     Counters* counters;
     void* out;

@@ -551,6 +551,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             const uint32_t slot = cur.slot;
             const bool valid = cur.valid;
             bool ended = false;
+            uint32_t hit_sid = 8u;
             ItemRegs ir = cur.ir;
             if (valid) {
             RaySlot* rs = &wf.slots[slot].ray;
@@ -570,6 +571,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             const V3 normal = prim_normal<COMPACT>(rec, position);
             const V3 view = v_unit(v_scale(d, -1.0));
             const uint32_t sid = rec.tag() >> 8;
+            hit_sid = sid < 7u ? sid : 7u;
             const SurfaceDev* surf = sid < n_surf_lds ? &s_surf[sid] : sc.surfaces + sid;
             const Scatter ev = material_evaluate(surf, normal, view, rng);
             if (ev.scatter) {
@@ -597,6 +599,13 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 ir.acc[1] += light.y;
                 ir.acc[2] += light.z;
             }
+            }
+            if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    const uint32_t c = (uint32_t)__popcll(__ballot(hit_sid == k));
+                    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
+                }
             }
             next_sample(ended, slot, ir, true, cam, rp, wf, range, n_paths, retired);
         }

@@ -123,6 +123,11 @@ def mesh_scene(level: int, mat=None, area_light: bool = False, ply_path=None):
     return _SINGLE_CAM, objs, SAH_1000
 
 
+# A second framing of the mesh scenes for bench.py's secondary line: the reference's obj_scene camera
+# (test_scenes.rs:91-99, _SINGLE_CAM above) sees mostly floor; from here the mesh fills the frame.
+MESH_CLOSE_CAM = ((0.0, 2.1, 3.3), (0.0, 1.0, 0.0), (0.0, 1.2, 0.0), 40.0, 1920.0 / 500.0, 1920.0 / 500.0, 100)
+
+
 # ---- the benchmark configurations of BASELINE.json
 
 def config(n: int, ply_path=None):
