@@ -279,7 +279,9 @@ typedef struct {
     uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
     uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
                                0xffffffff = none */
-    uint32_t reserved[2];
+    uint32_t pipelines;     /* 1 or 2: halves of the pool on two streams, one's hit/miss kernels beside the
+                               other's traversal kernel (default: see rayrs_render_launch in abi.cpp) */
+    uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
 } rayrs_tuning;
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);

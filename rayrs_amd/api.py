@@ -308,7 +308,7 @@ class Scene:
         never change what is computed."""
         t = _ffi.Tuning()
         for k, v in kw.items():
-            if k not in dict(_ffi.Tuning._fields_) or k == "reserved":
+            if k not in dict(_ffi.Tuning._fields_):
                 raise ValueError(f"unknown tuning field {k}")
             setattr(t, k, int(v))
         _ffi.check(self._L.rayrs_scene_set_tuning(self._h, C.byref(t)), "rayrs_scene_set_tuning")

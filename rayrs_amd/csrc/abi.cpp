@@ -197,16 +197,22 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_partial) (void)hipFree(s->d_partial);
-    if (s->wf_block) (void)hipFree(s->wf_block);
-    if (s->d_wave_items) (void)hipFree(s->d_wave_items);
-    if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
-    if (s->wf.ctl) (void)hipFree(s->wf.ctl);
-    if (s->h_live) (void)hipHostFree(s->h_live);
+    for (auto& pl : s->pipe) {
+        if (pl.block) (void)hipFree(pl.block);
+        if (pl.d_wave_items) (void)hipFree(pl.d_wave_items);
+        if (pl.d_stack_spill) (void)hipFree(pl.d_stack_spill);
+        if (pl.wf.ctl) (void)hipFree(pl.wf.ctl);
+        if (pl.h_live) (void)hipHostFree(pl.h_live);
+        for (auto& e : pl.ev_batch)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : pl.ev_trav)
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (s->d_next_item) (void)hipFree(s->d_next_item);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+    for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_stagger})
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev)
-        if (e) (void)hipEventDestroy(e);
-    for (auto& e : s->ev_batch)
-        if (e) (void)hipEventDestroy(e);
-    for (auto& e : s->ev_trav)
         if (e) (void)hipEventDestroy(e);
 }
 
@@ -259,9 +265,16 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         const int st = scene_configure_traversal(s);
         if (st != RAYRS_OK) return st;
     }
-    HIP_TRY(hipMalloc((void**)&s->wf.ctl, sizeof(WfCtl)));
-    HIP_TRY(hipHostMalloc((void**)&s->h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
-    for (auto& e : s->ev_batch) HIP_TRY(hipEventCreate(&e));
+    for (auto& pl : s->pipe) {
+        HIP_TRY(hipMalloc((void**)&pl.wf.ctl, sizeof(WfCtl)));
+        HIP_TRY(hipHostMalloc((void**)&pl.h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
+        for (auto& e : pl.ev_batch) HIP_TRY(hipEventCreate(&e));
+    }
+    HIP_TRY(hipMalloc((void**)&s->d_next_item, sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_stagger, hipEventDisableTiming));
     return RAYRS_OK;
 }
 
@@ -352,7 +365,8 @@ int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device 
 
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     if (!scene || !tuning) return RAYRS_INVALID_ARG;
-    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u) return RAYRS_INVALID_ARG;
+    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u)
+        return RAYRS_INVALID_ARG;
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
         if (scene->pending && scene->last_stream) {
@@ -414,10 +428,10 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits);
-    RAYRS_STRUCT(rayrs_tuning, 7);
+    RAYRS_STRUCT(rayrs_tuning, 8);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
-    RAYRS_FIELD(rayrs_tuning, reserved);
+    RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -542,104 +556,144 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     }
     if (scene->tuning.pool_slots) np64 = scene->tuning.pool_slots;
     if (np64 > rp.total_items) np64 = rp.total_items;
-    const uint32_t live = (uint32_t)np64;
-    np64 = (np64 + 1023ull) & ~1023ull;  // whole windows
-    const uint32_t np = (uint32_t)np64;
-    if (np > scene->wf.np || !scene->wf_block) {
-        if (scene->wf_block) HIP_TRY(hipFree(scene->wf_block));
-        scene->wf_block = nullptr;
-        scene->wf.np = 0;
-        const size_t bytes = (size_t)np * (sizeof(Slot) + 1);
-        HIP_TRY(hipMalloc(&scene->wf_block, bytes));
-        uint8_t* p = static_cast<uint8_t*>(scene->wf_block);
-        scene->wf.slots = reinterpret_cast<Slot*>(p);
-        p += (size_t)np * sizeof(Slot);
-        scene->wf.state = p;
-        scene->wf.np = np;
-    }
-    WfDev wf = scene->wf;
-    wf.np = np;
+    const uint64_t live_total = np64;
 
+    // ---- one pipeline, or two halves of the pool on two streams (scene_internal.hpp Pipeline).  With two,
+    // the second starts its first traversal when the first pipeline's has finished, and from then on each
+    // runs its rounds at its own pace: while one is in its hit and miss kernels (memory bound, the vector
+    // ALUs mostly idle) the other is in its traversal kernel (ALU bound, a third of the memory traffic).
+    uint32_t n_pipes = scene->tuning.pipelines == 2u ? 2u : 1u;
+    if (live_total < 2ull * 65536ull) n_pipes = 1;
+    scene->n_pipes = n_pipes;
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    const uint32_t trav_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->blocks_per_cu;
-    {
-        // whole round-robin rounds covering about static_pct % of the pool's windows
-        uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
-        if (static_pct > 100) static_pct = 100;
-        const uint64_t n_windows = np / wf_window_slots(), n_waves = (uint64_t)trav_blocks * 4u;
-        rp.static_windows = (uint32_t)(n_windows * static_pct / 100u / n_waves * n_waves);
-    }
-    uint32_t flat_blocks = (np / wf_window_slots() + 3u) / 4u;  // one wave per window
-    const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
-    if (flat_blocks > flat_cap) flat_blocks = flat_cap;
-    // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three
-    wf.n_flat_waves = flat_blocks * 4u;
-    if (wf.n_flat_waves > scene->wave_items_cap) {
-        if (scene->d_wave_items) HIP_TRY(hipFree(scene->d_wave_items));
-        scene->d_wave_items = nullptr;
-        scene->wave_items_cap = 0;
-        HIP_TRY(hipMalloc((void**)&scene->d_wave_items, (size_t)wf.n_flat_waves * 2 * sizeof(unsigned long long)));
-        scene->wave_items_cap = wf.n_flat_waves;
-    }
-    wf.wave_items = scene->d_wave_items;
-    wf.trav_threads = trav_blocks * 256u;
-    {
-        const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
-        const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
-        if (words > scene->stack_spill_words) {
-            if (scene->d_stack_spill) HIP_TRY(hipFree(scene->d_stack_spill));
-            scene->d_stack_spill = nullptr;
-            scene->stack_spill_words = 0;
-            HIP_TRY(hipMalloc((void**)&scene->d_stack_spill, words * sizeof(uint32_t)));
-            scene->stack_spill_words = words;
+    uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
+    if (scene->tuning.trav_blocks_per_cu && scene->tuning.trav_blocks_per_cu < trav_bpc) trav_bpc = scene->tuning.trav_blocks_per_cu;
+    const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
+    uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
+    if (static_pct > 100) static_pct = 100;
+
+    hipStream_t streams[2] = {stream, scene->aux_stream};
+    WfDev wfs[2];
+    RenderDev rps[2];
+    uint32_t lives[2], flat_blocks[2];
+    for (uint32_t p = 0; p < n_pipes; p++) {
+        rayrs_scene::Pipeline& pl = scene->pipe[p];
+        const uint64_t live64 = live_total / n_pipes + (p < live_total % n_pipes ? 1u : 0u);
+        const uint32_t np = (uint32_t)((live64 + 1023ull) & ~1023ull);  // whole windows
+        lives[p] = (uint32_t)live64;
+        if (np > pl.block_slots || !pl.block) {
+            if (pl.block) HIP_TRY(hipFree(pl.block));
+            pl.block = nullptr;
+            pl.block_slots = 0;
+            HIP_TRY(hipMalloc(&pl.block, (size_t)np * (sizeof(Slot) + 1)));
+            uint8_t* b = static_cast<uint8_t*>(pl.block);
+            pl.wf.slots = reinterpret_cast<Slot*>(b);
+            pl.wf.state = b + (size_t)np * sizeof(Slot);
+            pl.block_slots = np;
         }
-        wf.stack_spill = scene->d_stack_spill;
+        WfDev wf = pl.wf;
+        wf.np = np;
+        RenderDev r = rp;
+        {
+            // whole round-robin rounds covering about static_pct % of the pool's windows
+            const uint64_t n_windows = np / wf_window_slots(), n_waves = (uint64_t)trav_blocks * 4u;
+            r.static_windows = (uint32_t)(n_windows * static_pct / 100u / n_waves * n_waves);
+        }
+        uint32_t fb = (np / wf_window_slots() + 3u) / 4u;  // one wave per window
+        const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
+        if (fb > flat_cap) fb = flat_cap;
+        flat_blocks[p] = fb;
+        // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three
+        wf.n_flat_waves = fb * 4u;
+        if (wf.n_flat_waves > pl.wave_items_cap) {
+            if (pl.d_wave_items) HIP_TRY(hipFree(pl.d_wave_items));
+            pl.d_wave_items = nullptr;
+            pl.wave_items_cap = 0;
+            HIP_TRY(hipMalloc((void**)&pl.d_wave_items, (size_t)wf.n_flat_waves * 2 * sizeof(unsigned long long)));
+            pl.wave_items_cap = wf.n_flat_waves;
+        }
+        wf.wave_items = pl.d_wave_items;
+        wf.trav_threads = trav_blocks * 256u;
+        {
+            const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
+            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
+            if (words > pl.stack_spill_words) {
+                if (pl.d_stack_spill) HIP_TRY(hipFree(pl.d_stack_spill));
+                pl.d_stack_spill = nullptr;
+                pl.stack_spill_words = 0;
+                HIP_TRY(hipMalloc((void**)&pl.d_stack_spill, words * sizeof(uint32_t)));
+                pl.stack_spill_words = words;
+            }
+            wf.stack_spill = pl.d_stack_spill;
+        }
+        r.next_item = scene->d_next_item;
+        wfs[p] = wf;
+        rps[p] = r;
+        pl.timed_rounds = 0;
     }
+    rp.next_item = scene->d_next_item;
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
+    HIP_TRY(hipMemsetAsync(scene->d_next_item, 0, sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
     scene->rounds = 0;
-    scene->timed_rounds = 0;
     if (rp.total_items > 0) {
-        HIP_TRY(wf_launch_init(wf, live, stream));
-        HIP_TRY(wf_launch_gen(cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
-        // Rounds are enqueued in batches; the live-slot count of batch b is read
-        // back while batch b+1 is already queued, so the GPU never waits for the host.
-        // Rounds behind the frame's last one find live_slots == 0 and return at once; batches shrink from
-        // 16 rounds to 4 once fewer than an eighth of the slots have work, so that at most 7 such rounds
-        // (about 21 launches of a few microseconds) are queued after the end.
+        if (n_pipes > 1) {  // fork: the second stream starts behind everything queued on the caller's so far
+            HIP_TRY(hipEventRecord(scene->ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(scene->aux_stream, scene->ev_fork, 0));
+        }
+        for (uint32_t p = 0; p < n_pipes; p++) {
+            HIP_TRY(wf_launch_init(wfs[p], lives[p], streams[p]));
+            HIP_TRY(wf_launch_gen(cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
+            scene->pipe[p].h_live[0] = scene->pipe[p].h_live[1] = lives[p];
+        }
+        // Rounds are enqueued in batches; the live-slot counts of batch b are read back while batch b+1 is
+        // already queued, so the GPU never waits for the host.  Rounds behind a pipeline's last one find
+        // live_slots == 0 and return at once; batches shrink from 16 rounds to 4 once fewer than an eighth of
+        // the slots have work, so that at most 7 such rounds are queued after the end.
         constexpr uint32_t MAX_TIMED = 8192;
-        scene->h_live[0] = scene->h_live[1] = live;
         uint32_t it = 0;
         uint32_t batch = 16;
         for (uint32_t b = 0;; b++) {
             for (uint32_t k = 0; k < batch; k++, it++) {
-                const bool timed = it < MAX_TIMED;
-                if (timed) {
-                    while (scene->ev_trav.size() < 2 * (size_t)(it + 1)) {
-                        hipEvent_t e;
-                        HIP_TRY(hipEventCreate(&e));
-                        scene->ev_trav.push_back(e);
+                for (uint32_t p = 0; p < n_pipes; p++) {
+                    rayrs_scene::Pipeline& pl = scene->pipe[p];
+                    hipStream_t st = streams[p];
+                    if (p == 1 && it == 0) HIP_TRY(hipStreamWaitEvent(st, scene->ev_stagger, 0));  // half a round behind
+                    const bool timed = it < MAX_TIMED;
+                    if (timed) {
+                        while (pl.ev_trav.size() < 2 * (size_t)(it + 1)) {
+                            hipEvent_t e;
+                            HIP_TRY(hipEventCreate(&e));
+                            pl.ev_trav.push_back(e);
+                        }
+                        HIP_TRY(hipEventRecord(pl.ev_trav[2 * it], st));
                     }
-                    HIP_TRY(hipEventRecord(scene->ev_trav[2 * it], stream));
+                    HIP_TRY(wf_launch_trav(compact, count, sc, rps[p], wfs[p], trav_blocks, st));
+                    if (timed) {
+                        HIP_TRY(hipEventRecord(pl.ev_trav[2 * it + 1], st));
+                        pl.timed_rounds = it + 1;
+                    }
+                    if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
+                    HIP_TRY(wf_launch_hit(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    HIP_TRY(wf_launch_miss(sc, cam, rps[p], wfs[p], flat_blocks[p], st));
                 }
-                HIP_TRY(wf_launch_trav(compact, count, sc, rp, wf, trav_blocks, stream));
-                if (timed) {
-                    HIP_TRY(hipEventRecord(scene->ev_trav[2 * it + 1], stream));
-                    scene->timed_rounds = it + 1;
-                }
-                HIP_TRY(wf_launch_hit(compact, sc, cam, rp, wf, flat_blocks, stream));
-                HIP_TRY(wf_launch_miss(sc, cam, rp, wf, flat_blocks, stream));
             }
-            HIP_TRY(hipMemcpyAsync(&scene->h_live[b & 1u], &wf.ctl->live_slots, sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipEventRecord(scene->ev_batch[b & 1u], stream));
+            for (uint32_t p = 0; p < n_pipes; p++) {
+                rayrs_scene::Pipeline& pl = scene->pipe[p];
+                HIP_TRY(hipMemcpyAsync(&pl.h_live[b & 1u], &wfs[p].ctl->live_slots, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       streams[p]));
+                HIP_TRY(hipEventRecord(pl.ev_batch[b & 1u], streams[p]));
+            }
             if (b > 0) {
-                HIP_TRY(hipEventSynchronize(scene->ev_batch[(b - 1u) & 1u]));
-                const uint32_t seen = scene->h_live[(b - 1u) & 1u];
+                uint64_t seen = 0;
+                for (uint32_t p = 0; p < n_pipes; p++) {
+                    HIP_TRY(hipEventSynchronize(scene->pipe[p].ev_batch[(b - 1u) & 1u]));
+                    seen += scene->pipe[p].h_live[(b - 1u) & 1u];
+                }
                 if (seen == 0u) break;
-                batch = (uint64_t)seen * 8u < np ? 4u : 16u;
+                batch = seen * 8u < live_total ? 4u : 16u;
             }
             if (it > (1u << 26)) {
                 g_last_error = "path rounds did not terminate";
@@ -647,6 +701,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             }
         }
         scene->rounds = it;
+        if (n_pipes > 1) {  // join: the resolve pass waits for the second stream
+            HIP_TRY(hipEventRecord(scene->ev_join, scene->aux_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, scene->ev_join, 0));
+        }
     }
     HIP_TRY(hipEventRecord(scene->ev[1], stream));
     HIP_TRY(launch_resolve(cam, rp, stream));
@@ -688,15 +746,19 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[2]));
         stats->total_ms = ms;
         double trav = 0.0;
-        for (uint32_t r = 0; r < scene->timed_rounds; r++) {
-            HIP_TRY(hipEventElapsedTime(&ms, scene->ev_trav[2 * r], scene->ev_trav[2 * r + 1]));
-            trav += ms;
+        for (uint32_t p = 0; p < scene->n_pipes; p++) {
+            const rayrs_scene::Pipeline& pl = scene->pipe[p];
+            double t = 0.0;
+            for (uint32_t r = 0; r < pl.timed_rounds; r++) {
+                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[2 * r], pl.ev_trav[2 * r + 1]));
+                t += ms;
+            }
+            // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
+            if (pl.timed_rounds && scene->rounds > pl.timed_rounds) t *= (double)scene->rounds / (double)pl.timed_rounds;
+            trav += t;
         }
-        // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
-        if (scene->timed_rounds && scene->rounds > scene->timed_rounds)
-            trav *= (double)scene->rounds / (double)scene->timed_rounds;
         stats->kernel_ms = trav;
-        stats->kernel_launches = scene->rounds;
+        stats->kernel_launches = (uint64_t)scene->rounds * scene->n_pipes;
     }
     return RAYRS_OK;
 }

@@ -129,6 +129,7 @@ struct RenderDev {
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // total_items * 3
+    unsigned long long* next_item;  // device-wide item counter (shared by the render's pipelines)
     Counters* counters;
     void* out;
 };

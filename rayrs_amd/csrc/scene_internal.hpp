@@ -34,19 +34,30 @@ struct rayrs_scene {
     int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
     uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
     uint32_t hot_records = 0;    // leading wide records kept in LDS
-    uint32_t* d_stack_spill = nullptr;
-    size_t stack_spill_words = 0;
     uint64_t device_bytes = 0;
-    // path pool and queues of the wavefront pipeline
-    rayrs::WfDev wf = {};
-    void* wf_block = nullptr;    // one allocation holding the slot records and the state bytes
-    unsigned long long* d_wave_items = nullptr;  // per-wave reserved item ranges
-    uint32_t wave_items_cap = 0;
-    uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
-    hipEvent_t ev_batch[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
+    // The path pool, as one or two pipelines (abi.cpp rayrs_render_launch): each owns its slots, state
+    // bytes, control words, per-wave item ranges and traversal-stack overflow strips, and runs its rounds on
+    // a stream of its own, so that one pipeline's memory-bound hit/miss kernels can run beside the other's
+    // ALU-bound traversal kernel.
+    struct Pipeline {
+        rayrs::WfDev wf = {};
+        void* block = nullptr;       // one allocation holding the slot records and the state bytes
+        uint32_t block_slots = 0;
+        unsigned long long* d_wave_items = nullptr;
+        uint32_t wave_items_cap = 0;
+        uint32_t* d_stack_spill = nullptr;
+        size_t stack_spill_words = 0;
+        uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
+        hipEvent_t ev_batch[2] = {nullptr, nullptr};
+        std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
+        uint32_t timed_rounds = 0;
+    };
+    Pipeline pipe[2];
+    uint32_t n_pipes = 1;            // pipelines of the render in flight
+    hipStream_t aux_stream = nullptr;  // the second pipeline's stream (the first uses the caller's)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
+    unsigned long long* d_next_item = nullptr;  // the device-wide item counter both pipelines draw from
     uint32_t rounds = 0;
-    uint32_t timed_rounds = 0;
     rayrs_tuning tuning = {};  // zeros = defaults (rayrs_scene_set_tuning)
 };
 

@@ -63,8 +63,7 @@ constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)
 struct WfCtl {
     uint32_t next_window;  // window cursor of the traversal kernel
     uint32_t live_slots;   // slots that still have or can get work
-    unsigned long long next_item;
-    uint32_t pad[4];
+    uint32_t pad[6];
 };
 
 struct WfDev {

@@ -158,7 +158,6 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
         WfCtl* c = wf.ctl;
         c->next_window = 0;
         c->live_slots = live;
-        c->next_item = 0ull;
     }
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
@@ -216,7 +215,6 @@ RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r)
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const CameraDev& cam,
                         const RenderDev& rp, const WfDev& wf, ItemRange& range, unsigned long long& n_paths,
                         uint32_t& retired) {
-    WfCtl* ctl = wf.ctl;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     ItemSlot* ps = &wf.slots[slot].item;
@@ -242,7 +240,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     while (need_mask != 0ull) {
         if (range.next >= range.end) {  // wave-uniform
             unsigned long long first = 0;
-            if (lane == 0) first = atomicAdd(&ctl->next_item, (unsigned long long)ITEM_RESERVE);
+            if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
             const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
             const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
             first = ((unsigned long long)fhi << 32) | flo;

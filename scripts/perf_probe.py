@@ -15,6 +15,9 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False, ranks=1):
     hdri = procedural.make_hdri(1024, 512)
     t = time.time()
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=0)
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_TUNING", "").split(",") if kv)}
+    if tune:
+        scene.set_tuning(**tune)
     tb = time.time() - t
     cam = rayrs_amd.Camera(*cam_args)
     info = scene.info()
@@ -50,6 +53,8 @@ if __name__ == "__main__":
         run(4, 2048, 2048, 128, chunk=4)
     if what == "big5":
         run(5, 2048, 2048, 64, chunk=16)
+    if what == "full5":
+        run(5, 2048, 2048, 1024, chunk=4)
     if what == "shard8":
         chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 16
         run(5, 2048, 2048, 1024, chunk=chunk, ranks=8)

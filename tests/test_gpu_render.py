@@ -236,3 +236,18 @@ def test_glass_on_a_triangle_mesh():
     ref, ost = osc.render(ocam, 4, 50, traversal=0)
     assert st["rays"] == ost["rays"]
     assert_same_frame(img, ref)
+
+
+def test_two_pipelines_render_the_same_frame():
+    """rayrs_tuning.pipelines = 2: the pool as two halves on two streams (one half's hit/miss kernels beside the
+    other's traversal kernel).  Items are handed out in a different order, every item's samples are still
+    summed in order: the frame must not change by a bit, nor the ray count."""
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 256, 256, 16)
+    one, st1 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
+    scene.set_tuning(pipelines=2, trav_blocks_per_cu=4)
+    two, st2 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
+    assert st2["kernel_launches"] > st1["kernel_launches"]  # two traversal launches per round
+    assert st1["rays"] == st2["rays"] and st1["paths"] == st2["paths"]
+    assert np.array_equal(one.view(np.uint64), two.view(np.uint64))
+    ref, ost = osc.render(ocam, 16, sample_chunk=4, rows=(120, 136))
+    assert np.array_equal(two[120:136].view(np.uint64), ref[120:136].view(np.uint64))
