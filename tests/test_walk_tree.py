@@ -115,3 +115,32 @@ def test_deep_reference_tree_gives_a_shallow_walk_tree():
     d = np.stack([np.abs(r.normal(size=500)) + 0.2, r.normal(size=500) * 0.05, -np.abs(r.normal(size=500)) * 0.3], 1)
     hit = both_walks(objs, BvhHeuristic.Midpoint, o, d, 1e-6, 1e60)
     assert (hit >= 0).sum() > 100
+
+
+def test_hostile_rays_and_scene_scales():
+    """Axes with d == 0, -0, denormal-small or huge components, origins far outside the scene and exactly on
+    round coordinates, at scene scales of 1e-3, 1 and 1e6: the walk tree must return the reference's hits."""
+    r = np.random.default_rng(21)
+    for scale in (1e-3, 1.0, 1e6):
+        objs = []
+        for i in range(300):
+            c = r.uniform(-5, 5, 3) * scale
+            if i % 2:
+                objs.append(Object.sphere(float(r.uniform(0.1, 0.8)) * scale, c, NR, DARK))
+            else:
+                objs.append(Object.triangle(c, c + r.uniform(-1, 1, 3) * scale, c + r.uniform(-1, 1, 3) * scale, NR, DARK))
+        n = 3000
+        o = r.uniform(-8, 8, (n, 3)) * scale
+        o[:300] *= 1e6
+        o[300:600] = np.round(o[300:600] / scale) * scale
+        d = r.normal(size=(n, 3))
+        d[::5, 0] = 0.0
+        d[1::5, 1] = -0.0
+        d[2::7, 2] = 1e-300
+        d[3::11, 0] = 1e-40
+        d[4::13] *= 1e200
+        d[(d == 0).all(axis=1)] = (0.0, 1.0, 0.0)
+        d[:300] = -o[:300] + r.normal(size=(300, 3)) * scale
+        hit = both_walks(objs, BvhHeuristic.Sah(1000), np.ascontiguousarray(o), np.ascontiguousarray(d), 1e-6 * scale,
+                         1e12 * scale)
+        assert (hit >= 0).sum() > 50, scale
