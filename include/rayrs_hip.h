@@ -120,8 +120,8 @@ typedef struct rayrs_scene rayrs_scene;
 /* Scene::new(objects, z_near, z_far, heuristic, hdri)               lib.rs:227
  * Consumes nothing: `objs` stays owned by the caller and may be destroyed
  * right after.  Builds the BVH exactly as Bvh::build does (bvh.rs:199-389,
- * same splits, same child order), flattens it and uploads it to HIP device
- * `device`.  device = -1 builds a host-only scene (no GPU needed) that can
+ * same splits, same child order), derives the tree the kernels walk from it
+ * (rayrs_scene_export_wide) and uploads that to HIP device `device`.  device = -1 builds a host-only scene (no GPU needed) that can
  * be inspected with rayrs_scene_info / rayrs_scene_export_bvh but not
  * rendered.  hdri_rgb: hdri_w*hdri_h RGB f32 texels, row-major, image origin
  * upper left; values are clipped to [0, 3] as main.rs:43 does. */
@@ -160,11 +160,14 @@ int rayrs_scene_device(const rayrs_scene* scene);
  * 1 = 1..4 primitives behind a box test (payload = first<<2 | count-1),
  * 2 = one primitive with no box test (payload = prim<<2). */
 int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t* child_ref, uint32_t* prim_object);
-/* The records the kernels actually walk: two levels of the tree above folded into one
- * record of up to four slots (wide_box: n_wide*4*6 f64, wide_ref: n_wide*4 u32, kind 3 =
- * unused slot).  A slot's box is the one whose test gates the reference's access to that
- * subtree: the grandchild's own box, or its parent's when the grandchild is a direct leaf
- * (bvh.rs:297, :302), which then appears as a one-primitive kind-1 reference. */
+/* The records the kernels actually walk (wide_box: n_wide*4*6 f64, wide_ref: n_wide*4 u32, kind 3 =
+ * unused slot): NOT the reference's topology but a tree built for traversal speed over the reference's
+ * leaf groups.  A leaf slot (kind 1) is one group -- the 1..4 leaves that share a parent Node, contiguous
+ * in depth-first order -- behind exactly the box that gates the reference's access to it (the parent
+ * Node's box; boxes on a root path nest exactly and the slab test is monotone, so passing it implies
+ * passing every box above).  An interior slot (kind 0) carries the union of the boxes below it: a ray
+ * that misses it misses every gating box inside.  Every group appears exactly once
+ * (tests/test_bvh_builder.py checks all of this from the two exports alone). */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 
 /* ---- Camera: lib.rs:54-211 ---- */

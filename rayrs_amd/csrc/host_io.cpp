@@ -70,13 +70,31 @@ double read_binary_scalar(const uint8_t* p, int type) {
 
 }  // namespace
 
+// Writers report a short write, a full disk or a failed flush instead of returning OK on a truncated file.
+static int finish_write(FILE* f, bool ok, const char* path) {
+    ok = ok && std::ferror(f) == 0;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RAYRS_OK : io_fail(std::string("write failed: ") + path);
+}
+
+// No exception crosses the C boundary: allocation failures of the loaders and writers become statuses.
+#define IO_GUARDED(call)                     \
+    try {                                    \
+        return call;                         \
+    } catch (const std::bad_alloc&) {        \
+        g_io_error = "out of memory";        \
+        return RAYRS_OOM;                    \
+    } catch (const std::exception& e) {      \
+        return io_fail(e.what());            \
+    }
+
 extern "C" {
 
 const char* rayrs_io_last_error(void) { return g_io_error.c_str(); }
 
 void rayrs_buffer_free(void* p) { std::free(p); }
 
-int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, uint32_t** idx_out, uint32_t* ntris_out) {
+static int ply_load_impl(const char* path, float** verts_out, uint32_t* nverts_out, uint32_t** idx_out, uint32_t* ntris_out) {
     if (!path || !verts_out || !nverts_out || !idx_out || !ntris_out) return RAYRS_INVALID_ARG;
     *verts_out = nullptr;
     *idx_out = nullptr;
@@ -159,8 +177,15 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
             }
             if (ix < 0 || iy < 0 || iz < 0) return io_fail("vertex element without x/y/z");
             if (e.count >= (1ull << 32)) return io_fail("too many vertices");
-            verts.reserve((size_t)e.count * 3);
         }
+        // the header is not trusted: an element of `count` rows needs at least one byte per property and row
+        // (two in ascii: a digit and a separator), so a count the body cannot hold is refused before any reserve
+        {
+            const uint64_t min_row = std::max<uint64_t>(e.props.size(), 1) * (format == 0 ? 2u : 1u);
+            const uint64_t left = body.size() - std::min(body.size(), format == 0 ? (size_t)0 : pos);
+            if (e.count > left / min_row + 1) return io_fail("element count exceeds the file size");
+        }
+        if (is_vertex) verts.reserve((size_t)e.count * 3);
         std::vector<double> poly;
         for (uint64_t r = 0; r < e.count; r++) {
             double xyz[3] = {0, 0, 0};
@@ -169,6 +194,7 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
                 if (p.is_list) {
                     double n;
                     if (!next_scalar(p.count_type, n)) return io_fail("truncated PLY body");
+                    if (!(n >= 0.0 && n <= 1e6)) return io_fail("bad list length");
                     poly.clear();
                     for (int j = 0; j < (int)n; j++) {
                         double v;
@@ -176,6 +202,8 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
                         poly.push_back(v);
                     }
                     if (is_face && (p.name == "vertex_indices" || p.name == "vertex_index")) {
+                        for (double v : poly)  // validated as read, before any narrowing cast
+                            if (!(v >= 0.0 && v < 4294967296.0 && v == std::floor(v))) return io_fail("face index out of range");
                         for (size_t j = 2; j < poly.size(); j++) {  // fan triangulation, winding kept
                             idx.push_back((uint32_t)poly[0]);
                             idx.push_back((uint32_t)poly[j - 1]);
@@ -186,6 +214,12 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
                     double v;
                     if (!next_scalar(p.type, v)) return io_fail("truncated PLY body");
                     if (is_vertex) {
+                        // `property double x`: the caller gets f32 vertices, so only values an f32 holds exactly
+                        // pass (anything else would silently move the geometry; NaN fails the comparison too).
+                        // A `float` property is an f32 by declaration: its decimal text is rounded to it.
+                        const bool coord = (int)k == ix || (int)k == iy || (int)k == iz;
+                        if (coord && p.type == T_F64 && (double)(float)v != v)
+                            return io_fail("double vertex coordinate is not representable in f32");
                         if ((int)k == ix) xyz[0] = v;
                         if ((int)k == iy) xyz[1] = v;
                         if ((int)k == iz) xyz[2] = v;
@@ -193,9 +227,7 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
                 }
             }
             if (is_vertex) {
-                verts.push_back((float)xyz[0]);
-                verts.push_back((float)xyz[1]);
-                verts.push_back((float)xyz[2]);
+                for (double c : xyz) verts.push_back((float)c);
             }
         }
     }
@@ -204,7 +236,13 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
         if (i >= nv) return io_fail("face index out of range");
     *verts_out = static_cast<float*>(std::malloc(std::max<size_t>(verts.size(), 1) * sizeof(float)));
     *idx_out = static_cast<uint32_t*>(std::malloc(std::max<size_t>(idx.size(), 1) * sizeof(uint32_t)));
-    if (!*verts_out || !*idx_out) return RAYRS_OOM;
+    if (!*verts_out || !*idx_out) {
+        std::free(*verts_out);
+        std::free(*idx_out);
+        *verts_out = nullptr;
+        *idx_out = nullptr;
+        return RAYRS_OOM;
+    }
     std::memcpy(*verts_out, verts.data(), verts.size() * sizeof(float));
     std::memcpy(*idx_out, idx.data(), idx.size() * sizeof(uint32_t));
     *nverts_out = nv;
@@ -212,7 +250,18 @@ int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, ui
     return RAYRS_OK;
 }
 
-int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const uint32_t* idx, uint32_t ntris,
+int rayrs_ply_load(const char* path, float** verts_out, uint32_t* nverts_out, uint32_t** idx_out, uint32_t* ntris_out) {
+    try {  // nothing unwinds across the C boundary
+        return ply_load_impl(path, verts_out, nverts_out, idx_out, ntris_out);
+    } catch (const std::bad_alloc&) {
+        g_io_error = "out of memory";
+        return RAYRS_OOM;
+    } catch (const std::exception& e) {
+        return io_fail(e.what());
+    }
+}
+
+static int rayrs_ply_save_impl(const char* path, const float* verts, uint32_t nverts, const uint32_t* idx, uint32_t ntris,
                    int binary) {
     if (!path || (!verts && nverts) || (!idx && ntris)) return RAYRS_INVALID_ARG;
     std::ofstream f(path, std::ios::binary);
@@ -243,7 +292,7 @@ int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const 
 
 // load_obj_file, wavefront_obj.rs:15-45: `v x y z` and `f i j k` lines only, fields split
 // on single spaces, 1-based plain indices, triangles only.  Vertices stay f64.
-int rayrs_obj_load(const char* path, double** verts_out, uint32_t* nverts_out, uint32_t** idx_out,
+static int rayrs_obj_load_impl(const char* path, double** verts_out, uint32_t* nverts_out, uint32_t** idx_out,
                    uint32_t* ntris_out) {
     if (!path || !verts_out || !nverts_out || !idx_out || !ntris_out) return RAYRS_INVALID_ARG;
     std::ifstream f(path);
@@ -296,7 +345,7 @@ int rayrs_obj_load(const char* path, double** verts_out, uint32_t* nverts_out, u
 
 // Reads a Radiance RGBE picture (-Y h +X w, flat or new-style RLE scanlines) into w*h RGB f32,
 // row-major, top row first: what HdrDecoder::read_image_hdr yields (main.rs:36-41).
-int rayrs_hdr_load(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out) {
+static int rayrs_hdr_load_impl(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out) {
     if (!path || !rgb_out || !w_out || !h_out) return RAYRS_INVALID_ARG;
     *rgb_out = nullptr;
     FILE* f = std::fopen(path, "rb");
@@ -375,11 +424,11 @@ int rayrs_hdr_load(const char* path, float** rgb_out, uint32_t* w_out, uint32_t*
 }
 
 // HDREncoder::encode (main.rs:113-121): flat (non-RLE) RGBE scanlines.
-int rayrs_hdr_save(const char* path, const float* rgb, uint32_t w, uint32_t h) {
+static int rayrs_hdr_save_impl(const char* path, const float* rgb, uint32_t w, uint32_t h) {
     if (!path || !rgb || !w || !h) return RAYRS_INVALID_ARG;
     FILE* f = std::fopen(path, "wb");
     if (!f) return io_fail(std::string("cannot create ") + path);
-    std::fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %u +X %u\n", h, w);
+    bool ok = std::fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %u +X %u\n", h, w) > 0;
     std::vector<uint8_t> scan((size_t)w * 4);
     for (uint32_t y = 0; y < h; y++) {
         for (uint32_t x = 0; x < w; x++) {
@@ -397,10 +446,9 @@ int rayrs_hdr_save(const char* path, const float* rgb, uint32_t w, uint32_t h) {
                 o[3] = (uint8_t)(e + 128);
             }
         }
-        std::fwrite(scan.data(), 1, scan.size(), f);
+        ok = ok && std::fwrite(scan.data(), 1, scan.size(), f) == scan.size();
     }
-    std::fclose(f);
-    return RAYRS_OK;
+    return finish_write(f, ok, path);
 }
 
 // ------------------------------------------------------------- LDR output
@@ -430,14 +478,13 @@ int rayrs_ppm_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t 
     if (!path || !bytes) return RAYRS_INVALID_ARG;
     FILE* f = std::fopen(path, "wb");
     if (!f) return io_fail(std::string("cannot create ") + path);
-    std::fprintf(f, "P6\n%u %u\n255\n", w, h);
-    std::fwrite(bytes, 1, (size_t)w * h * 3, f);
-    std::fclose(f);
-    return RAYRS_OK;
+    bool ok = std::fprintf(f, "P6\n%u %u\n255\n", w, h) > 0;
+    ok = ok && std::fwrite(bytes, 1, (size_t)w * h * 3, f) == (size_t)w * h * 3;
+    return finish_write(f, ok, path);
 }
 
 // image::save_buffer(.., ColorType::Rgb8) to PNG (main.rs:104-110): 8-bit RGB, zlib "stored" blocks.
-int rayrs_png_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h) {
+static int rayrs_png_save_impl(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h) {
     if (!path || !bytes || !w || !h) return RAYRS_INVALID_ARG;
     static uint32_t crc_table[256];
     static bool have = false;
@@ -504,8 +551,15 @@ int rayrs_png_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t 
     z.insert(z.end(), ad, ad + 4);
     chunk("IDAT", z);
     chunk("IEND", {});
-    std::fclose(f);
-    return RAYRS_OK;
+    return finish_write(f, true, path);
 }
+
+int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const uint32_t* idx, uint32_t ntris,
+                   int binary) { IO_GUARDED(rayrs_ply_save_impl(path, verts, nverts, idx, ntris, binary)); }
+int rayrs_obj_load(const char* path, double** verts_out, uint32_t* nverts_out, uint32_t** idx_out,
+                   uint32_t* ntris_out) { IO_GUARDED(rayrs_obj_load_impl(path, verts_out, nverts_out, idx_out, ntris_out)); }
+int rayrs_hdr_load(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out) { IO_GUARDED(rayrs_hdr_load_impl(path, rgb_out, w_out, h_out)); }
+int rayrs_hdr_save(const char* path, const float* rgb, uint32_t w, uint32_t h) { IO_GUARDED(rayrs_hdr_save_impl(path, rgb, w, h)); }
+int rayrs_png_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h) { IO_GUARDED(rayrs_png_save_impl(path, bytes, w, h)); }
 
 }  // extern "C"

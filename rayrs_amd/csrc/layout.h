@@ -1,12 +1,16 @@
 // layout.h -- HBM data layout shared by the host flattener and the gfx950 kernels.
 //
 // Everything the traversal touches is one of two record arrays, each record a
-// whole number of 16-byte words so that a lane fetches it with global_load_dwordx4:
+// whole number of 16-byte words so that a lane fetches it with dwordx4 loads:
 //
-//   interior record  two child boxes + two child refs          64 B (compact) / 128 B (full)
+//   wide record      four boxes + four references              128 B (compact) / 256 B (full)
 //   primitive record triangle | sphere | plane + tag, DFS order  48 B (compact) /  80 B (full)
 //
-// "compact" = every node bound and every triangle vertex is exactly
+// The wide records are the product's own tree over the reference's leaf groups
+// (scene_host.cpp build_walk_tree); the two-child records of the reference's tree
+// exist on the host only (rayrs_scene_export_bvh).
+//
+// "compact" = every box bound and every triangle vertex is exactly
 // representable in f32 (true for PLY meshes, whose vertices are f32), so the
 // f32 storage widens back to the very f64 values the reference computes with.
 // Spheres and planes always keep f64 parameters inside their record.
@@ -17,8 +21,10 @@ namespace rayrs {
 
 // child reference: kind << 30 | payload
 constexpr uint32_t REF_INTERIOR = 0u;  // payload = interior record index
-constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1); box tested by the parent
-constexpr uint32_t REF_SINGLE = 2u;    // payload = prim << 2; no box test (bvh.rs:297, :302)
+constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1): 1..4 primitives behind their gating box
+constexpr uint32_t REF_SINGLE = 2u;    // two-child export only: payload = prim << 2, a direct leaf (no box of its own,
+                                       // bvh.rs:297, :302); the walk tree holds it as a one-primitive REF_RANGE behind
+                                       // the box of the Node it hangs under
 constexpr uint32_t REF_NONE = 3u;
 
 // primitive tag: kind | axis << 2 | surface << 8
@@ -39,12 +45,10 @@ struct NodeF64 {  // 128 B
 static_assert(sizeof(NodeF32) == 64, "NodeF32");
 static_assert(sizeof(NodeF64) == 128, "NodeF64");
 
-// The records the traversal kernel reads are "wide": two levels of the reference's binary
-// tree folded into one record of up to four slots, so that a query makes half as many
-// dependent fetches.  A slot holds the box whose test gates the reference's access to that
-// subtree: the grandchild's own box (which implies its parent's, boxes nest exactly) or, for
-// a grandchild that is a direct leaf (no box test of its own in the reference, bvh.rs:297,
-// :302), its parent's box.  Unused slots carry REF_NONE.
+// The records the traversal kernel reads are "wide": up to four slots, each a box and a reference.
+// A leaf slot holds a group of the reference's tree (the 1..4 leaves under one Node) behind the box
+// whose test gates the reference's access to it; an interior slot holds the union of the boxes below
+// it and the record they are in.  Unused slots carry REF_NONE and the inverted box.
 struct Node4F32 {  // 128 B
     float box[4][6];
     uint32_t ref[4];

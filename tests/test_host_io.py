@@ -1,5 +1,6 @@
 """File formats either side of the path: PLY/OBJ ingest,
 Radiance .hdr, the reference's 8-bit conversion, PPM/PNG writers.  CPU only."""
+import os
 import struct
 import zlib
 
@@ -117,3 +118,43 @@ def test_mesh_scene_through_ply_is_the_same_scene(tmp_path):
     a = rayrs_amd.Scene(direct, 1e-6, 1e6, heur, hdri, device=-1).export_bvh()
     b = rayrs_amd.Scene(via_ply, 1e-6, 1e6, heur, hdri, device=-1).export_bvh()
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_ply_header_is_not_trusted(tmp_path):
+    """a PLY header claiming 2^32-1 vertices, a face list longer than the file, an index that is
+    negative, fractional or huge, a double coordinate an f32 cannot hold -- all refused with RAYRS_IO_ERROR
+    (-6), none crashes or allocates what the header asks for."""
+    from rayrs_amd import _ffi
+
+    def status(text, binary_tail=b""):
+        p = tmp_path / "bad.ply"
+        p.write_bytes(text.encode() + binary_tail)
+        try:
+            io.load_ply(p)
+        except _ffi.RayrsError as e:
+            return e.status
+        return 0
+
+    head = "ply\nformat ascii 1.0\nelement vertex {nv}\nproperty float x\nproperty float y\nproperty float z\n" \
+           "element face {nf}\nproperty list uchar int vertex_indices\nend_header\n"
+    good = head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n"
+    assert status(good) == 0
+    assert status(head.format(nv=4294967295, nf=1) + "0 0 0\n") == -6            # count the body cannot hold
+    assert status(head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 -2\n") == -6   # negative index
+    assert status(head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 1.5\n") == -6  # fractional index
+    assert status(head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n") == -6    # beyond the vertices
+    dbl = head.replace("property float x", "property double x")
+    assert status(dbl.format(nv=3, nf=1) + "0.1 0 0\n1 0 0\n0 1 0\n3 0 1 2\n") == -6   # 0.1 is not an f32 value
+    assert status(dbl.format(nv=3, nf=1) + "0.5 0 0\n1 0 0\n0 1 0\n3 0 1 2\n") == 0    # 0.5 is
+    binh = head.replace("ascii", "binary_little_endian")
+    assert status(binh.format(nv=1000000, nf=0), b"\0" * 36) == -6                     # truncated binary body
+
+
+def test_writers_report_failure(tmp_path):
+    from rayrs_amd import _ffi
+    img = np.zeros((4, 4, 3), dtype=np.float32)
+    with pytest.raises(_ffi.RayrsError):
+        io.save_hdr(tmp_path / "no_such_dir" / "x.hdr", img)
+    if os.path.exists("/dev/full"):  # every write fails with ENOSPC
+        with pytest.raises(_ffi.RayrsError):
+            io.save_hdr("/dev/full", np.zeros((64, 64, 3), dtype=np.float32))
