@@ -142,7 +142,7 @@ typedef struct {
     uint64_t device_bytes; /* total scene footprint in HBM */
     double root_box[6];    /* xmin,xmax,ymin,ymax,zmin,zmax */
     double build_seconds;
-    uint32_t n_wide;        /* four-slot records the kernels traverse (two levels of the tree each) */
+    uint32_t n_wide;        /* four-slot records of the walk tree the kernels traverse */
     uint32_t wide_root_ref;
     uint32_t wide_depth;    /* stack entries the traversal can need */
     uint32_t reserved;

@@ -52,7 +52,7 @@ struct FlatScene {
     std::vector<uint32_t> prim_object;
     uint32_t root_ref = 0;
     uint32_t depth = 0;
-    // the same tree with two levels folded into one record (what the kernels traverse)
+    // the walk tree: four-slot records over the reference's leaf groups (what the kernels traverse)
     std::vector<double> wide_box;    // n_wide * 24
     std::vector<uint32_t> wide_ref;  // n_wide * 4
     uint32_t wide_root_ref = 0;

@@ -173,11 +173,11 @@ def test_sentinel_boxes_of_the_wide_records():
             assert L.orc_aabb_intersect(nothing, _oracle.d3(o), _oracle.d3(d), 1e-6, 1e6) == 0
 
 
-def test_folded_walk_equals_reference_on_degenerate_rays():
+def test_kernel_walk_equals_reference_on_degenerate_rays():
     """Rays built to hit the slab test's special cases -- origins exactly on box planes, direction
     components exactly zero (1/0 = inf, 0 * inf = NaN, which f64::max/min ignore, geometry.rs:458-513)
     -- through a scene on an integer grid, so that such coincidences are the rule.  The walk over
-    the folded four-slot records (what the kernel does) must find what the reference's recursion
+    the four-slot records of the product's walk tree (what the kernel does) must find what the reference's recursion
     finds: skipping a parent's box in favour of its child's is only sound if the slab test is
     monotone in these cases too."""
     r = np.random.default_rng(11)
