@@ -57,10 +57,12 @@ OPS_RAY = 54               # 1/d (3 div x 11) + the root box test (21)
 
 
 def useful_f64_ops(stats, info):
+    """Of the traversal kernel.  Primary rays that miss the root box never reach it (direct_rays: the kernel
+    that makes them finishes their sample)."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
     return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
-            + stats["plane_tests"] * OPS_PLANE + stats["rays"] * OPS_RAY)
+            + stats["plane_tests"] * OPS_PLANE + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY)
 
 
 def algorithmic_bytes(stats, info):
@@ -70,7 +72,7 @@ def algorithmic_bytes(stats, info):
     writes back (t + primitive, 12 B) and the slot's state byte (read + write)."""
     return (stats["interior_visits"] * info["node_bytes"]
             + (stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"]) * info["prim_bytes"]
-            + stats["rays"] * (48 + 12 + 2))
+            + (stats["rays"] - stats.get("direct_rays", 0)) * (48 + 12 + 2))
 
 
 def source_hash():

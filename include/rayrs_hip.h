@@ -232,6 +232,10 @@ typedef struct {
      * the k-th distinct (Material, Emission) pair in object insertion order, pairs 7 and up together;
      * rays - sum(surface_hits) = queries that found nothing (Scene::background) */
     uint64_t surface_hits[8];
+    /* primary rays that missed the root Node's box (bvh.rs:394: a Miss before anything else is looked at): their
+     * samples are finished by the kernel that made the ray, without a trip through the traversal and miss
+     * kernels.  They are part of `rays` and of `escaped_paths`. */
+    uint64_t direct_rays;
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:

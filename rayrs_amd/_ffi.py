@@ -68,7 +68,7 @@ class RenderStats(C.Structure):
                 ("leaf_wave", C.c_uint64), ("interior_ticks", C.c_uint64), ("leaf_ticks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
-                ("surface_hits", C.c_uint64 * 8)]
+                ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -416,7 +416,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 21);
+    RAYRS_STRUCT(rayrs_render_stats, 22);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -427,7 +427,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, leaf_ticks), RAYRS_FIELD(rayrs_render_stats, kernel_ms);
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
-    RAYRS_FIELD(rayrs_render_stats, surface_hits);
+    RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_STRUCT(rayrs_tuning, 8);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
@@ -645,7 +645,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
         for (uint32_t p = 0; p < n_pipes; p++) {
             HIP_TRY(wf_launch_init(wfs[p], lives[p], streams[p]));
-            HIP_TRY(wf_launch_gen(cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
+            HIP_TRY(wf_launch_gen(sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
             scene->pipe[p].h_live[0] = scene->pipe[p].h_live[1] = lives[p];
         }
         // Rounds are enqueued in batches; the live-slot counts of batch b are read back while batch b+1 is
@@ -740,6 +740,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->leaf_wave = c.leaf_wave, stats->interior_ticks = c.interior_ticks, stats->leaf_ticks = c.leaf_ticks;
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
+        stats->direct_rays = c.direct_rays;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;

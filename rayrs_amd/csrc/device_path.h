@@ -266,18 +266,23 @@ struct Trav {
     int sp;
 };
 
+// What BvhTree::intersect does first (bvh.rs:394): the box of the root Node.  A ray that misses it
+// is a Miss without anything else being looked at.
+RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
+    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+    double entry;
+    return slab(nx ? sc.root_box[1] : sc.root_box[0], nx ? sc.root_box[0] : sc.root_box[1],
+                ny ? sc.root_box[3] : sc.root_box[2], ny ? sc.root_box[2] : sc.root_box[3],
+                nz ? sc.root_box[5] : sc.root_box[4], nz ? sc.root_box[4] : sc.root_box[5], o, inv, sc.t0, sc.t1,
+                entry);
+}
+
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    const bool nx = tv.inv.x < 0.0, ny = tv.inv.y < 0.0, nz = tv.inv.z < 0.0;
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
-    double entry;
-    const bool hit = slab(nx ? sc.root_box[1] : sc.root_box[0], nx ? sc.root_box[0] : sc.root_box[1],
-                          ny ? sc.root_box[3] : sc.root_box[2], ny ? sc.root_box[2] : sc.root_box[3],
-                          nz ? sc.root_box[5] : sc.root_box[4], nz ? sc.root_box[4] : sc.root_box[5], o, tv.inv, sc.t0,
-                          sc.t1, entry);
-    tv.cur = hit ? sc.root_ref : TRAV_DONE;
+    tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
 RR_DEV void trav_pop(const LaneStack& stack, Trav& tv) {

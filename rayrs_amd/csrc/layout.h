@@ -117,6 +117,7 @@ struct Counters {
     unsigned long long step_wave, step_lane, inner_wave, leaf_wave;
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
+    unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
 };
 
 struct RenderDev {

@@ -209,6 +209,7 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->neg_pixels += s.neg_pixels, stats->escaped_paths += s.escaped_paths;
                 stats->interior_visits += s.interior_visits, stats->tri_tests += s.tri_tests;
                 stats->sphere_tests += s.sphere_tests, stats->plane_tests += s.plane_tests;
+                stats->direct_rays += s.direct_rays;
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
                 if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
                 if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;

@@ -83,8 +83,8 @@ struct WfDev {
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
-hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
-                         hipStream_t stream);
+hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+                         uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
 hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);

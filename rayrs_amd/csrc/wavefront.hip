@@ -212,111 +212,150 @@ RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r)
     }
 }
 
-RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const CameraDev& cam,
-                        const RenderDev& rp, const WfDev& wf, ItemRange& range, unsigned long long& n_paths,
-                        uint32_t& retired) {
+// What the kernels that start samples count per lane.
+struct SampleCount {
+    unsigned long long paths;   // samples started
+    unsigned long long direct;  // of them: primary rays that missed the root box (answered here, below)
+    uint32_t retired;           // slots that found no further item
+};
+
+// A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
+// (bvh.rs:394), so its sample is the background (lib.rs:555) -- finished here, in registers, instead of
+// sending the ray through the traversal and miss kernels for the same answer: the lane goes on to the
+// item's next sample, and to the next item, until it holds a ray that enters the root box.  From the
+// reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
+RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
+                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
+                        SampleCount& sn) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     ItemSlot* ps = &wf.slots[slot].item;
+    bool todo = want;  // lanes still without a ray for their slot
     bool has_item = want && ir.has_item != 0u;
-    uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end, row = 0, col = 0;
-    // an item whose samples are all done is written out (its sum goes to the resolve kernel)
-    bool keep_acc = false;
-    if (want && has_item && s_cur >= s_end) {
-        double* dst = rp.partial + (size_t)item * 3;
-        dst[0] = ir.acc[0];
-        dst[1] = ir.acc[1];
-        dst[2] = ir.acc[2];
-        has_item = false;
-    } else if (want && has_item) {
-        keep_acc = acc_dirty;  // the item goes on: its updated sum has to reach the slot
-    }
-    // slots without an item take the next ones from the wave's reserved range (ballot + rank),
-    // which is refilled from the device-wide counter
-    bool need = want && !has_item;
-    bool fresh = false;
-    bool dead = false;
-    unsigned long long need_mask = __ballot(need);
-    while (need_mask != 0ull) {
-        if (range.next >= range.end) {  // wave-uniform
-            unsigned long long first = 0;
-            if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
-            const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
-            const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
-            first = ((unsigned long long)fhi << 32) | flo;
-            if (first >= rp.total_items) {  // the counter has run out: these slots are done
-                if (need) dead = true;
-                break;
-            }
-            range.next = first;
-            range.end = first + ITEM_RESERVE < rp.total_items ? first + ITEM_RESERVE : rp.total_items;
+    uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
+    uint32_t row = ir.pix >> 16, col = ir.pix & 0xffffu;
+    double acc0 = ir.acc[0], acc1 = ir.acc[1], acc2 = ir.acc[2];
+    bool fresh = false;            // the slot's item record has to be written in full
+    bool acc_write = acc_dirty;    // the item goes on with a sum the slot does not hold yet
+    for (;;) {
+        // an item whose samples are all done is written out (its sum goes to the resolve kernel)
+        if (todo && has_item && s_cur >= s_end) {
+            double* dst = rp.partial + (size_t)item * 3;
+            dst[0] = acc0;
+            dst[1] = acc1;
+            dst[2] = acc2;
+            has_item = false;
         }
-        const uint32_t avail = (uint32_t)(range.end - range.next);
-        const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
-        if (need && rank < avail) {
-            item = (uint32_t)(range.next + rank);
-            uint32_t s_begin;
-            item_geometry(rp, item, row, col, s_begin, s_end);
-            s_cur = s_begin;
-            if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
-                // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
-                double* dst = rp.partial + (size_t)item * 3;
-                dst[0] = dst[1] = dst[2] = 0.0;
-                if (row < cam.H && col < cam.W) n_paths += s_end - s_begin;
+        // slots without an item take the next ones from the wave's reserved range (ballot + rank),
+        // which is refilled from the device-wide counter
+        bool need = todo && !has_item;
+        bool dead = false;
+        unsigned long long need_mask = __ballot(need);
+        while (need_mask != 0ull) {
+            if (range.next >= range.end) {  // wave-uniform
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
+                const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
+                const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
+                first = ((unsigned long long)fhi << 32) | flo;
+                if (first >= rp.total_items) {  // the counter has run out: these slots are done
+                    if (need) dead = true;
+                    break;
+                }
+                range.next = first;
+                range.end = first + ITEM_RESERVE < rp.total_items ? first + ITEM_RESERVE : rp.total_items;
+            }
+            const uint32_t avail = (uint32_t)(range.end - range.next);
+            const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+            if (need && rank < avail) {
+                item = (uint32_t)(range.next + rank);
+                uint32_t s_begin;
+                item_geometry(rp, item, row, col, s_begin, s_end);
+                s_cur = s_begin;
+                if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
+                    // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
+                    double* dst = rp.partial + (size_t)item * 3;
+                    dst[0] = dst[1] = dst[2] = 0.0;
+                    if (row < cam.H && col < cam.W) sn.paths += s_end - s_begin;
+                } else {
+                    has_item = true;
+                    fresh = true;
+                    acc0 = acc1 = acc2 = 0.0;
+                    need = false;
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need_mask);
+            range.next += wanted < avail ? wanted : avail;
+            need_mask = __ballot(need);
+        }
+        if (todo && dead) {
+            ps->has_item = 0;
+            wf.state[slot] = WF_DEAD;
+            sn.retired++;
+            todo = false;
+        }
+        if (todo && has_item) {
+            // start the slot's next sample (main.rs:68-76)
+            Rng rng;
+            rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
+            rng.draw = 0;
+            V3 o, d;
+            // image origin is upper left, camera origin lower right (main.rs:74-75)
+            primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
+            sn.paths++;
+            s_cur++;
+            if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) {
+                // radiance() with the first query a Miss: light 0 + throughput 1 * background (lib.rs:522-523, :555)
+                const V3 result = v_add(mk(0.0, 0.0, 0.0), v_mul(mk(1.0, 1.0, 1.0), background(sc, d)));
+                acc0 += result.x;
+                acc1 += result.y;
+                acc2 += result.z;
+                acc_write = true;
+                sn.direct++;
             } else {
-                has_item = true;
-                fresh = true;
-                need = false;
+                RaySlot* rs = &wf.slots[slot].ray;
+                rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
+                rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
+                rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
+                wf.slots[slot].hot.key = rng.key;
+                ps->s_cur = s_cur;
+                if (fresh) {
+                    ps->has_item = 1;
+                    ps->item = item;
+                    ps->s_end = s_end;
+                    ps->pix = row << 16 | col;  // both below 2^16 (checked at launch)
+                }
+                if (fresh || acc_write) ps->acc[0] = acc0, ps->acc[1] = acc1, ps->acc[2] = acc2;
+                wf.state[slot] = WF_READY;
+                todo = false;
             }
         }
-        const uint32_t wanted = (uint32_t)__popcll(need_mask);
-        range.next += wanted < avail ? wanted : avail;
-        need_mask = __ballot(need);
-    }
-    if (want && dead) {
-        ps->has_item = 0;
-        wf.state[slot] = WF_DEAD;
-        retired++;
-    }
-    if (want && has_item) {
-        if (!fresh) row = ir.pix >> 16, col = ir.pix & 0xffffu;
-        // start the slot's next sample (main.rs:68-76)
-        Rng rng;
-        rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
-        rng.draw = 0;
-        V3 o, d;
-        // image origin is upper left, camera origin lower right (main.rs:74-75)
-        primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
-        RaySlot* rs = &wf.slots[slot].ray;
-        rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
-        rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
-        rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
-        wf.slots[slot].hot.key = rng.key;
-        ps->s_cur = s_cur + 1u;
-        if (fresh) {
-            ps->has_item = 1;
-            ps->item = item;
-            ps->s_end = s_end;
-            ps->pix = row << 16 | col;  // both below 2^16 (checked at launch)
-            ps->acc[0] = ps->acc[1] = ps->acc[2] = 0.0;
-        } else if (keep_acc) {
-            ps->acc[0] = ir.acc[0], ps->acc[1] = ir.acc[1], ps->acc[2] = ir.acc[2];
-        }
-        wf.state[slot] = WF_READY;
-        n_paths++;
+        if (__ballot(todo) == 0ull) break;
     }
 }
 
+// rays and samples the sample-starting kernels account for, one atomic each per wave
+RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const SampleCount& sn) {
+    wave_atomic_add(&rp.counters->paths, sn.paths);
+    const unsigned long long direct = wave_sum(sn.direct);
+    if ((threadIdx.x & 63u) == 0 && direct) {
+        atomicAdd(&rp.counters->rays, direct);
+        atomicAdd(&rp.counters->escaped_paths, direct);
+        atomicAdd(&rp.counters->direct_rays, direct);
+    }
+    const uint32_t r = (uint32_t)wave_sum(sn.retired);
+    if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
+}
+
 // Initial fill of the pool (every live slot starts IDLE).
-__global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp, WfDev wf) {
+__global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    unsigned long long n_paths = 0;
-    uint32_t retired = 0;
+    SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -324,15 +363,11 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(CameraDev cam, RenderDev rp
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
             const ItemRegs ir = load_item(wf, slot);
-            next_sample(valid, slot, ir, false, cam, rp, wf, range, n_paths, retired);
+            next_sample(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
     store_item_range(wf, wave, range);
-    wave_atomic_add(&rp.counters->paths, n_paths);
-    {
-        const uint32_t r = (uint32_t)wave_sum(retired);
-        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
-    }
+    store_sample_count(rp, wf, sn);
 }
 
 // ------------------------------------------------------------------- trav
@@ -532,8 +567,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    unsigned long long n_paths = 0;
-    uint32_t retired = 0;
+    SampleCount sn{0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -605,17 +639,13 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample(ended, slot, ir, true, cam, rp, wf, range, n_paths, retired);
+            next_sample(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
         have = have_next;
     }
     store_item_range(wf, wave, range);
-    wave_atomic_add(&rp.counters->paths, n_paths);
-    {
-        const uint32_t r = (uint32_t)wave_sum(retired);
-        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
-    }
+    store_sample_count(rp, wf, sn);
 }
 
 // ------------------------------------------------------------------- miss
@@ -645,8 +675,8 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    unsigned long long n_escaped = 0, n_paths = 0;
-    uint32_t retired = 0;
+    unsigned long long n_escaped = 0;
+    SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
@@ -668,18 +698,14 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample(cur.valid, cur.slot, ir, true, cam, rp, wf, range, n_paths, retired);
+        next_sample(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
         cur = nxt;
         have = have_next;
     }
     n_escaped = feed.total;
     store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
-    wave_atomic_add(&rp.counters->paths, n_paths);
-    {
-        const uint32_t r = (uint32_t)wave_sum(retired);
-        if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
-    }
+    store_sample_count(rp, wf, sn);
 }
 
 // ----------------------------------------------------------- launch glue
@@ -695,9 +721,9 @@ hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t wf_launch_gen(const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
-                         hipStream_t stream) {
-    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, cam, rp, wf);
+hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+                         uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 

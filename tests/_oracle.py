@@ -338,6 +338,10 @@ def orthonormal_basis(n):
     return tuple(e1), tuple(e2)
 
 
+def aabb_intersect(box, o, d, tmin, tmax):
+    return bool(lib().orc_aabb_intersect((C.c_double * 6)(*box), d3(o), d3(d), tmin, tmax))
+
+
 def aabb_expand(a, b):
     out = (C.c_double * 6)()
     lib().orc_aabb_expand((C.c_double * 6)(*a), (C.c_double * 6)(*b), out)

@@ -251,3 +251,45 @@ def test_two_pipelines_render_the_same_frame():
     assert np.array_equal(one.view(np.uint64), two.view(np.uint64))
     ref, ost = osc.render(ocam, 16, sample_chunk=4, rows=(120, 136))
     assert np.array_equal(two[120:136].view(np.uint64), ref[120:136].view(np.uint64))
+
+
+def _mesh_from(origin, lookat):
+    def fn():
+        cam_args, objs, heur = scenes.mesh_scene(3, area_light=True)
+        return (origin, cam_args[1], lookat) + tuple(cam_args[3:]), objs, heur
+    return fn
+
+
+def test_primary_rays_that_miss_the_root_box_are_answered_where_they_are_made():
+    """bvh.rs:394: a ray that misses the root Node's box is a Miss at once.  The kernels that start a
+    sample test that box themselves and add the background there (wavefront.hip next_sample) instead of
+    sending the ray through the traversal and miss kernels.  Horizon through the frame: part of the
+    primary rays take that way, part do not, within the same items; the frame, the ray count and the
+    number of escaped paths must not change."""
+    scene, cam, osc, ocam = both(_mesh_from((0.0, 6.0, 10.0), (0.0, 5.5, 0.0)), 64, 48, 12)
+    box = osc.bbox()[0]
+    missed = 0
+    for i in range(0, 48, 4):
+        for j in range(0, 64, 4):
+            o, d = ocam.primary_ray(48 - i, 64 - j, 77 + i * 64 + j)[:2]
+            missed += not _oracle.aabb_intersect(box, o, d, 1e-6, 1e6)
+    assert 0.2 < missed / (12 * 16) < 0.8  # the case is what it says
+    for chunk in (0, 4, 5):
+        img, st = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True, count_work=True)
+        ref, ost = osc.use_walk_tree(scene).render(ocam, 12, 50, sample_chunk=chunk, traversal=2)
+        for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "plane_tests"):
+            assert st[k] == ost[k], (chunk, k)
+        assert 0.3 * 64 * 48 * 12 < st["direct_rays"] < 0.7 * 64 * 48 * 12
+        assert_same_frame(img, ref)
+
+
+def test_a_frame_of_sky_needs_no_path_rounds():
+    """Camera turned away from the scene: every primary ray misses the root box, so every sample is
+    finished by the kernel that starts it; the slots never hold a ray and the frame takes the first batch
+    of (empty) rounds only, however many samples a pixel has."""
+    scene, cam, osc, ocam = both(_mesh_from((0.0, 5.0, 10.0), (0.0, 9.0, 20.0)), 40, 24, 96)
+    img, st = rayrs_amd.render(scene, cam, 96, 50, out_f64=True)  # one item per pixel: 96 samples in a row
+    ref, ost = osc.render(ocam, 96, 50, traversal=0)
+    assert st["rays"] == ost["rays"] == st["paths"] == 40 * 24 * 96 == st["escaped_paths"] == st["direct_rays"]
+    assert st["kernel_launches"] <= 32  # two batches of 16 enqueued before the host sees the pool empty
+    assert_same_frame(img, ref)
