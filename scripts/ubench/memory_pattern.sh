@@ -7,7 +7,7 @@ for n in copy_rate pool_rw pool_coop; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ub/$n $ROOT/scripts/ubench/$n.hip || exit 1
 done
 {
-  echo "## copy_rate: plain dwordx4 copy and in-place read-modify-write, 6 GiB"
+  echo "## copy_rate: streaming rates with ordinary and non-temporal (nt) accesses, 6 GiB buffers"
   /tmp/ub/copy_rate
   echo "## pool_rw: per-lane reads of whole 192-byte slots + 128-byte write-back, windows compacted as the hit kernel does"
   /tmp/ub/pool_rw
