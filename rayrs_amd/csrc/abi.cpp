@@ -255,12 +255,12 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
     HIP_TRY(hipMemcpy(s->d_surfaces, s->surfaces.data(), s->surfaces.size() * sizeof(SurfaceDev),
                       hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&s->d_hdri, f.hdri_rgba.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_rgba.data(), f.hdri_rgba.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&s->d_hdri, f.hdri_quads.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
-                      f.hdri_rgba.size() * sizeof(float);
+                      f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
         if (st != RAYRS_OK) return st;

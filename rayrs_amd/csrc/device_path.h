@@ -763,14 +763,23 @@ RR_DEV uint32_t f64_as_index(double x) {  // Rust `as usize`: NaN and negatives 
     return (uint32_t)x;
 }
 
-RR_DEV V3 hdri_texel(const SceneDev& sc, uint32_t i, uint32_t j) {
-    // Image::pixel would panic out of range (image.rs:183-186); that only
-    // happens for phi == 2*pi or theta == pi, where the weights of the
-    // out-of-range texels are zero.  Clamp.
+// The four texels of a lookup at (i, j): one 64-byte record (scene_host.cpp).  Image::pixel would panic
+// out of range (image.rs:183-186); that only happens for phi == 2*pi or theta == pi, where the weights
+// of the out-of-range texels are zero: the record holds the clamped neighbours.
+struct HdriQuad {
+    V3 f0, f1, f2, f3;  // (i, j), (i+1, j), (i, j+1), (i+1, j+1)
+};
+RR_DEV HdriQuad hdri_quad(const SceneDev& sc, uint32_t i, uint32_t j) {
     if (i >= sc.hdri_h) i = sc.hdri_h - 1;
     if (j >= sc.hdri_w) j = sc.hdri_w - 1;
-    const float4 t = reinterpret_cast<const float4*>(sc.hdri)[(size_t)i * sc.hdri_w + j];
-    return mk((double)t.x, (double)t.y, (double)t.z);
+    const float4* q = reinterpret_cast<const float4*>(sc.hdri) + ((size_t)i * sc.hdri_w + j) * 4;
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    HdriQuad r;
+    r.f0 = mk((double)a.x, (double)a.y, (double)a.z);
+    r.f1 = mk((double)b.x, (double)b.y, (double)b.z);
+    r.f2 = mk((double)c.x, (double)c.y, (double)c.z);
+    r.f3 = mk((double)d.x, (double)d.y, (double)d.z);
+    return r;
 }
 
 // Scene::background, lib.rs:254-285
@@ -783,12 +792,11 @@ RR_DEV V3 background(const SceneDev& sc, V3 dir) {
     const double x_f = rr_floor(x), x_c = rr_ceil(x), y_f = rr_floor(y), y_c = rr_ceil(y);
     const uint32_t i = f64_as_index(y_f);
     const uint32_t j = f64_as_index(x_f);
-    const V3 f0 = hdri_texel(sc, i, j), f1 = hdri_texel(sc, i + 1, j), f2 = hdri_texel(sc, i, j + 1),
-             f3 = hdri_texel(sc, i + 1, j + 1);
-    const V3 a = v_scale(v_scale(f0, x_c - x), y_c - y);
-    const V3 b = v_scale(v_scale(f1, x_c - x), y - y_f);
-    const V3 c = v_scale(v_scale(f2, x - x_f), y_c - y);
-    const V3 e = v_scale(v_scale(f3, x - x_f), y - y_f);
+    const HdriQuad q = hdri_quad(sc, i, j);
+    const V3 a = v_scale(v_scale(q.f0, x_c - x), y_c - y);
+    const V3 b = v_scale(v_scale(q.f1, x_c - x), y - y_f);
+    const V3 c = v_scale(v_scale(q.f2, x - x_f), y_c - y);
+    const V3 e = v_scale(v_scale(q.f3, x - x_f), y - y_f);
     return v_add(v_add(v_add(a, b), c), e);
 }
 

@@ -91,7 +91,7 @@ struct SceneDev {
     const void* nodes;
     const void* prims;
     const SurfaceDev* surfaces;
-    const float* hdri;  // RGBA f32 texels (A unused), clipped to [0,3]
+    const float* hdri;  // per texel (i, j): the 2x2 footprint of a lookup there, 4 x RGBA f32 (A unused), clipped to [0,3]
     uint32_t hdri_w, hdri_h;
     uint32_t root_ref;
     uint32_t stack_depth;  // entries a traversal can have pending (FlatScene::wide_depth)

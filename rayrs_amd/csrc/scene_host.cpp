@@ -701,16 +701,30 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
         rec[dw - 1] = s.kind | (s.axis << 2) | (o.surface << 8);
     }
 
-    // ---- HDRI: clip(0, 3) (main.rs:43; clip = min(max).max(min), vecmath.rs:388-396), RGBA
+    // ---- HDRI: clip(0, 3) (main.rs:43; clip = min(max).max(min), vecmath.rs:388-396), then one record per
+    // texel (i, j) holding the four texels Scene::background reads for it -- (i, j), (i+1, j), (i, j+1),
+    // (i+1, j+1), RGBA f32 each, out-of-range neighbours clamped exactly as device_path.h hdri_texel did --
+    // so that a lookup is ONE aligned 64-byte read instead of two or three 128-byte lines
     f.hdri_w = hdri_w;
     f.hdri_h = hdri_h;
-    f.hdri_rgba.resize((size_t)hdri_w * hdri_h * 4);
-    for (size_t t = 0; t < (size_t)hdri_w * hdri_h; t++) {
-        for (int k = 0; k < 3; k++) {
-            const double v = rr_max(rr_min((double)hdri_rgb[t * 3 + k], 3.0), 0.0);
-            f.hdri_rgba[t * 4 + k] = (float)v;  // v is an f32 value or 0 or 3: exact
+    {
+        std::vector<float> rgb((size_t)hdri_w * hdri_h * 3);
+        for (size_t t = 0; t < rgb.size(); t++) {
+            const double v = rr_max(rr_min((double)hdri_rgb[t], 3.0), 0.0);
+            rgb[t] = (float)v;  // v is an f32 value or 0 or 3: exact
         }
-        f.hdri_rgba[t * 4 + 3] = 0.f;
+        f.hdri_quads.assign((size_t)hdri_w * hdri_h * 16, 0.f);
+        for (uint32_t i = 0; i < hdri_h; i++) {
+            const uint32_t i1 = i + 1 < hdri_h ? i + 1 : hdri_h - 1;
+            for (uint32_t j = 0; j < hdri_w; j++) {
+                const uint32_t j1 = j + 1 < hdri_w ? j + 1 : hdri_w - 1;
+                const size_t src[4] = {(size_t)i * hdri_w + j, (size_t)i1 * hdri_w + j, (size_t)i * hdri_w + j1,
+                                       (size_t)i1 * hdri_w + j1};
+                float* q = &f.hdri_quads[((size_t)i * hdri_w + j) * 16];
+                for (int k = 0; k < 4; k++)
+                    for (int c = 0; c < 3; c++) q[k * 4 + c] = rgb[src[k] * 3 + c];
+            }
+        }
     }
 
     f.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

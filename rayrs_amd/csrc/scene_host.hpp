@@ -62,7 +62,7 @@ struct FlatScene {
     // device images
     std::vector<uint8_t> node_bytes;
     std::vector<uint8_t> prim_bytes;
-    std::vector<float> hdri_rgba;
+    std::vector<float> hdri_quads;  // 16 floats per texel: the 2x2 footprint of a lookup at (i, j), RGBA each
     uint32_t hdri_w = 0, hdri_h = 0;
     double t0 = 0, t1 = 0;
     double build_seconds = 0;
