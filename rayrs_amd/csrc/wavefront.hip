@@ -75,16 +75,36 @@ RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint
 // bytes of the following window are loaded while the current one is being worked on, and the
 // kernels fetch batch b + 1's slot records before they compute batch b, so that a wave waits
 // for memory once per batch (the record that depends on the slot's contents) instead of three
-// times.
+// times.  Fewer than 64 slots left over from a window are carried into the next one's list (the
+// list holds pool-wide slot indices), so every batch but a wave's last is full: at the headline
+// frame's 58 % / 34 % of a window that is 4.6 instead of 5 and 2.7 instead of 3 batches per window.
+constexpr uint32_t FEED_LIST = WINDOW + 64;  // entries per wave
+
 struct BatchFeed {
-    uint32_t win, next_win, n_waves, n_windows, count, k, total;  // wave-uniform
-    StateWords ahead;                                            // state bytes of window next_win
+    uint32_t next_win, n_waves, n_windows, count, k, total;  // wave-uniform
+    StateWords ahead;                                        // state bytes of window next_win
     uint8_t want;
-    uint16_t* list;
+    uint32_t* list;
 };
 
-RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_waves, uint8_t want, uint16_t* list) {
-    f.win = 0, f.next_win = wave, f.n_waves = n_waves, f.n_windows = wf.np / WINDOW;
+RR_DEV uint32_t compact_words_abs(const StateWords& sw, uint8_t want, uint32_t base, uint32_t* list) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    const uint32_t* words = sw.w;
+    uint32_t count = 0;
+#pragma unroll
+    for (int j = 0; j < (int)SPL; j++) {
+        const uint32_t s = (words[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+        const bool m = s == (uint32_t)want;
+        const unsigned long long mask = __ballot(m);
+        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = base + lane * SPL + (uint32_t)j;
+        count += (uint32_t)__popcll(mask);
+    }
+    return count;
+}
+
+RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_waves, uint8_t want, uint32_t* list) {
+    f.next_win = wave, f.n_waves = n_waves, f.n_windows = wf.np / WINDOW;
     f.count = 0, f.k = 0, f.total = 0, f.want = want, f.list = list;
     f.ahead.w[0] = f.ahead.w[1] = 0;
     if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
@@ -93,17 +113,20 @@ RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_w
 // Next batch: false when the wave's windows are exhausted.
 RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid) {
     const uint32_t lane = threadIdx.x & 63u;
-    while (f.k >= f.count) {
-        if (f.next_win >= f.n_windows) return false;
-        f.win = f.next_win;
-        f.next_win += f.n_waves;
-        f.count = compact_words(f.ahead, f.want, f.list);
-        f.total += f.count;
+    while (f.count - f.k < 64u && f.next_win < f.n_windows) {
+        const uint32_t left = f.count - f.k;  // < 64: one entry per lane, moved to the front
+        const uint32_t carry = lane < left ? f.list[f.k + lane] : 0u;
+        if (lane < left) f.list[lane] = carry;
+        const uint32_t fresh = compact_words_abs(f.ahead, f.want, f.next_win * WINDOW, f.list + left);
+        f.total += fresh;
+        f.count = left + fresh;
         f.k = 0;
+        f.next_win += f.n_waves;
         if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
     }
+    if (f.k >= f.count) return false;
     valid = f.k + lane < f.count;
-    slot = f.win * WINDOW + (valid ? (uint32_t)f.list[f.k + lane] : 0u);
+    slot = valid ? f.list[f.k + lane] : 0u;
     f.k += 64u;
     return true;
 }
@@ -555,7 +578,7 @@ RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0:
 
 template <bool COMPACT>
 __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
-    __shared__ uint16_t lists[4][WINDOW];
+    __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
     // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
     __shared__ SurfaceDev s_surf[HIT_SURFACES_LDS];
@@ -564,7 +587,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     for (uint32_t i = threadIdx.x; i < n_surf_lds * (uint32_t)(sizeof(SurfaceDev) / 4); i += 256u)
         reinterpret_cast<uint32_t*>(s_surf)[i] = reinterpret_cast<const uint32_t*>(sc.surfaces)[i];
     __syncthreads();
-    uint16_t* list = lists[threadIdx.x >> 6];
+    uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     SampleCount sn{0, 0, 0};
@@ -669,10 +692,10 @@ RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 
 }
 
 __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
-    __shared__ uint16_t lists[4][WINDOW];
+    __shared__ uint32_t lists[4][FEED_LIST];
     if (wf.ctl->live_slots == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
-    uint16_t* list = lists[threadIdx.x >> 6];
+    uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
