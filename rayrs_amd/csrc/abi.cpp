@@ -428,10 +428,11 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
-    RAYRS_STRUCT(rayrs_tuning, 8);
+    RAYRS_STRUCT(rayrs_tuning, 9);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
+    RAYRS_FIELD(rayrs_tuning, wide_slots);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -573,6 +574,12 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
     if (static_pct > 100) static_pct = 100;
 
+    // The path slot: one 128-byte line when no surface of the scene emits (then a path's light is +0 or NaN
+    // per component, three bits: wavefront.h LeanSlot), 192 bytes otherwise.
+    bool lean = !scene->tuning.wide_slots && params->spp <= LEAN_SAMPLE_MASK;
+    for (const SurfaceDev& sf : scene->surfaces)
+        if (sf.emit[0] != 0.0 || sf.emit[1] != 0.0 || sf.emit[2] != 0.0) lean = false;
+    const uint32_t slot_bytes = lean ? (uint32_t)sizeof(LeanSlot) : (uint32_t)sizeof(Slot);
     hipStream_t streams[2] = {stream, scene->aux_stream};
     WfDev wfs[2];
     RenderDev rps[2];
@@ -582,16 +589,17 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         const uint64_t live64 = live_total / n_pipes + (p < live_total % n_pipes ? 1u : 0u);
         const uint32_t np = (uint32_t)((live64 + 1023ull) & ~1023ull);  // whole windows
         lives[p] = (uint32_t)live64;
-        if (np > pl.block_slots || !pl.block) {
+        const size_t block_bytes = (size_t)np * (slot_bytes + 1u);
+        if (block_bytes > pl.block_bytes || !pl.block) {
             if (pl.block) HIP_TRY(hipFree(pl.block));
             pl.block = nullptr;
-            pl.block_slots = 0;
-            HIP_TRY(hipMalloc(&pl.block, (size_t)np * (sizeof(Slot) + 1)));
-            uint8_t* b = static_cast<uint8_t*>(pl.block);
-            pl.wf.slots = reinterpret_cast<Slot*>(b);
-            pl.wf.state = b + (size_t)np * sizeof(Slot);
-            pl.block_slots = np;
+            pl.block_bytes = 0;
+            HIP_TRY(hipMalloc(&pl.block, block_bytes));
+            pl.block_bytes = block_bytes;
         }
+        pl.wf.slots = static_cast<unsigned char*>(pl.block);
+        pl.wf.slot_bytes = slot_bytes;
+        pl.wf.state = pl.wf.slots + (size_t)np * slot_bytes;
         WfDev wf = pl.wf;
         wf.np = np;
         RenderDev r = rp;

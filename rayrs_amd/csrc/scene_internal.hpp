@@ -42,7 +42,7 @@ struct rayrs_scene {
     struct Pipeline {
         rayrs::WfDev wf = {};
         void* block = nullptr;       // one allocation holding the slot records and the state bytes
-        uint32_t block_slots = 0;
+        size_t block_bytes = 0;
         unsigned long long* d_wave_items = nullptr;
         uint32_t wave_items_cap = 0;
         uint32_t* d_stack_spill = nullptr;

@@ -41,7 +41,7 @@ struct ItemSlot {
 };
 static_assert(sizeof(ItemSlot) == 48, "ItemSlot");
 
-// One slot = 192 contiguous bytes.  Random 64-byte accesses to HBM run at ~0.9 TB/s on this
+// The wide slot = 192 contiguous bytes.  Random 64-byte accesses to HBM run at ~0.9 TB/s on this
 // chip against ~6 TB/s streamed (scripts/ubench/fetch_calib.hip), i.e. the number of separate
 // DRAM rows a kernel opens per slot matters more than the bytes it moves: keeping the three
 // records of a slot adjacent makes a slot one row activation per kernel.
@@ -52,6 +52,26 @@ struct Slot {
     uint64_t pad[2];
 };
 static_assert(sizeof(Slot) == 192, "Slot");
+
+// The lean slot = ONE 128-byte line, for scenes in which nothing emits (every surface's Emission::emit() is
+// exactly zero; an HDRI-lit scene).  There `light` (lib.rs:523, :534) is +0 + throughput * 0 at every hit: a
+// component of it is +0, or NaN once the throughput's component stopped being finite -- one bit each.  The
+// sample's RNG key is recomputed from the pixel and the sample index (in both layouts).  What is left fits
+// the half line behind the ray: throughput, the item's sum and its four identifying words.
+struct LeanTail {
+    double thr[3];
+    double acc[3];
+    uint32_t item;
+    uint32_t s_cur;  // next sample to start (28 bits) | LEAN_LIGHT_NAN << 28 (x, y, z) | has_item << 31
+    uint32_t s_end;
+    uint32_t pix;
+};
+struct LeanSlot {
+    RaySlot ray;
+    LeanTail tail;
+};
+static_assert(sizeof(LeanSlot) == 128, "LeanSlot");
+constexpr uint32_t LEAN_SAMPLE_MASK = (1u << 28) - 1u;  // samples per pixel the lean layout can count
 
 // slot states
 constexpr uint8_t WF_IDLE = 0;   // no path in flight: gen_kernel's input
@@ -67,7 +87,9 @@ struct WfCtl {
 };
 
 struct WfDev {
-    Slot* slots;
+    unsigned char* slots;  // np slots of slot_bytes each; every layout starts with the RaySlot
+    uint32_t slot_bytes;   // sizeof(Slot) or sizeof(LeanSlot)
+    uint32_t pad_;
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024
@@ -83,6 +105,7 @@ struct WfDev {
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
+// the gen, hit and miss kernels exist for both slot layouts (wf.slot_bytes says which)
 hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,

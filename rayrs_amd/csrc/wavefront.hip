@@ -173,6 +173,13 @@ RR_DEV void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uin
     s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
 }
 
+// Slot addressing.  Both layouts (wavefront.h) start with the RaySlot; the traversal kernel uses nothing else.
+RR_DEV RaySlot* ray_slot(const WfDev& wf, uint32_t slot) {
+    return reinterpret_cast<RaySlot*>(wf.slots + (size_t)slot * wf.slot_bytes);
+}
+RR_DEV Slot* wide_slot(const WfDev& wf, uint32_t slot) { return reinterpret_cast<Slot*>(wf.slots) + slot; }
+RR_DEV LeanSlot* lean_slot(const WfDev& wf, uint32_t slot) { return reinterpret_cast<LeanSlot*>(wf.slots) + slot; }
+
 // ------------------------------------------------------------------- init
 
 __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
@@ -185,7 +192,8 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
-    wf.slots[i].item.has_item = 0;
+    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot)) lean_slot(wf, i)->tail.s_cur = 0;
+    else wide_slot(wf, i)->item.has_item = 0;
 }
 
 // -------------------------------------------------------------------- gen
@@ -201,14 +209,30 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
 struct ItemRegs {
     double acc[3];
     uint32_t item, s_cur, s_end, has_item, pix;
+    uint32_t light_nan;  // lean layout: bit k = component k of the path's light is NaN (else +0)
 };
 
+template <bool LEAN>
 RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
-    const ItemSlot* is = &wf.slots[slot].item;
     ItemRegs r;
-    r.acc[0] = is->acc[0], r.acc[1] = is->acc[1], r.acc[2] = is->acc[2];
-    r.item = is->item, r.s_cur = is->s_cur, r.s_end = is->s_end, r.has_item = is->has_item, r.pix = is->pix;
+    if (LEAN) {
+        const LeanTail* t = &lean_slot(wf, slot)->tail;
+        r.acc[0] = t->acc[0], r.acc[1] = t->acc[1], r.acc[2] = t->acc[2];
+        const uint32_t w = t->s_cur;
+        r.item = t->item, r.s_cur = w & LEAN_SAMPLE_MASK, r.s_end = t->s_end, r.has_item = w >> 31, r.pix = t->pix;
+        r.light_nan = (w >> 28) & 7u;
+    } else {
+        const ItemSlot* is = &wide_slot(wf, slot)->item;
+        r.acc[0] = is->acc[0], r.acc[1] = is->acc[1], r.acc[2] = is->acc[2];
+        r.item = is->item, r.s_cur = is->s_cur, r.s_end = is->s_end, r.has_item = is->has_item, r.pix = is->pix;
+        r.light_nan = 0;
+    }
     return r;
+}
+
+// The RNG key of the sample a slot has in flight: the item's pixel and the sample before its cursor.
+RR_DEV uint64_t sample_key(const RenderDev& rp, const CameraDev& cam, const ItemRegs& ir) {
+    return rr_path_key(rp.seed, (uint64_t)(ir.pix >> 16) * cam.W + (ir.pix & 0xffffu), (uint64_t)(ir.s_cur - 1u));
 }
 
 // A wave's private range of reserved item ids [next, end).  Items are taken from the
@@ -247,12 +271,12 @@ struct SampleCount {
 // sending the ray through the traversal and miss kernels for the same answer: the lane goes on to the
 // item's next sample, and to the next item, until it holds a ray that enters the root box.  From the
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
+template <bool LEAN>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
                         const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
                         SampleCount& sn) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    ItemSlot* ps = &wf.slots[slot].item;
     bool todo = want;  // lanes still without a ray for their slot
     bool has_item = want && ir.has_item != 0u;
     uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
@@ -312,7 +336,8 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             need_mask = __ballot(need);
         }
         if (todo && dead) {
-            ps->has_item = 0;
+            if (LEAN) lean_slot(wf, slot)->tail.s_cur = 0;
+            else wide_slot(wf, slot)->item.has_item = 0;
             wf.state[slot] = WF_DEAD;
             sn.retired++;
             todo = false;
@@ -336,19 +361,30 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                 acc_write = true;
                 sn.direct++;
             } else {
-                RaySlot* rs = &wf.slots[slot].ray;
+                RaySlot* rs = ray_slot(wf, slot);
                 rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
                 rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
                 rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
-                wf.slots[slot].hot.key = rng.key;
-                ps->s_cur = s_cur;
-                if (fresh) {
-                    ps->has_item = 1;
-                    ps->item = item;
-                    ps->s_end = s_end;
-                    ps->pix = row << 16 | col;  // both below 2^16 (checked at launch)
+                if (LEAN) {
+                    LeanTail* t = &lean_slot(wf, slot)->tail;
+                    t->s_cur = s_cur | (1u << 31);  // has an item; the light's NaN bits start clear
+                    if (fresh) {
+                        t->item = item;
+                        t->s_end = s_end;
+                        t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
+                    }
+                    if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
+                } else {
+                    ItemSlot* ps = &wide_slot(wf, slot)->item;
+                    ps->s_cur = s_cur;
+                    if (fresh) {
+                        ps->has_item = 1;
+                        ps->item = item;
+                        ps->s_end = s_end;
+                        ps->pix = row << 16 | col;
+                    }
+                    if (fresh || acc_write) ps->acc[0] = acc0, ps->acc[1] = acc1, ps->acc[2] = acc2;
                 }
-                if (fresh || acc_write) ps->acc[0] = acc0, ps->acc[1] = acc1, ps->acc[2] = acc2;
                 wf.state[slot] = WF_READY;
                 todo = false;
             }
@@ -371,6 +407,7 @@ RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const Sampl
 }
 
 // Initial fill of the pool (every live slot starts IDLE).
+template <bool LEAN>
 __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
@@ -385,8 +422,8 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            const ItemRegs ir = load_item(wf, slot);
-            next_sample(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
+            const ItemRegs ir = load_item<LEAN>(wf, slot);
+            next_sample<LEAN>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -454,7 +491,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
             // ---- retire finished queries: result and new state to the slot
             if (pending) {
-                RaySlot* rs = &wf.slots[slot].ray;
+                RaySlot* rs = ray_slot(wf, slot);
                 rs->t = tv.best_t;
                 rs->prim = tv.best_prim;
                 wf.state[slot] = tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
@@ -486,7 +523,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                 const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
                 if (need && rank < avail) {
                     slot = list_base + (uint32_t)list[list_pos + rank];
-                    const RaySlot* rs = &wf.slots[slot].ray;
+                    const RaySlot* rs = ray_slot(wf, slot);
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
@@ -555,28 +592,42 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
 struct HitIn {
     uint32_t slot;
     bool valid;
-    V3 o, d, thr, light;
+    V3 o, d, thr, light;  // light: wide layout only (the lean one keeps ir.light_nan)
     double t;
     uint32_t prim, bd;
-    uint64_t key;
     ItemRegs ir;
 };
 
+// A path's light in the lean layout: +0, or NaN where the bit says so (wavefront.h LeanTail).
+RR_DEV V3 lean_light(uint32_t nan_bits) {
+    const double q = __builtin_nan("");
+    return mk(nan_bits & 1u ? q : 0.0, nan_bits & 2u ? q : 0.0, nan_bits & 4u ? q : 0.0);
+}
+RR_DEV uint32_t lean_light_bits(V3 light) {
+    return (light.x != light.x ? 1u : 0u) | (light.y != light.y ? 2u : 0u) | (light.z != light.z ? 4u : 0u);
+}
+
+template <bool LEAN>
 RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0: harmless
-    const RaySlot* rs = &wf.slots[h.slot].ray;
-    const HotSlot* hs = &wf.slots[h.slot].hot;
+    const RaySlot* rs = ray_slot(wf, h.slot);
     h.o = mk(rs->o[0], rs->o[1], rs->o[2]);
     h.d = mk(rs->d[0], rs->d[1], rs->d[2]);
     h.t = rs->t;
     h.prim = rs->prim;
     h.bd = rs->bd;
-    h.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-    h.light = mk(hs->light[0], hs->light[1], hs->light[2]);
-    h.key = hs->key;
-    h.ir = load_item(wf, h.slot);
+    if (LEAN) {
+        const LeanTail* t = &lean_slot(wf, h.slot)->tail;
+        h.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
+        h.light = mk(0.0, 0.0, 0.0);
+    } else {
+        const HotSlot* hs = &wide_slot(wf, h.slot)->hot;
+        h.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+        h.light = mk(hs->light[0], hs->light[1], hs->light[2]);
+    }
+    h.ir = load_item<LEAN>(wf, h.slot);
 }
 
-template <bool COMPACT>
+template <bool COMPACT, bool LEAN>
 __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
@@ -597,11 +648,11 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     feed_init(feed, wf, wave, n_waves, WF_HIT, list);
     HitIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
-    if (have) load_hit_in(wf, cur);
+    if (have) load_hit_in<LEAN>(wf, cur);
     while (have) {
         HitIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_hit_in(wf, nxt);
+        if (have_next) load_hit_in<LEAN>(wf, nxt);
         {
             const uint32_t slot = cur.slot;
             const bool valid = cur.valid;
@@ -609,8 +660,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             uint32_t hit_sid = 8u;
             ItemRegs ir = cur.ir;
             if (valid) {
-            RaySlot* rs = &wf.slots[slot].ray;
-            HotSlot* hs = &wf.slots[slot].hot;
+            RaySlot* rs = ray_slot(wf, slot);
             const V3 o = cur.o;
             const V3 d = cur.d;
             const double t = cur.t;
@@ -618,8 +668,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             const uint32_t bounce = cur.bd & 0xffffu;
             // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
             V3 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
-            V3 light = bounce > 1u ? cur.light : mk(0.0, 0.0, 0.0);
-            Rng rng{cur.key, cur.bd >> 16};
+            V3 light = bounce > 1u ? (LEAN ? lean_light(ir.light_nan) : cur.light) : mk(0.0, 0.0, 0.0);
+            Rng rng{sample_key(rp, cam, ir), cur.bd >> 16};
             // lib.rs:528-551
             const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
             const V3 position = v_add(o, v_scale(d, t));
@@ -642,8 +692,15 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
                     rs->d[0] = ev.dir.x, rs->d[1] = ev.dir.y, rs->d[2] = ev.dir.z;
                     rs->bd = (bounce + 1u) | (rng.draw << 16);
-                    hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
-                    hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
+                    if (LEAN) {
+                        LeanTail* lt = &lean_slot(wf, slot)->tail;
+                        lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
+                        lt->s_cur = ir.s_cur | (lean_light_bits(light) << 28) | (1u << 31);
+                    } else {
+                        HotSlot* hs = &wide_slot(wf, slot)->hot;
+                        hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
+                        hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
+                    }
                     wf.state[slot] = WF_READY;
                 }
             } else {
@@ -662,7 +719,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
+            next_sample<LEAN>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
         have = have_next;
@@ -681,16 +738,24 @@ struct MissIn {
     ItemRegs ir;
 };
 
+template <bool LEAN>
 RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 0: harmless
-    const RaySlot* rs = &wf.slots[m.slot].ray;
-    const HotSlot* hs = &wf.slots[m.slot].hot;
+    const RaySlot* rs = ray_slot(wf, m.slot);
     m.d = mk(rs->d[0], rs->d[1], rs->d[2]);
     m.bd = rs->bd;
-    m.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-    m.light = mk(hs->light[0], hs->light[1], hs->light[2]);
-    m.ir = load_item(wf, m.slot);
+    m.ir = load_item<LEAN>(wf, m.slot);
+    if (LEAN) {
+        const LeanTail* t = &lean_slot(wf, m.slot)->tail;
+        m.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
+        m.light = lean_light(m.ir.light_nan);
+    } else {
+        const HotSlot* hs = &wide_slot(wf, m.slot)->hot;
+        m.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
+        m.light = mk(hs->light[0], hs->light[1], hs->light[2]);
+    }
 }
 
+template <bool LEAN>
 __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     if (wf.ctl->live_slots == 0u) return;
@@ -705,11 +770,11 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
-    if (have) load_miss_in(wf, cur);
+    if (have) load_miss_in<LEAN>(wf, cur);
     while (have) {
         MissIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_miss_in(wf, nxt);
+        if (have_next) load_miss_in<LEAN>(wf, nxt);
         ItemRegs ir = cur.ir;
         if (cur.valid) {
             // throughput and light are loaded unconditionally and ignored while bounce == 1 (lib.rs:522-523)
@@ -721,7 +786,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        next_sample<LEAN>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
         cur = nxt;
         have = have_next;
     }
@@ -746,7 +811,10 @@ hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
 
 hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot))
+        hipLaunchKernelGGL(wf_gen_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else
+        hipLaunchKernelGGL(wf_gen_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 
@@ -783,16 +851,24 @@ hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_reco
 
 hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream) {
-    if (compact)
-        hipLaunchKernelGGL(wf_hit_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    const bool lean = wf.slot_bytes == (uint32_t)sizeof(LeanSlot);
+    if (compact && lean)
+        hipLaunchKernelGGL((wf_hit_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else if (compact)
+        hipLaunchKernelGGL((wf_hit_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else if (lean)
+        hipLaunchKernelGGL((wf_hit_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else
-        hipLaunchKernelGGL(wf_hit_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 
 hipError_t wf_launch_miss(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_miss_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot))
+        hipLaunchKernelGGL(wf_miss_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else
+        hipLaunchKernelGGL(wf_miss_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 

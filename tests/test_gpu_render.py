@@ -354,3 +354,20 @@ def test_random_scenes_render_the_oracles_frame(seed):
     ref0, ost0 = osc.render(ocam, 6, 50, seed=seed, sample_chunk=chunk, traversal=0)  # the reference's recursion
     assert ost0["rays"] == st["rays"]
     assert_same_frame(img, ref0)
+
+
+def test_lean_and_wide_path_slots_render_the_same_frame():
+    """A scene in which nothing emits keeps a path in one 128-byte line (no light accumulator: the light is
+    +0 or NaN per component, three bits; the sample's RNG key is recomputed) -- wavefront.h LeanSlot.
+    rayrs_tuning.wide_slots forces the 192-byte slot every scene with an emitter uses: same frame, same
+    counts, both the oracle's."""
+    for fn, chunk in ((lambda: scenes.mesh_scene(3), 4), (scenes.material_test, 0), (scenes.glass_single_sphere, 5)):
+        scene, cam, osc, ocam = both(fn, 72, 40, 12)
+        lean, st1 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
+        scene.set_tuning(wide_slots=1)
+        wide, st2 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
+        ref, ost = osc.render(ocam, 12, 50, sample_chunk=chunk, traversal=0)
+        for k in ("rays", "paths", "escaped_paths", "nan_pixels", "neg_pixels"):
+            assert st1[k] == st2[k] == ost[k], k
+        assert_same_frame(lean, ref)
+        assert_same_frame(wide, ref)
