@@ -502,39 +502,78 @@ struct WalkBuilder {
     }
 };
 
-// One record of up to four slots per call: the node's two children, then twice the interior
-// slot with the largest box replaced by its two children.  Returns the record's reference;
+// Which nodes of the binary tree become four-slot records, and which are opened inside their parent's
+// record, is chosen to minimise the expected number of records a ray reads: a record behind a box of
+// area A is read with probability ~ A / A(root), so cost(n as a record) = A(n) + the best way to spend
+// four slots on n's two subtrees, where a subtree given j slots either is one record (one slot) or is
+// opened and splits its j slots between its own children -- the dynamic programme of Ylitie et al. 2017,
+// with zero cost for the leaf slots (a group's gating box is tested in the record that holds it).
+struct WideCollapse {
+    const std::vector<WalkNode>& nodes;
+    std::vector<float> cost;    // [n * 4 + (j - 1)]: subtree n in at most j slots
+    std::vector<uint8_t> used;  // [n * 4 + (j - 1)]: slots it actually takes (1 = a record of its own)
+    std::vector<uint8_t> argk;  // [n * 4 + (j - 1)]: of `used` slots, how many go to the left child
+
+    explicit WideCollapse(const std::vector<WalkNode>& nd) : nodes(nd) {
+        const size_t n = nd.size();
+        cost.assign(n * 4, 0.f), used.assign(n * 4, 1), argk.assign(n * 4, 0);
+        for (size_t i = n; i-- > 0;) {  // children were created after their parent
+            const WalkNode& w = nd[i];
+            if (w.left < 0) continue;  // a group: no record, no cost
+            float d[5];
+            uint8_t dk[5];
+            for (int j = 2; j <= 4; j++) {
+                d[j] = std::numeric_limits<float>::infinity(), dk[j] = 1;
+                for (int k = 1; k < j; k++) {
+                    const float c = cost[(size_t)w.left * 4 + (k - 1)] + cost[(size_t)w.right * 4 + (j - k - 1)];
+                    if (c < d[j]) d[j] = c, dk[j] = (uint8_t)k;
+                }
+            }
+            cost[i * 4] = (float)box_area(w.box) + d[4];
+            used[i * 4] = 1, argk[i * 4] = dk[4];  // as a record: its four slots split dk[4] : 4 - dk[4]
+            for (int j = 2; j <= 4; j++) {
+                if (d[j] < cost[i * 4 + (j - 2)]) cost[i * 4 + (j - 1)] = d[j], used[i * 4 + (j - 1)] = (uint8_t)j, argk[i * 4 + (j - 1)] = dk[j];
+                else cost[i * 4 + (j - 1)] = cost[i * 4 + (j - 2)], used[i * 4 + (j - 1)] = used[i * 4 + (j - 2)], argk[i * 4 + (j - 1)] = argk[i * 4 + (j - 2)];
+            }
+        }
+    }
+
+    // the slots subtree n fills when it is given j of them
+    void expand(int32_t n, int j, int32_t* slots, int& ns) const {
+        const WalkNode& w = nodes[n];
+        if (w.left < 0 || used[(size_t)n * 4 + (j - 1)] == 1) {
+            slots[ns++] = n;
+            return;
+        }
+        const int u = used[(size_t)n * 4 + (j - 1)], k = argk[(size_t)n * 4 + (j - 1)];
+        expand(w.left, k, slots, ns);
+        expand(w.right, u - k, slots, ns);
+    }
+};
+
+// One record per call: the slots the collapse gives node n's two subtrees.  Returns the record's reference;
 // *stack_need is the number of stack entries a traversal below it can have pending.
-uint32_t emit_wide(FlatScene& f, const std::vector<WalkNode>& nodes, int32_t n, uint32_t* stack_need) {
+uint32_t emit_wide(FlatScene& f, const WideCollapse& wc, int32_t n, uint32_t* stack_need) {
+    const std::vector<WalkNode>& nodes = wc.nodes;
     const uint32_t rec = f.n_wide();
     f.wide_ref.resize(f.wide_ref.size() + 4, REF_NONE << 30);
     f.wide_box.resize(f.wide_box.size() + 24, 0.0);
-    int32_t slots[4] = {nodes[n].left, nodes[n].right, -1, -1};
-    int ns = 2;
-    while (ns < 4) {
-        int pick = -1;
-        double pick_area = -1.0;
-        for (int i = 0; i < ns; i++) {
-            if (nodes[slots[i]].left < 0) continue;
-            const double a = box_area(nodes[slots[i]].box);
-            if (a > pick_area) pick_area = a, pick = i;
-        }
-        if (pick < 0) break;
-        const int32_t open = slots[pick];
-        slots[pick] = nodes[open].left;
-        slots[ns++] = nodes[open].right;
-    }
+    int32_t slots[4] = {-1, -1, -1, -1};
+    int ns = 0;
+    const int k = wc.argk[(size_t)n * 4];
+    wc.expand(nodes[n].left, k, slots, ns);
+    wc.expand(nodes[n].right, 4 - k, slots, ns);
     uint32_t below = 0;
     for (int i = 0; i < ns; i++) {
         const WalkNode& c = nodes[slots[i]];
         uint32_t ref = c.ref;
         if (c.left >= 0) {
             uint32_t need = 0;
-            ref = emit_wide(f, nodes, slots[i], &need);
+            ref = emit_wide(f, wc, slots[i], &need);
             if (need > below) below = need;
         }
         f.wide_ref[(size_t)rec * 4 + i] = ref;
-        for (int k = 0; k < 6; k++) f.wide_box[((size_t)rec * 4 + i) * 6 + k] = c.box[k];
+        for (int q = 0; q < 6; q++) f.wide_box[((size_t)rec * 4 + i) * 6 + q] = c.box[q];
     }
     *stack_need = (uint32_t)(ns - 1) + below;
     return (REF_INTERIOR << 30) | rec;
@@ -554,7 +593,8 @@ void build_walk_tree(FlatScene& f) {
     b.build();
     f.wide_box.reserve(groups.size() * 12);
     f.wide_ref.reserve(groups.size() * 2);
-    f.wide_root_ref = emit_wide(f, b.nodes, 0, &f.wide_depth);
+    const WideCollapse wc(b.nodes);
+    f.wide_root_ref = emit_wide(f, wc, 0, &f.wide_depth);
 }
 
 void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
