@@ -502,6 +502,20 @@ struct WalkBuilder {
     }
 };
 
+// children before parents
+std::vector<int32_t> post_order(const std::vector<WalkNode>& nodes) {
+    std::vector<int32_t> order, stack{0};
+    order.reserve(nodes.size());
+    while (!stack.empty()) {  // pre-order with right before left, reversed below
+        const int32_t n = stack.back();
+        stack.pop_back();
+        order.push_back(n);
+        if (nodes[n].left >= 0) stack.push_back(nodes[n].left), stack.push_back(nodes[n].right);
+    }
+    std::reverse(order.begin(), order.end());
+    return order;
+}
+
 // Which nodes of the binary tree become four-slot records, and which are opened inside their parent's
 // record, is chosen to minimise the expected number of records a ray reads: a record behind a box of
 // area A is read with probability ~ A / A(root), so cost(n as a record) = A(n) + the best way to spend
@@ -517,7 +531,8 @@ struct WideCollapse {
     explicit WideCollapse(const std::vector<WalkNode>& nd) : nodes(nd) {
         const size_t n = nd.size();
         cost.assign(n * 4, 0.f), used.assign(n * 4, 1), argk.assign(n * 4, 0);
-        for (size_t i = n; i-- > 0;) {  // children were created after their parent
+        for (const int32_t ni : post_order(nd)) {
+            const size_t i = (size_t)ni;
             const WalkNode& w = nd[i];
             if (w.left < 0) continue;  // a group: no record, no cost
             float d[5];
