@@ -646,71 +646,88 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_HIT, list);
+    // Three fetches per hit depend on each other: slot -> primitive record -> surface row.  The slot records of
+    // batch b + 1 are requested before batch b is computed; the primitive records of batch b + 1 as soon as batch
+    // b's arithmetic is done -- before batch b's stores, so that the wait for them is not behind the stores
+    // (memory operations of a wave complete in order); the surface rows wait in LDS.
     HitIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
-    if (have) load_hit_in<LEAN>(wf, cur);
+    PrimRec<COMPACT> rec_cur;
+    if (have) {
+        load_hit_in<LEAN>(wf, cur);
+        rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
+    }
     while (have) {
         HitIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
         if (have_next) load_hit_in<LEAN>(wf, nxt);
+        PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
             const bool valid = cur.valid;
-            bool ended = false;
+            bool ended = false, goes_on = false;
             uint32_t hit_sid = 8u;
             ItemRegs ir = cur.ir;
+            V3 thr = mk(1.0, 1.0, 1.0), light = mk(0.0, 0.0, 0.0), position = mk(0.0, 0.0, 0.0), dir = mk(0.0, 0.0, 1.0);
+            uint32_t bd_next = 0;
             if (valid) {
-            RaySlot* rs = ray_slot(wf, slot);
-            const V3 o = cur.o;
-            const V3 d = cur.d;
-            const double t = cur.t;
-            const uint32_t prim = cur.prim;
-            const uint32_t bounce = cur.bd & 0xffffu;
-            // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
-            V3 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
-            V3 light = bounce > 1u ? (LEAN ? lean_light(ir.light_nan) : cur.light) : mk(0.0, 0.0, 0.0);
-            Rng rng{sample_key(rp, cam, ir), cur.bd >> 16};
-            // lib.rs:528-551
-            const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
-            const V3 position = v_add(o, v_scale(d, t));
-            const V3 normal = prim_normal<COMPACT>(rec, position);
-            const V3 view = v_unit(v_scale(d, -1.0));
-            const uint32_t sid = rec.tag() >> 8;
-            hit_sid = sid < 7u ? sid : 7u;
-            const SurfaceDev* surf = sid < n_surf_lds ? &s_surf[sid] : sc.surfaces + sid;
-            const Scatter ev = material_evaluate(surf, normal, view, rng);
-            if (ev.scatter) {
-                light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
-                thr = v_mul(thr, ev.color);
-                const double p = rr_max(rr_max(thr.x, thr.y), thr.z);
-                if (rng.next() > p) {
-                    ended = true;
-                } else if (bounce >= rp.max_bounces) {  // loop bound of lib.rs:525; lib.rs:559
-                    ended = true;
-                } else {
-                    thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
-                    rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
-                    rs->d[0] = ev.dir.x, rs->d[1] = ev.dir.y, rs->d[2] = ev.dir.z;
-                    rs->bd = (bounce + 1u) | (rng.draw << 16);
-                    if (LEAN) {
-                        LeanTail* lt = &lean_slot(wf, slot)->tail;
-                        lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
-                        lt->s_cur = ir.s_cur | (lean_light_bits(light) << 28) | (1u << 31);
+                const V3 o = cur.o;
+                const V3 d = cur.d;
+                const double t = cur.t;
+                const uint32_t bounce = cur.bd & 0xffffu;
+                // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
+                thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
+                light = bounce > 1u ? (LEAN ? lean_light(ir.light_nan) : cur.light) : mk(0.0, 0.0, 0.0);
+                Rng rng{sample_key(rp, cam, ir), cur.bd >> 16};
+                // lib.rs:528-551
+                const PrimRec<COMPACT>& rec = rec_cur;
+                position = v_add(o, v_scale(d, t));
+                const V3 normal = prim_normal<COMPACT>(rec, position);
+                const V3 view = v_unit(v_scale(d, -1.0));
+                const uint32_t sid = rec.tag() >> 8;
+                hit_sid = sid < 7u ? sid : 7u;
+                const SurfaceDev* surf = sid < n_surf_lds ? &s_surf[sid] : sc.surfaces + sid;
+                const Scatter ev = material_evaluate(surf, normal, view, rng);
+                if (ev.scatter) {
+                    light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
+                    thr = v_mul(thr, ev.color);
+                    const double p = rr_max(rr_max(thr.x, thr.y), thr.z);
+                    if (rng.next() > p) {
+                        ended = true;
+                    } else if (bounce >= rp.max_bounces) {  // loop bound of lib.rs:525; lib.rs:559
+                        ended = true;
                     } else {
-                        HotSlot* hs = &wide_slot(wf, slot)->hot;
-                        hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
-                        hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
+                        thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
+                        dir = ev.dir;
+                        bd_next = (bounce + 1u) | (rng.draw << 16);
+                        goes_on = true;
                     }
-                    wf.state[slot] = WF_READY;
+                } else {
+                    ended = true;  // lib.rs:550
                 }
-            } else {
-                ended = true;  // lib.rs:550
+                if (ended) {  // radiance() returns `light`; main.rs:69 adds it to the pixel
+                    ir.acc[0] += light.x;
+                    ir.acc[1] += light.y;
+                    ir.acc[2] += light.z;
+                }
             }
-            if (ended) {  // radiance() returns `light`; main.rs:69 adds it to the pixel
-                ir.acc[0] += light.x;
-                ir.acc[1] += light.y;
-                ir.acc[2] += light.z;
-            }
+            // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
+            if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
+            if (goes_on) {
+                RaySlot* rs = ray_slot(wf, slot);
+                rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
+                rs->d[0] = dir.x, rs->d[1] = dir.y, rs->d[2] = dir.z;
+                rs->bd = bd_next;
+                if (LEAN) {
+                    LeanTail* lt = &lean_slot(wf, slot)->tail;
+                    lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
+                    lt->s_cur = ir.s_cur | (lean_light_bits(light) << 28) | (1u << 31);
+                } else {
+                    HotSlot* hs = &wide_slot(wf, slot)->hot;
+                    hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
+                    hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
+                }
+                wf.state[slot] = WF_READY;
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
@@ -722,6 +739,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             next_sample<LEAN>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
+        rec_cur = rec_nxt;
         have = have_next;
     }
     store_item_range(wf, wave, range);
