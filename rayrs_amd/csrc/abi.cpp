@@ -541,15 +541,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
     // and drain are a fixed cost, so large pools win even when that leaves only one or two
-    // items per slot -- up to the point where the hit and miss kernels, which touch two or
-    // three scattered lines per slot, lose more to the larger footprint.  Swept on the
-    // headline frame: 4 M slots 2.4, 8 M 2.9, 16 M 3.41, 32 M 3.56, 64 M 3.54, 128 M
-    // 3.45 Gray/s (on a one-eighth tile share 16 M and 32 M tie, 64 M loses 8 %).
-    // 32 M slots are 6.4 GB of the 288 GB.  A frame should also last some tens of rounds, or
-    // filling and draining the pool is all it does: at most one slot per 16 samples (on the
-    // 268 M-sample sphere-row frame 16 M slots give 4.9, 32 M 4.3 Gray/s).
+    // items per slot -- up to the point where the hit and miss kernels lose more to the larger
+    // footprint.  Swept on the headline frame with one-line slots: 24 M slots 1520 ms, 32 M 1516,
+    // 48 M 1497, 64 M 1467, 96 M 1468, 128 M 1481, 192 M 1498 (round 1, 192-byte slots: 32 M).
+    // 64 M slots are 8.3 GB of the 288 GB.  A frame should also last some tens of rounds, or
+    // filling and draining the pool is all it does: at most one slot per 16 samples -- which is
+    // what a one-eighth tile share of the headline frame gets (33.5 M; 64 M would cost it 5 %).
     uint64_t np64 = rp.total_items;
-    if (np64 > (1ull << 25)) np64 = 1ull << 25;
+    if (np64 > (1ull << 26)) np64 = 1ull << 26;
     {
         const uint64_t samples = n_local * 64ull * rp.spp;
         const uint64_t by_work = samples / 16u > (1ull << 20) ? samples / 16u : (1ull << 20);
