@@ -516,7 +516,17 @@ RR_DEV double beckmann_from_tan(double tan_theta_h, double alpha2, double nh) { 
     return rr_exp(-tan_theta_h * tan_theta_h / alpha2) / (RR_PI * alpha2 * pow4(nh));
 }
 
-RR_DEV V3 ct_brdf(const CtLayer& ct, V3 n, V3 l, V3 v) {  // :1276-1322
+// The reference evaluates the Beckmann term of the half vector twice for a Cook-Torrance reflection: once in
+// the pdf (Pdf::Beckmann::value :915-941, on |n.h|) and once in the BRDF (:1276-1322, on n.h).  l + v and
+// v + l are the same vector, so whenever n.h >= 0 the two evaluations have the same inputs bit for bit
+// (acos, tan, exp, powi(4), two divisions): the pdf leaves what it computed here and the BRDF takes it.
+struct CtHalf {
+    bool valid;            // tan_abs (and, unless it is infinite, beckmann_abs) were computed from fabs(nh)
+    double nh;             // n . h, signed
+    double tan_abs, beckmann_abs;
+};
+
+RR_DEV V3 ct_brdf(const CtLayer& ct, V3 n, V3 l, V3 v, const CtHalf* half = nullptr) {  // :1276-1322
     const double nv = rr_fabs(v_dot(n, v));
     const double nl = rr_fabs(v_dot(n, l));
     V3 h = v_add(v, l);
@@ -524,9 +534,16 @@ RR_DEV V3 ct_brdf(const CtLayer& ct, V3 n, V3 l, V3 v) {  // :1276-1322
     if (v_is_zeros(h)) return mk(0, 0, 0);
     h = v_unit(h);
     const double nh = v_dot(n, h);
-    const double tan_theta_h = rr_tan(rr_acos(nh));
+    double tan_theta_h, beckmann = 0.0;
+    const bool shared = half != nullptr && half->valid && nh >= 0.0;  // then fabs(nh) and nh are the same number
+    if (shared) {
+        tan_theta_h = half->tan_abs;
+    } else {
+        tan_theta_h = rr_tan(rr_acos(nh));
+    }
     if (__builtin_isinf(tan_theta_h)) return mk(0, 0, 0);
-    const double beckmann = beckmann_from_tan(tan_theta_h, ct.alpha2, nh);
+    if (shared) beckmann = half->beckmann_abs;
+    else beckmann = beckmann_from_tan(tan_theta_h, ct.alpha2, nh);
     const double hv = v_dot(h, v);
     const double g = rr_min(2.0 * nh * nv / hv, rr_min(2.0 * nh * nl / hv, 1.0));
     const V3 f = fresnel_value(ct, h, v, true);
@@ -568,14 +585,19 @@ RR_DEV V3 ct_btdf(const CtLayer& ct, V3 n, V3 l, V3 v, bool entering) {  // :136
     return v_div(r, denom);
 }
 
-RR_DEV double pdf_beckmann_reflect_value(double alpha2, V3 n, V3 l, V3 v) {  // :915-941
+RR_DEV double pdf_beckmann_reflect_value(double alpha2, V3 n, V3 l, V3 v, CtHalf* half = nullptr) {  // :915-941
+    if (half) half->valid = false;
     V3 h = v_add(l, v);
     if (v_is_zeros(h)) return 1.0;
     h = v_unit(h);
-    const double nh = rr_fabs(v_dot(n, h));
+    const double nh_signed = v_dot(n, h);
+    const double nh = rr_fabs(nh_signed);
     const double tan_theta_h = rr_tan(rr_acos(nh));
+    if (half) half->valid = true, half->nh = nh_signed, half->tan_abs = tan_theta_h, half->beckmann_abs = 0.0;
     if (__builtin_isinf(tan_theta_h)) return 1.0;
-    return beckmann_from_tan(tan_theta_h, alpha2, nh);
+    const double b = beckmann_from_tan(tan_theta_h, alpha2, nh);
+    if (half) half->beckmann_abs = b;
+    return b;
 }
 
 // Pdf::Beckmann.generate (:1006-1020) / MicrofacetDistribution::generate (:1139-1161)
@@ -607,12 +629,13 @@ struct Scatter {
 
 RR_DEV Scatter no_scatter() { return Scatter{false, mk(0, 0, 0), mk(0, 0, 0)}; }
 
-RR_DEV Scatter ct_evaluate_reflection(const CtLayer& ct, V3 n, V3 h, V3 v, V3 l, double pdf) {  // :721-758
+RR_DEV Scatter ct_evaluate_reflection(const CtLayer& ct, V3 n, V3 h, V3 v, V3 l, double pdf,
+                                      const CtHalf* half = nullptr) {  // :721-758
     if (v_dot(h, v) < 0.0) return no_scatter();
     const double nl = v_dot(n, l);
     if (nl < 0.0) return no_scatter();
     const double frac_dwh_dwi = 4.0 * v_dot(h, l);
-    V3 color = v_scale(ct_brdf(ct, n, l, v), nl);
+    V3 color = v_scale(ct_brdf(ct, n, l, v, half), nl);
     color = v_scale(v_div(color, pdf), frac_dwh_dwi);
     if (v_is_zeros(color)) return no_scatter();
     return Scatter{true, color, l};
@@ -656,7 +679,9 @@ RR_DEV Scatter ct_scatter(const CtLayer& ct, V3 n, V3 v, Rng& rng) {  // :403-42
     double unused;
     const V3 h = beckmann_generate<false>(ct.alpha2, n, rng, unused);
     const V3 l = reflect(h, v);
-    return ct_evaluate_reflection(ct, n, h, v, l, pdf_beckmann_reflect_value(ct.alpha2, n, l, v));
+    CtHalf half;
+    const double pdf = pdf_beckmann_reflect_value(ct.alpha2, n, l, v, &half);
+    return ct_evaluate_reflection(ct, n, h, v, l, pdf, &half);
 }
 
 RR_DEV V3 reflect_brdf(V3 color, V3 n, V3 l) { return v_div(color, rr_fabs(v_dot(n, l))); }  // :1254-1265

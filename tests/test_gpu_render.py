@@ -191,13 +191,14 @@ def test_seed_changes_image_and_same_seed_repeats():
     assert not np.array_equal(a, c)
 
 
-@pytest.mark.parametrize("n", [2, 3])
-def test_render_multi_on_logical_ranks_equals_the_single_device_frame(n):
+@pytest.mark.parametrize("n,lit", [(2, True), (3, True), (2, False)])
+def test_render_multi_on_logical_ranks_equals_the_single_device_frame(n, lit):
     """rayrs_render_multi (the block loop over several GPUs inside the library): n handles of the same
     scene, here all on device 0, one host thread and stream each, tiles t % n == rank, the buffers
     summed -- ranks sharing a device by the accumulate kernel, the distinct devices by one RCCL
     reduce (a one-rank communicator here).  The frame must equal the single-handle frame bit for bit."""
-    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 77, 45, 6)
+    # with the area light the pool uses 192-byte slots, without it one-line slots (wavefront.h)
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), 77, 45, 6)
     full, st = rayrs_amd.render(scene, cam, 6, sample_chunk=4, out_f64=False)
     clones = [scene] + [scene.clone_to_device(0) for _ in range(n - 1)]
     img, mst = rayrs_amd.render_multi(clones, cam, 6, sample_chunk=4)
@@ -242,7 +243,12 @@ def test_two_pipelines_render_the_same_frame():
     """rayrs_tuning.pipelines = 2: the pool as two halves on two streams (one half's hit/miss kernels beside the
     other's traversal kernel).  Items are handed out in a different order, every item's samples are still
     summed in order: the frame must not change by a bit, nor the ray count."""
-    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 256, 256, 16)
+    _two_pipelines(True)
+    _two_pipelines(False)  # one-line slots
+
+
+def _two_pipelines(lit):
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), 256, 256, 16)
     one, st1 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
     scene.set_tuning(pipelines=2, trav_blocks_per_cu=4)
     two, st2 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
