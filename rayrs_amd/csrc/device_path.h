@@ -521,7 +521,8 @@ RR_DEV double beckmann_from_tan(double tan_theta_h, double alpha2, double nh) { 
 // v + l are the same vector, so whenever n.h >= 0 the two evaluations have the same inputs bit for bit
 // (acos, tan, exp, powi(4), two divisions): the pdf leaves what it computed here and the BRDF takes it.
 struct CtHalf {
-    bool valid;            // tan_abs (and, unless it is infinite, beckmann_abs) were computed from fabs(nh)
+    bool valid;            // h is the unit half vector; tan_abs (and, unless it is infinite, beckmann_abs) come from fabs(nh)
+    V3 h;
     double nh;             // n . h, signed
     double tan_abs, beckmann_abs;
 };
@@ -529,11 +530,17 @@ struct CtHalf {
 RR_DEV V3 ct_brdf(const CtLayer& ct, V3 n, V3 l, V3 v, const CtHalf* half = nullptr) {  // :1276-1322
     const double nv = rr_fabs(v_dot(n, v));
     const double nl = rr_fabs(v_dot(n, l));
-    V3 h = v_add(v, l);
     if (nv == 0.0 || nl == 0.0) return mk(0, 0, 0);
-    if (v_is_zeros(h)) return mk(0, 0, 0);
-    h = v_unit(h);
-    const double nh = v_dot(n, h);
+    V3 h;
+    double nh;
+    if (half != nullptr && half->valid) {  // (l + v).unit() of the pdf: the same vector, and not zero
+        h = half->h, nh = half->nh;
+    } else {
+        h = v_add(v, l);
+        if (v_is_zeros(h)) return mk(0, 0, 0);
+        h = v_unit(h);
+        nh = v_dot(n, h);
+    }
     double tan_theta_h, beckmann = 0.0;
     const bool shared = half != nullptr && half->valid && nh >= 0.0;  // then fabs(nh) and nh are the same number
     if (shared) {
@@ -593,7 +600,7 @@ RR_DEV double pdf_beckmann_reflect_value(double alpha2, V3 n, V3 l, V3 v, CtHalf
     const double nh_signed = v_dot(n, h);
     const double nh = rr_fabs(nh_signed);
     const double tan_theta_h = rr_tan(rr_acos(nh));
-    if (half) half->valid = true, half->nh = nh_signed, half->tan_abs = tan_theta_h, half->beckmann_abs = 0.0;
+    if (half) half->valid = true, half->h = h, half->nh = nh_signed, half->tan_abs = tan_theta_h, half->beckmann_abs = 0.0;
     if (__builtin_isinf(tan_theta_h)) return 1.0;
     const double b = beckmann_from_tan(tan_theta_h, alpha2, nh);
     if (half) half->beckmann_abs = b;
