@@ -1,0 +1,46 @@
+"""One-off stress of the parity claim: many random scenes (tests/test_gpu_render.py::_random_scene) rendered on
+the GPU and by the oracle, frames compared bit for bit, ray and work counts compared.  GPU box only.
+usage: python scripts/fuzz_parity.py [first_seed] [count]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import _oracle, rayrs_amd
+from rayrs_amd import procedural, scenes
+import test_gpu_render as T
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+HDRI = procedural.make_hdri(256, 128)
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    r = np.random.default_rng(seed ^ 0xABCDEF)
+    w, h = int(r.integers(9, 90)), int(r.integers(9, 70))
+    spp = int(r.integers(1, 13))
+    chunk = int(r.choice([0, 1, 3, 4, 5]))
+    mb = int(r.choice([1, 2, 5, 50]))
+    cam_args, objs, heur = T._random_scene(seed)
+    if seed % 3 == 0:  # no emitters: the one-line slot
+        from rayrs_amd.api import Emission, Object
+        for o in objs:
+            o.emission = Emission.Dark()
+    cam_args = scenes.camera_for_resolution(cam_args, w, h)
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    cam = rayrs_amd.Camera(*cam_args)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+    ocam = _oracle.OracleCamera(*cam_args)
+    if seed % 5 == 0:
+        scene.set_tuning(pool_slots=int(r.integers(1, 40)) * 1024)
+    img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
+    ref, ost = osc.use_walk_tree(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+    ok = np.array_equal(img.view(np.uint64), ref.view(np.uint64))
+    for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
+        ok = ok and st[k] == ost[k]
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, w, h, spp, chunk, mb, {k: (st[k], ost[k]) for k in ("rays", "interior_visits")}, flush=True)
+    if (seed - first) % 20 == 19:
+        print(f"{seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print("done:", count, "scenes,", bad, "mismatches")
+sys.exit(1 if bad else 0)
