@@ -289,8 +289,8 @@ typedef struct {
     uint32_t pipelines;     /* 1 or 2: halves of the pool on two streams, one's hit/miss kernels beside the
                                other's traversal kernel (default: see rayrs_render_launch in abi.cpp) */
     uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
-    uint32_t wide_slots;    /* 1 = keep the 192-byte path slot also where the 128-byte one would do (a scene in
-                               which no surface emits needs no light accumulator: wavefront.h LeanSlot) */
+    uint32_t eager_light;   /* 1 = the hit and miss kernels request a path's entry of the light side array together
+                               with its slot also where no surface emits (they do anyway where one does) */
 } rayrs_tuning;
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);

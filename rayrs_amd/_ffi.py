@@ -79,7 +79,7 @@ class RenderStats(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("pool_slots", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
                 ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
-                ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("wide_slots", C.c_uint32)]
+                ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in

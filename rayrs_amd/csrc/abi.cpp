@@ -432,7 +432,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
-    RAYRS_FIELD(rayrs_tuning, wide_slots);
+    RAYRS_FIELD(rayrs_tuning, eager_light);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -573,12 +573,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
     if (static_pct > 100) static_pct = 100;
 
-    // The path slot: one 128-byte line when no surface of the scene emits (then a path's light is +0 or NaN
-    // per component, three bits: wavefront.h LeanSlot), 192 bytes otherwise.
-    bool lean = !scene->tuning.wide_slots && params->spp <= LEAN_SAMPLE_MASK;
+    // A path's light lives in a side array and only while it is not +0 (wavefront.h PathSlot).  Where a surface
+    // emits, paths do get light, and the hit and miss kernels request the side array's entry together with the
+    // slot instead of after it.
+    bool eager_light = scene->tuning.eager_light != 0u;
     for (const SurfaceDev& sf : scene->surfaces)
-        if (sf.emit[0] != 0.0 || sf.emit[1] != 0.0 || sf.emit[2] != 0.0) lean = false;
-    const uint32_t slot_bytes = lean ? (uint32_t)sizeof(LeanSlot) : (uint32_t)sizeof(Slot);
+        if (sf.emit[0] != 0.0 || sf.emit[1] != 0.0 || sf.emit[2] != 0.0) eager_light = true;
+    if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;  // the slot's sample cursor has 30 bits
+    constexpr size_t slot_bytes = sizeof(PathSlot) + 4 * sizeof(double);  // slot + its entry of the light array
     hipStream_t streams[2] = {stream, scene->aux_stream};
     WfDev wfs[2];
     RenderDev rps[2];
@@ -596,9 +598,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             HIP_TRY(hipMalloc(&pl.block, block_bytes));
             pl.block_bytes = block_bytes;
         }
-        pl.wf.slots = static_cast<unsigned char*>(pl.block);
-        pl.wf.slot_bytes = slot_bytes;
-        pl.wf.state = pl.wf.slots + (size_t)np * slot_bytes;
+        pl.wf.slots = static_cast<PathSlot*>(pl.block);
+        pl.wf.light = reinterpret_cast<double*>(pl.wf.slots + np);
+        pl.wf.state = reinterpret_cast<uint8_t*>(pl.wf.light + (size_t)np * 4u);
         WfDev wf = pl.wf;
         wf.np = np;
         RenderDev r = rp;
@@ -683,8 +685,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                         pl.timed_rounds = it + 1;
                     }
                     if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
-                    HIP_TRY(wf_launch_hit(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
-                    HIP_TRY(wf_launch_miss(sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    HIP_TRY(wf_launch_miss(eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
                 }
             }
             for (uint32_t p = 0; p < n_pipes; p++) {

@@ -19,59 +19,34 @@ struct RaySlot {
 };
 static_assert(sizeof(RaySlot) == 64, "RaySlot");
 
-// Path state the hit/miss kernels carry from bounce to bounce.  While bounce == 1 the
-// throughput is (1,1,1) and the light (0,0,0) (lib.rs:522-523) and are not stored.
-struct HotSlot {
-    double thr[3];    // throughput
-    double light[3];
-    uint64_t key;     // rr_path_key of the sample in flight
-    uint64_t pad;
-};
-static_assert(sizeof(HotSlot) == 64, "HotSlot");
-
-// The item (pixel, sample chunk) the slot is working on; touched only when a path ends.
-struct ItemSlot {
-    double acc[3];    // sum of the item's finished samples, main.rs:67-69
-    uint32_t item;
-    uint32_t s_cur;   // next sample of the item to start
-    uint32_t s_end;
-    uint32_t has_item;
-    uint32_t pix;     // row << 16 | col of the item's pixel (image coordinates)
-    uint32_t pad;
-};
-static_assert(sizeof(ItemSlot) == 48, "ItemSlot");
-
-// The wide slot = 192 contiguous bytes.  Random 64-byte accesses to HBM run at ~0.9 TB/s on this
-// chip against ~6 TB/s streamed (scripts/ubench/fetch_calib.hip), i.e. the number of separate
-// DRAM rows a kernel opens per slot matters more than the bytes it moves: keeping the three
-// records of a slot adjacent makes a slot one row activation per kernel.
-struct Slot {
-    RaySlot ray;
-    HotSlot hot;
-    ItemSlot item;
-    uint64_t pad[2];
-};
-static_assert(sizeof(Slot) == 192, "Slot");
-
-// The lean slot = ONE 128-byte line, for scenes in which nothing emits (every surface's Emission::emit() is
-// exactly zero; an HDRI-lit scene).  There `light` (lib.rs:523, :534) is +0 + throughput * 0 at every hit: a
-// component of it is +0, or NaN once the throughput's component stopped being finite -- one bit each.  The
-// sample's RNG key is recomputed from the pixel and the sample index (in both layouts).  What is left fits
-// the half line behind the ray: throughput, the item's sum and its four identifying words.
-struct LeanTail {
+// The rest of a path's state, in the other half of the slot's line: throughput, the sum of the item's finished
+// samples (main.rs:67-69) and the four words that say which item, sample and pixel the slot is working on.
+// While bounce == 1 the throughput is (1,1,1) (lib.rs:522) and is not read.
+struct TailSlot {
     double thr[3];
     double acc[3];
     uint32_t item;
-    uint32_t s_cur;  // next sample to start (28 bits) | LEAN_LIGHT_NAN << 28 (x, y, z) | has_item << 31
+    uint32_t s_cur;  // next sample of the item to start (30 bits) | SLOT_LIGHT_BIT | SLOT_ITEM_BIT
     uint32_t s_end;
-    uint32_t pix;
+    uint32_t pix;    // row << 16 | col of the item's pixel (image coordinates)
 };
-struct LeanSlot {
+static_assert(sizeof(TailSlot) == 64, "TailSlot");
+
+// One slot = ONE 128-byte line.  Memory is fetched in whole lines on this chip (profiles/r02_fetch_calibration.json),
+// so what a kernel pays for a slot is the number of lines it touches, not the bytes it uses.
+// A path's `light` (lib.rs:523, :534) is not in the slot.  It is exactly +0 until the path meets a surface that
+// emits -- or until a component of the throughput stops being finite (+0 + NaN) -- and very few paths get
+// there; those keep their light in a side array (WfDev::light, 32 bytes per slot) and say so with
+// SLOT_LIGHT_BIT.  The sample's RNG key is recomputed from the pixel and the sample index.
+// (Until late in round 2 the slot was 192 bytes with light and key in it: two lines per access, 10 % of the frame.)
+struct PathSlot {
     RaySlot ray;
-    LeanTail tail;
+    TailSlot tail;
 };
-static_assert(sizeof(LeanSlot) == 128, "LeanSlot");
-constexpr uint32_t LEAN_SAMPLE_MASK = (1u << 28) - 1u;  // samples per pixel the lean layout can count
+static_assert(sizeof(PathSlot) == 128, "PathSlot");
+constexpr uint32_t SLOT_ITEM_BIT = 1u << 31;    // the slot has an item
+constexpr uint32_t SLOT_LIGHT_BIT = 1u << 30;   // the path's light is in WfDev::light (else it is +0)
+constexpr uint32_t SLOT_SAMPLE_MASK = (1u << 30) - 1u;  // samples per pixel a slot can count
 
 // slot states
 constexpr uint8_t WF_IDLE = 0;   // no path in flight: gen_kernel's input
@@ -87,9 +62,8 @@ struct WfCtl {
 };
 
 struct WfDev {
-    unsigned char* slots;  // np slots of slot_bytes each; every layout starts with the RaySlot
-    uint32_t slot_bytes;   // sizeof(Slot) or sizeof(LeanSlot)
-    uint32_t pad_;
+    PathSlot* slots;
+    double* light;  // 4 doubles per slot (3 used): the light of the paths that have any (SLOT_LIGHT_BIT)
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024
@@ -105,15 +79,15 @@ struct WfDev {
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
 hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
-// the gen, hit and miss kernels exist for both slot layouts (wf.slot_bytes says which)
 hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
 hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
-hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+// eager_light: request the side array's entry together with the slot (scenes in which a surface emits)
+hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
-hipError_t wf_launch_miss(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+hipError_t wf_launch_miss(bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
 
 }  // namespace rayrs

@@ -173,12 +173,9 @@ RR_DEV void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uin
     s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
 }
 
-// Slot addressing.  Both layouts (wavefront.h) start with the RaySlot; the traversal kernel uses nothing else.
-RR_DEV RaySlot* ray_slot(const WfDev& wf, uint32_t slot) {
-    return reinterpret_cast<RaySlot*>(wf.slots + (size_t)slot * wf.slot_bytes);
-}
-RR_DEV Slot* wide_slot(const WfDev& wf, uint32_t slot) { return reinterpret_cast<Slot*>(wf.slots) + slot; }
-RR_DEV LeanSlot* lean_slot(const WfDev& wf, uint32_t slot) { return reinterpret_cast<LeanSlot*>(wf.slots) + slot; }
+RR_DEV RaySlot* ray_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].ray; }
+RR_DEV TailSlot* tail_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].tail; }
+RR_DEV double* light_slot(const WfDev& wf, uint32_t slot) { return wf.light + (size_t)slot * 4u; }
 
 // ------------------------------------------------------------------- init
 
@@ -192,8 +189,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
-    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot)) lean_slot(wf, i)->tail.s_cur = 0;
-    else wide_slot(wf, i)->item.has_item = 0;
+    tail_slot(wf, i)->s_cur = 0;  // no item
 }
 
 // -------------------------------------------------------------------- gen
@@ -209,24 +205,16 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
 struct ItemRegs {
     double acc[3];
     uint32_t item, s_cur, s_end, has_item, pix;
-    uint32_t light_nan;  // lean layout: bit k = component k of the path's light is NaN (else +0)
+    uint32_t has_light;  // the path's light is in the side array (else it is +0)
 };
 
-template <bool LEAN>
 RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
+    const TailSlot* t = tail_slot(wf, slot);
     ItemRegs r;
-    if (LEAN) {
-        const LeanTail* t = &lean_slot(wf, slot)->tail;
-        r.acc[0] = t->acc[0], r.acc[1] = t->acc[1], r.acc[2] = t->acc[2];
-        const uint32_t w = t->s_cur;
-        r.item = t->item, r.s_cur = w & LEAN_SAMPLE_MASK, r.s_end = t->s_end, r.has_item = w >> 31, r.pix = t->pix;
-        r.light_nan = (w >> 28) & 7u;
-    } else {
-        const ItemSlot* is = &wide_slot(wf, slot)->item;
-        r.acc[0] = is->acc[0], r.acc[1] = is->acc[1], r.acc[2] = is->acc[2];
-        r.item = is->item, r.s_cur = is->s_cur, r.s_end = is->s_end, r.has_item = is->has_item, r.pix = is->pix;
-        r.light_nan = 0;
-    }
+    r.acc[0] = t->acc[0], r.acc[1] = t->acc[1], r.acc[2] = t->acc[2];
+    const uint32_t w = t->s_cur;
+    r.item = t->item, r.s_cur = w & SLOT_SAMPLE_MASK, r.s_end = t->s_end, r.pix = t->pix;
+    r.has_item = w >> 31, r.has_light = (w >> 30) & 1u;
     return r;
 }
 
@@ -271,7 +259,6 @@ struct SampleCount {
 // sending the ray through the traversal and miss kernels for the same answer: the lane goes on to the
 // item's next sample, and to the next item, until it holds a ray that enters the root box.  From the
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
-template <bool LEAN>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
                         const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
                         SampleCount& sn) {
@@ -336,8 +323,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             need_mask = __ballot(need);
         }
         if (todo && dead) {
-            if (LEAN) lean_slot(wf, slot)->tail.s_cur = 0;
-            else wide_slot(wf, slot)->item.has_item = 0;
+            tail_slot(wf, slot)->s_cur = 0;
             wf.state[slot] = WF_DEAD;
             sn.retired++;
             todo = false;
@@ -365,26 +351,14 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                 rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
                 rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
                 rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
-                if (LEAN) {
-                    LeanTail* t = &lean_slot(wf, slot)->tail;
-                    t->s_cur = s_cur | (1u << 31);  // has an item; the light's NaN bits start clear
-                    if (fresh) {
-                        t->item = item;
-                        t->s_end = s_end;
-                        t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
-                    }
-                    if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                } else {
-                    ItemSlot* ps = &wide_slot(wf, slot)->item;
-                    ps->s_cur = s_cur;
-                    if (fresh) {
-                        ps->has_item = 1;
-                        ps->item = item;
-                        ps->s_end = s_end;
-                        ps->pix = row << 16 | col;
-                    }
-                    if (fresh || acc_write) ps->acc[0] = acc0, ps->acc[1] = acc1, ps->acc[2] = acc2;
+                TailSlot* t = tail_slot(wf, slot);
+                t->s_cur = s_cur | SLOT_ITEM_BIT;  // a new path: no light yet
+                if (fresh) {
+                    t->item = item;
+                    t->s_end = s_end;
+                    t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
+                if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
                 wf.state[slot] = WF_READY;
                 todo = false;
             }
@@ -407,7 +381,6 @@ RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const Sampl
 }
 
 // Initial fill of the pool (every live slot starts IDLE).
-template <bool LEAN>
 __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
@@ -422,8 +395,8 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            const ItemRegs ir = load_item<LEAN>(wf, slot);
-            next_sample<LEAN>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
+            const ItemRegs ir = load_item(wf, slot);
+            next_sample(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -592,22 +565,22 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
 struct HitIn {
     uint32_t slot;
     bool valid;
-    V3 o, d, thr, light;  // light: wide layout only (the lean one keeps ir.light_nan)
+    V3 o, d, thr, light;  // light: the side array's entry, requested with the slot only when EAGER (else fetched on demand)
     double t;
     uint32_t prim, bd;
     ItemRegs ir;
 };
 
-// A path's light in the lean layout: +0, or NaN where the bit says so (wavefront.h LeanTail).
-RR_DEV V3 lean_light(uint32_t nan_bits) {
-    const double q = __builtin_nan("");
-    return mk(nan_bits & 1u ? q : 0.0, nan_bits & 2u ? q : 0.0, nan_bits & 4u ? q : 0.0);
+// A path's light: +0 unless the slot says it is in the side array (wavefront.h PathSlot).
+RR_DEV V3 load_light(const WfDev& wf, uint32_t slot) {
+    const double* l = light_slot(wf, slot);
+    return mk(l[0], l[1], l[2]);
 }
-RR_DEV uint32_t lean_light_bits(V3 light) {
-    return (light.x != light.x ? 1u : 0u) | (light.y != light.y ? 2u : 0u) | (light.z != light.z ? 4u : 0u);
+RR_DEV bool light_is_plus_zero(V3 light) {  // bitwise: -0 and NaN are not
+    return (rr_f64_bits(light.x) | rr_f64_bits(light.y) | rr_f64_bits(light.z)) == 0ull;
 }
 
-template <bool LEAN>
+template <bool EAGER>
 RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0: harmless
     const RaySlot* rs = ray_slot(wf, h.slot);
     h.o = mk(rs->o[0], rs->o[1], rs->o[2]);
@@ -615,19 +588,13 @@ RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0:
     h.t = rs->t;
     h.prim = rs->prim;
     h.bd = rs->bd;
-    if (LEAN) {
-        const LeanTail* t = &lean_slot(wf, h.slot)->tail;
-        h.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
-        h.light = mk(0.0, 0.0, 0.0);
-    } else {
-        const HotSlot* hs = &wide_slot(wf, h.slot)->hot;
-        h.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-        h.light = mk(hs->light[0], hs->light[1], hs->light[2]);
-    }
-    h.ir = load_item<LEAN>(wf, h.slot);
+    const TailSlot* t = tail_slot(wf, h.slot);
+    h.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
+    h.light = EAGER ? load_light(wf, h.slot) : mk(0.0, 0.0, 0.0);
+    h.ir = load_item(wf, h.slot);
 }
 
-template <bool COMPACT, bool LEAN>
+template <bool COMPACT, bool EAGER>
 __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
@@ -654,13 +621,13 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
     PrimRec<COMPACT> rec_cur;
     if (have) {
-        load_hit_in<LEAN>(wf, cur);
+        load_hit_in<EAGER>(wf, cur);
         rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
     }
     while (have) {
         HitIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_hit_in<LEAN>(wf, nxt);
+        if (have_next) load_hit_in<EAGER>(wf, nxt);
         PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
@@ -677,7 +644,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 const uint32_t bounce = cur.bd & 0xffffu;
                 // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
                 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
-                light = bounce > 1u ? (LEAN ? lean_light(ir.light_nan) : cur.light) : mk(0.0, 0.0, 0.0);
+                light = mk(0.0, 0.0, 0.0);
+                if (bounce > 1u && ir.has_light) light = EAGER ? cur.light : load_light(wf, slot);
                 Rng rng{sample_key(rp, cam, ir), cur.bd >> 16};
                 // lib.rs:528-551
                 const PrimRec<COMPACT>& rec = rec_cur;
@@ -718,15 +686,14 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
                 rs->d[0] = dir.x, rs->d[1] = dir.y, rs->d[2] = dir.z;
                 rs->bd = bd_next;
-                if (LEAN) {
-                    LeanTail* lt = &lean_slot(wf, slot)->tail;
-                    lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
-                    lt->s_cur = ir.s_cur | (lean_light_bits(light) << 28) | (1u << 31);
-                } else {
-                    HotSlot* hs = &wide_slot(wf, slot)->hot;
-                    hs->thr[0] = thr.x, hs->thr[1] = thr.y, hs->thr[2] = thr.z;
-                    hs->light[0] = light.x, hs->light[1] = light.y, hs->light[2] = light.z;
+                TailSlot* lt = tail_slot(wf, slot);
+                lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
+                const bool keep_light = !light_is_plus_zero(light);
+                if (keep_light) {
+                    double* l = light_slot(wf, slot);
+                    l[0] = light.x, l[1] = light.y, l[2] = light.z;
                 }
+                lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
                 wf.state[slot] = WF_READY;
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
@@ -736,7 +703,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample<LEAN>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
+            next_sample(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
         rec_cur = rec_nxt;
@@ -756,24 +723,18 @@ struct MissIn {
     ItemRegs ir;
 };
 
-template <bool LEAN>
+template <bool EAGER>
 RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 0: harmless
     const RaySlot* rs = ray_slot(wf, m.slot);
     m.d = mk(rs->d[0], rs->d[1], rs->d[2]);
     m.bd = rs->bd;
-    m.ir = load_item<LEAN>(wf, m.slot);
-    if (LEAN) {
-        const LeanTail* t = &lean_slot(wf, m.slot)->tail;
-        m.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
-        m.light = lean_light(m.ir.light_nan);
-    } else {
-        const HotSlot* hs = &wide_slot(wf, m.slot)->hot;
-        m.thr = mk(hs->thr[0], hs->thr[1], hs->thr[2]);
-        m.light = mk(hs->light[0], hs->light[1], hs->light[2]);
-    }
+    m.ir = load_item(wf, m.slot);
+    const TailSlot* t = tail_slot(wf, m.slot);
+    m.thr = mk(t->thr[0], t->thr[1], t->thr[2]);
+    m.light = EAGER ? load_light(wf, m.slot) : mk(0.0, 0.0, 0.0);
 }
 
-template <bool LEAN>
+template <bool EAGER>
 __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     if (wf.ctl->live_slots == 0u) return;
@@ -788,23 +749,24 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
-    if (have) load_miss_in<LEAN>(wf, cur);
+    if (have) load_miss_in<EAGER>(wf, cur);
     while (have) {
         MissIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_miss_in<LEAN>(wf, nxt);
+        if (have_next) load_miss_in<EAGER>(wf, nxt);
         ItemRegs ir = cur.ir;
         if (cur.valid) {
             // throughput and light are loaded unconditionally and ignored while bounce == 1 (lib.rs:522-523)
             const bool first = (cur.bd & 0xffffu) <= 1u;
             const V3 thr = first ? mk(1.0, 1.0, 1.0) : cur.thr;
-            const V3 light = first ? mk(0.0, 0.0, 0.0) : cur.light;
+            V3 light = mk(0.0, 0.0, 0.0);
+            if (!first && ir.has_light) light = EAGER ? cur.light : load_light(wf, cur.slot);
             const V3 result = v_add(light, v_mul(thr, background(sc, cur.d)));  // lib.rs:555
             ir.acc[0] += result.x;
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample<LEAN>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        next_sample(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
         cur = nxt;
         have = have_next;
     }
@@ -829,10 +791,7 @@ hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
 
 hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream) {
-    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot))
-        hipLaunchKernelGGL(wf_gen_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
-    else
-        hipLaunchKernelGGL(wf_gen_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 
@@ -867,9 +826,9 @@ hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_reco
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false>, 256, lds);
 }
 
-hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
-                         uint32_t blocks, hipStream_t stream) {
-    const bool lean = wf.slot_bytes == (uint32_t)sizeof(LeanSlot);
+hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
+                         const WfDev& wf, uint32_t blocks, hipStream_t stream) {
+    const bool lean = eager_light;
     if (compact && lean)
         hipLaunchKernelGGL((wf_hit_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else if (compact)
@@ -881,9 +840,9 @@ hipError_t wf_launch_hit(bool compact, const SceneDev& sc, const CameraDev& cam,
     return hipGetLastError();
 }
 
-hipError_t wf_launch_miss(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
-                          uint32_t blocks, hipStream_t stream) {
-    if (wf.slot_bytes == (uint32_t)sizeof(LeanSlot))
+hipError_t wf_launch_miss(bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
+                          const WfDev& wf, uint32_t blocks, hipStream_t stream) {
+    if (eager_light)
         hipLaunchKernelGGL(wf_miss_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else
         hipLaunchKernelGGL(wf_miss_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);

@@ -362,18 +362,32 @@ def test_random_scenes_render_the_oracles_frame(seed):
     assert_same_frame(img, ref0)
 
 
-def test_lean_and_wide_path_slots_render_the_same_frame():
-    """A scene in which nothing emits keeps a path in one 128-byte line (no light accumulator: the light is
-    +0 or NaN per component, three bits; the sample's RNG key is recomputed) -- wavefront.h LeanSlot.
-    rayrs_tuning.wide_slots forces the 192-byte slot every scene with an emitter uses: same frame, same
-    counts, both the oracle's."""
+def test_light_side_array_eager_and_on_demand():
+    """A path's light is +0 until it meets an emitter, and lives in a side array only from then on (wavefront.h
+    PathSlot).  Where a surface emits the kernels request the side entry with the slot (eager); elsewhere they
+    would fetch it on demand.  rayrs_tuning.eager_light forces the eager kernels on a scene without emitters:
+    same frame.  The scene WITH an emissive rectangle exercises the stored light, and must equal the oracle."""
     for fn, chunk in ((lambda: scenes.mesh_scene(3), 4), (scenes.material_test, 0), (scenes.glass_single_sphere, 5)):
         scene, cam, osc, ocam = both(fn, 72, 40, 12)
-        lean, st1 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
-        scene.set_tuning(wide_slots=1)
-        wide, st2 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
+        demand, st1 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
+        scene.set_tuning(eager_light=1)
+        eager, st2 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
         ref, ost = osc.render(ocam, 12, 50, sample_chunk=chunk, traversal=0)
         for k in ("rays", "paths", "escaped_paths", "nan_pixels", "neg_pixels"):
             assert st1[k] == st2[k] == ost[k], k
-        assert_same_frame(lean, ref)
-        assert_same_frame(wide, ref)
+        assert_same_frame(demand, ref)
+        assert_same_frame(eager, ref)
+    # emitters of all kinds of material, light picked up mid-path and carried over many bounces
+    from rayrs_amd.api import Axis, Emission, Material, Object
+    def lit():
+        cam_args, objs, heur = scenes.cook_torrance_spheres_metallic()
+        objs = list(objs)
+        objs.append(Object.plane(Axis.YRev, -4.0, 4.0, -4.0, 4.0, 5.0, Material.LambertianDiffuse((0.9, 0.9, 0.9)),
+                                 Emission.new(3.0, (1.0, 0.8, 0.6))))
+        objs.append(Object.sphere(0.6, (0.0, 3.0, 2.0), Material.Glass((1.0, 1.0, 1.0), 1.5), Emission.new(0.7, (0.2, 0.4, 1.0))))
+        return cam_args, objs, heur
+    scene, cam, osc, ocam = both(lit, 80, 40, 16)
+    img, st = rayrs_amd.render(scene, cam, 16, 50, sample_chunk=4, out_f64=True)
+    ref, ost = osc.render(ocam, 16, 50, sample_chunk=4, traversal=0)
+    assert st["rays"] == ost["rays"]
+    assert_same_frame(img, ref)
