@@ -491,8 +491,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (!scene || !camera || !params || !out_device) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
-    if (camera->x_pixels > 65535u || camera->y_pixels > 65535u) return RAYRS_UNSUPPORTED;  // ItemSlot::pix is 16 + 16 bits
+    if (camera->x_pixels > 65535u || camera->y_pixels > 65535u) return RAYRS_UNSUPPORTED;  // TailSlot::pix is 16 + 16 bits
     if (params->max_bounces > 8000u) return RAYRS_UNSUPPORTED;  // bounce and draw counters are 16-bit in the pool
+    if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;     // a slot's sample cursor has 30 bits
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
     HIP_TRY(hipSetDevice(scene->device));
@@ -579,7 +580,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     bool eager_light = scene->tuning.eager_light != 0u;
     for (const SurfaceDev& sf : scene->surfaces)
         if (sf.emit[0] != 0.0 || sf.emit[1] != 0.0 || sf.emit[2] != 0.0) eager_light = true;
-    if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;  // the slot's sample cursor has 30 bits
     constexpr size_t slot_bytes = sizeof(PathSlot) + 4 * sizeof(double);  // slot + its entry of the light array
     hipStream_t streams[2] = {stream, scene->aux_stream};
     WfDev wfs[2];

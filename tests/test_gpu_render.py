@@ -138,8 +138,8 @@ def test_deep_chain_tree_beyond_lds():
 
 def test_launch_limits_are_reported_not_rendered():
     """What the path pool cannot number is refused with RAYRS_UNSUPPORTED (-5), never rendered
-    wrongly: an image side beyond 16 bits (ItemSlot::pix), more than 2^32 (pixel, chunk) items,
-    a bounce budget beyond the pool's 16-bit bounce/draw counters."""
+    wrongly: an image side beyond 16 bits (TailSlot::pix), more than 2^32 (pixel, chunk) items,
+    a bounce budget beyond the pool's 16-bit bounce/draw counters, more samples per pixel than a slot's cursor counts."""
     from rayrs_amd import _ffi
     cam_args, objs, heur = scenes.diffuse_single_sphere()
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
@@ -157,6 +157,7 @@ def test_launch_limits_are_reported_not_rendered():
     assert status(big, spp=4096, max_bounces=4, sample_chunk=8) == -5  # 2^26 pixels * 512 chunks = 2^35 items
     small = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 8, 8))
     assert status(small, spp=1, max_bounces=9000) == -5
+    assert status(small, spp=(1 << 30) + 5, max_bounces=4) == -5          # a slot's sample cursor has 30 bits
 
 
 def test_tile_sharding_is_exact():
@@ -197,7 +198,7 @@ def test_render_multi_on_logical_ranks_equals_the_single_device_frame(n, lit):
     scene, here all on device 0, one host thread and stream each, tiles t % n == rank, the buffers
     summed -- ranks sharing a device by the accumulate kernel, the distinct devices by one RCCL
     reduce (a one-rank communicator here).  The frame must equal the single-handle frame bit for bit."""
-    # with the area light the pool uses 192-byte slots, without it one-line slots (wavefront.h)
+    # with the area light paths carry light in the side array (eager kernels), without it none does (wavefront.h)
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), 77, 45, 6)
     full, st = rayrs_amd.render(scene, cam, 6, sample_chunk=4, out_f64=False)
     clones = [scene] + [scene.clone_to_device(0) for _ in range(n - 1)]
