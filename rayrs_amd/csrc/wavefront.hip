@@ -229,6 +229,7 @@ RR_DEV uint64_t sample_key(const RenderDev& rp, const CameraDev& cam, const Item
 // (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
 // The range lives in registers during a launch and in WfDev::wave_items between launches.
 constexpr uint32_t ITEM_RESERVE = 256;
+constexpr unsigned long long ITEMS_GONE = ~0ull;  // ItemRange::end of a wave that found the counter exhausted
 
 struct ItemRange {
     unsigned long long next, end;
@@ -287,12 +288,18 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         unsigned long long need_mask = __ballot(need);
         while (need_mask != 0ull) {
             if (range.next >= range.end) {  // wave-uniform
-                unsigned long long first = 0;
-                if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
-                const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
-                const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
-                first = ((unsigned long long)fhi << 32) | flo;
+                // a wave that has seen the counter run out remembers it (range.end = ITEMS_GONE, kept in
+                // WfDev::wave_items between launches): at the end of a frame every batch of every wave would
+                // otherwise ask the one counter word again, which serves ~90 atomics per microsecond
+                unsigned long long first = ITEMS_GONE;
+                if (range.end != ITEMS_GONE) {
+                    if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
+                    const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
+                    const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
+                    first = ((unsigned long long)fhi << 32) | flo;
+                }
                 if (first >= rp.total_items) {  // the counter has run out: these slots are done
+                    range.next = range.end = ITEMS_GONE;
                     if (need) dead = true;
                     break;
                 }

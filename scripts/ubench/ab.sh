@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-.}
 cd $ROOT
 cp rayrs_amd/librayrs_hip.so /tmp/cur.so
-run() { cp $1 rayrs_amd/librayrs_hip.so; echo "== $2"; python scripts/perf_probe.py ${PROBE:-full5} 2>&1 | tail -${LINES_OUT:-1}; }
+run() { cp $1 rayrs_amd/librayrs_hip.so; echo "== $2"; python scripts/perf_probe.py ${PROBE:-full5} ${PROBE_ARG:-} 2>&1 | tail -${LINES_OUT:-1}; }
 run /tmp/cur.so current
 run scripts/ubench/alt/prev.so previous
 run scripts/ubench/alt/prev.so previous
