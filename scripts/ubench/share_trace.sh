@@ -4,7 +4,7 @@ OUT=$ROOT/gpurun_out/share_trace
 mkdir -p $OUT
 python -c 'import __graft_entry__ as g; g.build()' || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python $ROOT/scripts/perf_probe.py shard8 4 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python $ROOT/scripts/perf_probe.py ${PROBE:-shard8} ${PROBE_ARG-4} > $OUT/run.log 2>&1
 tail -1 $OUT/run.log
 python - $OUT <<'PY'
 import csv, glob, sys
