@@ -89,6 +89,14 @@ __global__ void test_math_kernel(int fn, const double* x, const double* y, uint6
         case 6: r = rr_atan2(a, b); break;
         case 7: r = rr_sqrt(a); break;
         case 8: r = a / b; break;
+        case 9:    // div3_by (device_path.h): the three quotients a / b, (a * 0x1p-600) / b, (-3 a) / b, one per call
+        case 10:
+        case 11: {
+            double q0, q1, q2;
+            div3_by(a, a * 0x1p-600, -3.0 * a, b, q0, q1, q2);
+            r = fn == 9 ? q0 : fn == 10 ? q1 : q2;
+            break;
+        }
         default: r = 0.0; break;
     }
     out[i] = r;

@@ -65,6 +65,31 @@ def test_atan2_and_division_bit_exact():
     assert np.array_equal(bits(gpu_math(8, a, b)), bits(a / b))
 
 
+def test_three_quotients_by_one_denominator_are_the_three_divisions():
+    """triangle_intersect's three true divisions (geometry.rs:364-374) share the refined reciprocal of their
+    denominator when the hardware scales it alike for all three numerators (device_path.h div3_by).  Whatever
+    the operands -- ordinary, subnormal, huge, zero, infinite, NaN, exponents 600 binades apart so that the
+    numerators scale the denominator differently -- each quotient must be the IEEE quotient, bit for bit."""
+    r = np.random.default_rng(21)
+    n = 60000
+    a = r.normal(size=n) * 2.0 ** r.integers(-1060, 1020, n)
+    b = r.normal(size=n) * 2.0 ** r.integers(-1060, 1020, n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308,
+                        1.7976931348623157e308, 1.0, -1.0, 3.0, 1e-300, 1e300])
+    k = len(special)
+    a[:k * k] = np.repeat(special, k)
+    b[:k * k] = np.tile(special, k)
+    a[k * k:k * k + 2000] = r.normal(size=2000)            # the ordinary case: nothing is scaled
+    b[k * k:k * k + 2000] = r.normal(size=2000)
+    with np.errstate(all="ignore"):
+        want = (a / b, (a * 2.0 ** -600) / b, (-3.0 * a) / b)
+    for fn, w in zip((9, 10, 11), want):
+        got = gpu_math(fn, a, b)
+        nan = np.isnan(w)
+        assert np.array_equal(np.isnan(got), nan)
+        assert np.array_equal(bits(got)[~nan], bits(w)[~nan]), fn
+
+
 def test_rng_bit_exact():
     L = _ffi.lib()
     r = np.random.default_rng(3)
