@@ -145,7 +145,8 @@ typedef struct {
     uint32_t n_wide;        /* four-slot records of the walk tree the kernels traverse */
     uint32_t wide_root_ref;
     uint32_t wide_depth;    /* stack entries the traversal can need */
-    uint32_t reserved;
+    uint32_t local_pool;    /* 1 = the walk tree is at most one record: renders keep every path in LDS
+                               (rayrs_tuning.local_pool, local_pool.hip) */
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -291,6 +292,10 @@ typedef struct {
     uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
     uint32_t eager_light;   /* 1 = the hit and miss kernels request a path's entry of the light side array together
                                with its slot also where no surface emits (they do anyway where one does) */
+    uint32_t local_pool;    /* a scene whose walk tree is at most one record (n_wide <= 1: the reference's sphere
+                               scenes) is rendered by ONE launch that keeps every path in LDS from its first ray
+                               to its last (local_pool.hip) instead of three launches per bounce over a pool in
+                               HBM; same arithmetic, same bits.  0 = do so, 1 = never (the streaming kernels) */
 } rayrs_tuning;
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);

@@ -51,7 +51,7 @@ class SceneInfo(C.Structure):
                 ("n_surfaces", C.c_uint32), ("node_bytes", C.c_uint32), ("prim_bytes", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
                 ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
-                ("wide_depth", C.c_uint32), ("reserved", C.c_uint32)]
+                ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
@@ -79,7 +79,8 @@ class RenderStats(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("pool_slots", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
                 ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
-                ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32)]
+                ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32),
+                ("local_pool", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in

@@ -13,6 +13,7 @@
 
 #include "../../include/rayrs_hip.h"
 #include "kernels.h"
+#include "local_pool.h"
 #include "scene_host.hpp"
 #include "scene_internal.hpp"
 #include "wavefront.h"
@@ -209,6 +210,8 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
             if (e) (void)hipEventDestroy(e);
     }
     if (s->d_next_item) (void)hipFree(s->d_next_item);
+    if (s->d_local_light) (void)hipFree(s->d_local_light);
+    if (s->d_local_items) (void)hipFree(s->d_local_items);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
     for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_stagger})
         if (e) (void)hipEventDestroy(e);
@@ -242,6 +245,42 @@ static int scene_configure_traversal(rayrs_scene* s) {
     return RAYRS_OK;
 }
 
+// The gating boxes of a walk tree of at most one record, as kernel arguments of local_pool.hip (LocalScene).
+constexpr uint32_t LOCAL_SEGMENT_ITEMS = 1u << 27;  // items per launch of the local-pool kernel
+constexpr uint32_t LOCAL_MAX_SEGMENTS = 64;
+static void scene_configure_local(rayrs_scene* s) {
+    const FlatScene& f = s->flat;
+    LocalScene& ls = s->local;
+    std::memset(&ls, 0, sizeof(ls));
+    s->local_ok = false;
+    if (f.n_wide() > 1 || f.n_prims() == 0 || f.n_prims() > LP_MAX_PRIMS || s->surfaces.size() > LP_MAX_PRIMS) return;
+    auto add_gate = [&](const double* box, uint32_t ref) {
+        if ((ref >> 30) != REF_RANGE) return false;
+        const uint32_t g = ls.n_gates++;
+        for (int i = 0; i < 6; i++) ls.box[g][i] = box[i];
+        ls.first[g] = (ref & 0x3fffffffu) >> 2;
+        ls.count[g] = (ref & 3u) + 1u;
+        return true;
+    };
+    if (f.n_wide() == 0) {  // the root group behind the root Node's box (trav_init)
+        if (!add_gate(f.root_box, f.wide_root_ref)) return;
+    } else {
+        if ((f.wide_root_ref >> 30) != REF_INTERIOR) return;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t ref = f.wide_ref[k];
+            if ((ref >> 30) == REF_NONE) continue;
+            if (!add_gate(&f.wide_box[(size_t)k * 6], ref)) return;  // an interior slot: not a one-record tree
+        }
+    }
+    uint32_t covered = 0;
+    for (uint32_t g = 0; g < ls.n_gates; g++) covered += ls.count[g];
+    if (covered != f.n_prims()) return;
+    ls.n_records = f.n_wide();
+    ls.n_prims = f.n_prims();
+    for (const SurfaceDev& sf : s->surfaces) ls.kind_mask |= 1u << (uint32_t)sf.kind;
+    s->local_ok = true;
+}
+
 extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     hipDeviceProp_t prop;
@@ -271,6 +310,10 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         for (auto& e : pl.ev_batch) HIP_TRY(hipEventCreate(&e));
     }
     HIP_TRY(hipMalloc((void**)&s->d_next_item, sizeof(unsigned long long)));
+    if (s->local_ok) {
+        HIP_TRY(lp_configure());
+        HIP_TRY(hipMalloc((void**)&s->d_local_items, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long)));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
@@ -289,6 +332,7 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     s->surfaces = objs->list.surfaces;
     s->n_objects = objs->list.objs.size();
     s->device = device;
+    scene_configure_local(s.get());
     if (device >= 0) {
         st = scene_upload(s.get());
         if (st != RAYRS_OK) {
@@ -316,6 +360,7 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->n_wide = f.n_wide();
     info->wide_root_ref = f.wide_root_ref;
     info->wide_depth = f.wide_depth;
+    info->local_pool = (scene->local_ok && scene->tuning.local_pool != 1u) ? 1u : 0u;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
     for (int i = 0; i < 6; i++) info->root_box[i] = f.root_box[i];
@@ -351,6 +396,7 @@ int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scen
         s->n_objects = scene->n_objects;
         s->tuning = scene->tuning;
         s->device = device;
+        scene_configure_local(s.get());
         const int st = scene_upload(s.get());
         if (st != RAYRS_OK) {
             scene_free_device(s.get());
@@ -365,7 +411,8 @@ int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device 
 
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     if (!scene || !tuning) return RAYRS_INVALID_ARG;
-    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u)
+    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u ||
+        tuning->local_pool > 1u)
         return RAYRS_INVALID_ARG;
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
@@ -410,7 +457,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, prim_bytes), RAYRS_FIELD(rayrs_scene_info_t, device_bytes);
     RAYRS_FIELD(rayrs_scene_info_t, root_box), RAYRS_FIELD(rayrs_scene_info_t, build_seconds);
     RAYRS_FIELD(rayrs_scene_info_t, n_wide), RAYRS_FIELD(rayrs_scene_info_t, wide_root_ref);
-    RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, reserved);
+    RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, local_pool);
     RAYRS_STRUCT(rayrs_render_params, 8);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
@@ -428,11 +475,11 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
-    RAYRS_STRUCT(rayrs_tuning, 9);
+    RAYRS_STRUCT(rayrs_tuning, 10);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
-    RAYRS_FIELD(rayrs_tuning, eager_light);
+    RAYRS_FIELD(rayrs_tuning, eager_light), RAYRS_FIELD(rayrs_tuning, local_pool);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -568,6 +615,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     scene->n_pipes = n_pipes;
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
+    const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
+    if (use_local && (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS > LOCAL_MAX_SEGMENTS)
+        return RAYRS_UNSUPPORTED;
     uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
     if (scene->tuning.trav_blocks_per_cu && scene->tuning.trav_blocks_per_cu < trav_bpc) trav_bpc = scene->tuning.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
@@ -585,7 +635,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     WfDev wfs[2];
     RenderDev rps[2];
     uint32_t lives[2], flat_blocks[2];
-    for (uint32_t p = 0; p < n_pipes; p++) {
+    for (uint32_t p = 0; p < n_pipes && !use_local; p++) {  // (the local-pool route keeps its paths in LDS)
         rayrs_scene::Pipeline& pl = scene->pipe[p];
         const uint64_t live64 = live_total / n_pipes + (p < live_total % n_pipes ? 1u : 0u);
         const uint32_t np = (uint32_t)((live64 + 1023ull) & ~1023ull);  // whole windows
@@ -645,9 +695,50 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
     HIP_TRY(hipMemsetAsync(scene->d_next_item, 0, sizeof(unsigned long long), stream));
+    if (use_local) HIP_TRY(hipMemsetAsync(scene->d_local_items, 0, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
     scene->rounds = 0;
-    if (rp.total_items > 0) {
+    scene->last_local = use_local;
+    if (use_local && rp.total_items > 0) {
+        // ---- one launch per segment of the frame's items; a launch ends when its last path has (local_pool.hip)
+        rayrs_scene::Pipeline& pl = scene->pipe[0];
+        scene->n_pipes = 1;
+        pl.timed_rounds = 0;
+        const uint64_t n_seg = (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS;
+        // two workgroups of four waves per CU; fewer when the frame has fewer items than resident paths
+        uint32_t blocks = (uint32_t)scene->cu_count * 2u;
+        {
+            const uint64_t seg_items = rp.total_items < LOCAL_SEGMENT_ITEMS ? rp.total_items : LOCAL_SEGMENT_ITEMS;
+            const uint64_t want = (seg_items + 4u * LP_PATHS_PER_WAVE - 1) / (4u * LP_PATHS_PER_WAVE);
+            if (want < blocks) blocks = (uint32_t)(want ? want : 1);
+        }
+        const size_t paths = (size_t)blocks * 4u * LP_PATHS_PER_WAVE;
+        if (paths > scene->local_light_paths) {
+            if (scene->d_local_light) HIP_TRY(hipFree(scene->d_local_light));
+            scene->d_local_light = nullptr;
+            scene->local_light_paths = 0;
+            HIP_TRY(hipMalloc((void**)&scene->d_local_light, paths * 4 * sizeof(double)));
+            scene->local_light_paths = paths;
+        }
+        for (uint64_t seg = 0; seg < n_seg; seg++) {
+            LocalDev lp;
+            lp.light = scene->d_local_light;
+            lp.next_item = scene->d_local_items + seg;
+            lp.item_base = seg * LOCAL_SEGMENT_ITEMS;
+            lp.item_count = rp.total_items - lp.item_base < LOCAL_SEGMENT_ITEMS ? rp.total_items - lp.item_base
+                                                                                 : LOCAL_SEGMENT_ITEMS;
+            while (pl.ev_trav.size() < 2 * (size_t)(seg + 1)) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                pl.ev_trav.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(pl.ev_trav[2 * seg], stream));
+            HIP_TRY(lp_launch(compact, count, sc, scene->local, cam, rp, lp, blocks, stream));
+            HIP_TRY(hipEventRecord(pl.ev_trav[2 * seg + 1], stream));
+            pl.timed_rounds = (uint32_t)seg + 1;
+        }
+        scene->rounds = (uint32_t)n_seg;
+    } else if (rp.total_items > 0) {
         if (n_pipes > 1) {  // fork: the second stream starts behind everything queued on the caller's so far
             HIP_TRY(hipEventRecord(scene->ev_fork, stream));
             HIP_TRY(hipStreamWaitEvent(scene->aux_stream, scene->ev_fork, 0));

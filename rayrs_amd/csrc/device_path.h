@@ -727,9 +727,9 @@ RR_DEV V3 refract_btdf(V3 color, V3 n, V3 l, V3 v) {                            
     return v_div(color, rr_fabs(v_dot(n, l)));
 }
 
-// Material::evaluate, material.rs:91-109
-RR_DEV Scatter material_evaluate(const SurfaceDev* s, V3 n, V3 v, Rng& rng) {
-    const int kind = s->kind;
+// Material::evaluate, material.rs:91-109.  `kind` is s->kind, passed apart so that a caller whose wave holds
+// one material kind only (local_pool.hip) can hand it over as a wave-uniform value: one arm, scalar branches.
+RR_DEV Scatter material_evaluate_kind(int kind, const SurfaceDev* s, V3 n, V3 v, Rng& rng) {
     const V3 color = mk(s->color[0], s->color[1], s->color[2]);
     switch (kind) {
         case RAYRS_MAT_LAMBERTIAN: return lambertian_scatter(color, n, rng);
@@ -815,6 +815,10 @@ RR_DEV Scatter material_evaluate(const SurfaceDev* s, V3 n, V3 v, Rng& rng) {
         }
         default: return no_scatter();  // NoReflect
     }
+}
+
+RR_DEV Scatter material_evaluate(const SurfaceDev* s, V3 n, V3 v, Rng& rng) {
+    return material_evaluate_kind(s->kind, s, n, v, rng);
 }
 
 // --------------------------------------------------------------- background

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/rayrs_hip.h"
+#include "local_pool.h"
 #include "scene_host.hpp"
 #include "wavefront.h"
 
@@ -58,6 +59,13 @@ struct rayrs_scene {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
     unsigned long long* d_next_item = nullptr;  // the device-wide item counter both pipelines draw from
     uint32_t rounds = 0;
+    // Scenes whose walk tree is at most one record are rendered by local_pool.hip: every path resident in LDS.
+    bool local_ok = false;
+    bool last_local = false;          // the render in flight took that route
+    rayrs::LocalScene local = {};
+    double* d_local_light = nullptr;  // 4 doubles per resident path
+    size_t local_light_paths = 0;
+    unsigned long long* d_local_items = nullptr;  // one item counter per launch segment
     rayrs_tuning tuning = {};  // zeros = defaults (rayrs_scene_set_tuning)
 };
 
