@@ -68,7 +68,9 @@ class RenderStats(C.Structure):
                 ("leaf_wave", C.c_uint64), ("interior_ticks", C.c_uint64), ("leaf_ticks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
-                ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64)]
+                ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64),
+                ("early_visits", C.c_uint64), ("early_tri_tests", C.c_uint64), ("early_sphere_tests", C.c_uint64),
+                ("early_plane_tests", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -80,7 +82,8 @@ class Tuning(C.Structure):
     _fields_ = [("pool_slots", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
                 ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
                 ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32),
-                ("local_pool", C.c_uint32)]
+                ("local_pool", C.c_uint32), ("leaf_group", C.c_uint32),
+                ("early_resolve", C.c_uint32), ("trav_queries", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in

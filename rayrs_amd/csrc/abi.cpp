@@ -240,7 +240,7 @@ static int scene_configure_traversal(rayrs_scene* s) {
     if (s->tuning.hot_records == 0xffffffffu) hot = 0;
     else if (s->tuning.hot_records) hot = s->tuning.hot_records < WIDE_FRONT ? s->tuning.hot_records : WIDE_FRONT;
     s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
-    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
+    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, s->tuning.trav_queries >= 2u ? s->tuning.trav_queries - 1u : 0u, &s->blocks_per_cu));
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
     return RAYRS_OK;
 }
@@ -412,7 +412,7 @@ int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device 
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     if (!scene || !tuning) return RAYRS_INVALID_ARG;
     if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u ||
-        tuning->local_pool > 1u)
+        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || tuning->early_resolve > 3u)
         return RAYRS_INVALID_ARG;
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
@@ -463,7 +463,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 22);
+    RAYRS_STRUCT(rayrs_render_stats, 26);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -475,11 +475,15 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
-    RAYRS_STRUCT(rayrs_tuning, 10);
+    RAYRS_FIELD(rayrs_render_stats, early_visits), RAYRS_FIELD(rayrs_render_stats, early_tri_tests);
+    RAYRS_FIELD(rayrs_render_stats, early_sphere_tests), RAYRS_FIELD(rayrs_render_stats, early_plane_tests);
+    RAYRS_STRUCT(rayrs_tuning, 13);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
     RAYRS_FIELD(rayrs_tuning, eager_light), RAYRS_FIELD(rayrs_tuning, local_pool);
+    RAYRS_FIELD(rayrs_tuning, leaf_group), RAYRS_FIELD(rayrs_tuning, early_resolve);
+    RAYRS_FIELD(rayrs_tuning, trav_queries);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -570,6 +574,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
     rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 32u;
+    rp.leaf_single = scene->tuning.leaf_group == 1u ? 1u : 0u;
+    rp.early_resolve = scene->tuning.early_resolve;  // bit 0: primary rays (next_sample), bit 1: bounced rays (hit kernel)
+    rp.trav_two = scene->tuning.trav_queries >= 2u ? scene->tuning.trav_queries - 1u : 0u;
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;
@@ -676,7 +683,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         wf.trav_threads = trav_blocks * 256u;
         {
             const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
-            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
+            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads * (rp.trav_two ? 2u : 1u);
             if (words > pl.stack_spill_words) {
                 if (pl.d_stack_spill) HIP_TRY(hipFree(pl.d_stack_spill));
                 pl.d_stack_spill = nullptr;
@@ -745,7 +752,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
         for (uint32_t p = 0; p < n_pipes; p++) {
             HIP_TRY(wf_launch_init(wfs[p], lives[p], streams[p]));
-            HIP_TRY(wf_launch_gen(sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
+            HIP_TRY(wf_launch_gen(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
             scene->pipe[p].h_live[0] = scene->pipe[p].h_live[1] = lives[p];
         }
         // Rounds are enqueued in batches; the live-slot counts of batch b are read back while batch b+1 is
@@ -777,7 +784,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                     }
                     if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
                     HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
-                    HIP_TRY(wf_launch_miss(eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
                 }
             }
             for (uint32_t p = 0; p < n_pipes; p++) {
@@ -841,6 +848,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         stats->direct_rays = c.direct_rays;
+        stats->early_visits = c.early_visits, stats->early_tri_tests = c.early_tri_tests;
+        stats->early_sphere_tests = c.early_sphere_tests, stats->early_plane_tests = c.early_plane_tests;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;

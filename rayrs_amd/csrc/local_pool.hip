@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
     LpRange range{0u, 0u, false};
     LpCount n{0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long u_wave = 0, u_lane = 0;
+    unsigned long long tk_isect = 0, tk_shade = 0, tk_other = 0, tk_last = COUNT ? clock64() : 0ull;
 
     for (;;) {
         // the phase most paths wait for
@@ -406,6 +407,13 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
             }
         }
         if (valid) pl.state[p] = (uint8_t)ns;
+        if (COUNT) {  // shader clock per phase kind: ISECT / SHADE_k / GEN and BG (Counters::*_ticks)
+            const unsigned long long now = clock64();
+            if (ph == LP_ISECT) tk_isect += now - tk_last;
+            else if (ph >= LP_SHADE0) tk_shade += now - tk_last;
+            else tk_other += now - tk_last;
+            tk_last = now;
+        }
 #pragma unroll
         for (uint32_t s = 0; s < LP_NSTATE; s++) {
             cnt[s] += (uint32_t)__popcll(__ballot(valid && ns == s));
@@ -423,7 +431,11 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
         lp_wave_add(&c->tri_tests, n.tri);
         lp_wave_add(&c->sphere_tests, n.sphere);
         lp_wave_add(&c->plane_tests, n.plane);
-        if (lane == 0) atomicAdd(&c->step_wave, u_wave * 64ull);
+        if (lane == 0) {
+            atomicAdd(&c->step_wave, u_wave * 64ull);
+            atomicAdd(&c->interior_ticks, tk_isect), atomicAdd(&c->leaf_ticks, tk_shade);
+            atomicAdd(&c->refill_ticks, tk_other);
+        }
         lp_wave_add(&c->step_lane, u_lane);
     }
 }

@@ -251,8 +251,10 @@ RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r)
 // What the kernels that start samples count per lane.
 struct SampleCount {
     unsigned long long paths;   // samples started
-    unsigned long long direct;  // of them: primary rays that missed the root box (answered here, below)
+    unsigned long long direct;  // of them: primary rays whose query was answered here with a Miss (sample finished here, below)
     uint32_t retired;           // slots that found no further item
+    unsigned long long resolved;  // queries answered here whose slot went on to the hit or miss kernel (resolve_root)
+    WorkCount early;              // the work of all queries answered here: root records entered, primitives tested
 };
 
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
@@ -260,6 +262,7 @@ struct SampleCount {
 // sending the ray through the traversal and miss kernels for the same answer: the lane goes on to the
 // item's next sample, and to the next item, until it holds a ray that enters the root box.  From the
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
+template <bool COMPACT>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
                         const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
                         SampleCount& sn) {
@@ -345,7 +348,14 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
             sn.paths++;
             s_cur++;
-            if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) {
+            // the first query, answered here when it needs no walk (resolve_root); else only its first step, the root
+            // Node's box (bvh.rs:394)
+            int first_query = RESOLVE_WALK;
+            double t_hit = 0.0;
+            uint32_t prim_hit = 0xffffffffu;
+            if (rp.early_resolve & 1u) first_query = resolve_root<COMPACT>(sc, o, d, t_hit, prim_hit, sn.early);
+            else if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) first_query = RESOLVE_MISS;
+            if (first_query == RESOLVE_MISS) {
                 // radiance() with the first query a Miss: light 0 + throughput 1 * background (lib.rs:522-523, :555)
                 const V3 result = v_add(mk(0.0, 0.0, 0.0), v_mul(mk(1.0, 1.0, 1.0), background(sc, d)));
                 acc0 += result.x;
@@ -366,7 +376,11 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                     t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
                 if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                wf.state[slot] = WF_READY;
+                if (first_query == RESOLVE_HIT) {
+                    rs->t = t_hit, rs->prim = prim_hit;
+                    sn.resolved++;
+                }
+                wf.state[slot] = first_query == RESOLVE_HIT ? WF_HIT : WF_READY;
                 todo = false;
             }
         }
@@ -383,11 +397,29 @@ RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const Sampl
         atomicAdd(&rp.counters->escaped_paths, direct);
         atomicAdd(&rp.counters->direct_rays, direct);
     }
+    if (rp.early_resolve) {  // wave-uniform
+        const unsigned long long resolved = wave_sum(sn.resolved);
+        if ((threadIdx.x & 63u) == 0 && resolved) {
+            atomicAdd(&rp.counters->rays, resolved);
+            atomicAdd(&rp.counters->direct_rays, resolved);
+        }
+        if (rp.count_work) {
+            wave_atomic_add(&rp.counters->interior_visits, sn.early.interior);
+            wave_atomic_add(&rp.counters->tri_tests, sn.early.tri);
+            wave_atomic_add(&rp.counters->sphere_tests, sn.early.sphere);
+            wave_atomic_add(&rp.counters->plane_tests, sn.early.plane);
+            wave_atomic_add(&rp.counters->early_visits, sn.early.interior);
+            wave_atomic_add(&rp.counters->early_tri_tests, sn.early.tri);
+            wave_atomic_add(&rp.counters->early_sphere_tests, sn.early.sphere);
+            wave_atomic_add(&rp.counters->early_plane_tests, sn.early.plane);
+        }
+    }
     const uint32_t r = (uint32_t)wave_sum(sn.retired);
     if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
 }
 
 // Initial fill of the pool (every live slot starts IDLE).
+template <bool COMPACT>
 __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint16_t lists[4][WINDOW];
     const uint32_t lane = threadIdx.x & 63u;
@@ -395,7 +427,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -403,7 +435,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
             const ItemRegs ir = load_item(wf, slot);
-            next_sample(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -417,7 +449,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-template <bool COMPACT, bool COUNT>
+template <bool COMPACT, bool COUNT, bool LEAF_ONE>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -529,7 +561,8 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                if (LEAF_ONE) trav_leaf_step_one<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                else trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -542,6 +575,227 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             if (at_int) {
                 trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
+            }
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_int += now - tk_last, tk_last = now;
+            }
+        }
+    }
+
+    Counters* c = rp.counters;
+    wave_atomic_add(&c->rays, n_rays);
+    if (COUNT) {
+        wave_atomic_add(&c->interior_visits, wc.interior);
+        wave_atomic_add(&c->tri_tests, wc.tri);
+        wave_atomic_add(&c->sphere_tests, wc.sphere);
+        wave_atomic_add(&c->plane_tests, wc.plane);
+        wave_atomic_add(&c->step_wave, u_int_wave), wave_atomic_add(&c->step_lane, u_int_lane);
+        wave_atomic_add(&c->inner_wave, u_leaf_lane), wave_atomic_add(&c->leaf_wave, u_leaf_wave);
+        if (lane == 0) {
+            atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
+            atomicAdd(&c->refill_ticks, tk_refill);
+        }
+    }
+}
+
+// ------------------------------------------------------------- trav, two queries per lane
+//
+// The same traversal with TWO queries per lane (A and B), each with its own stack.  A wave decides per
+// iteration, as above, whether to run an interior or a leaf step; a lane takes part with whichever of its two
+// queries stands in that phase (A first).  A lane is idle in a phase only if neither of its queries is in it:
+// with one query per lane 34 % of the lanes are idle in an interior step and 43 % in a leaf step on the headline
+// frame (lanes waiting for the other phase, or for the next refill).  The price: the step's operands are selected
+// from two register sets (v_cndmask) and written back, and a wave needs 24 more registers.
+
+struct Query {
+    V3 o, d;
+    Trav tv;
+    uint32_t slot;
+    bool active, pending;
+};
+
+// the wave's window list and how windows are dealt (wave-uniform)
+struct WindowFeed {
+    uint32_t static_next, static_windows, n_waves, n_windows;
+    uint32_t list_pos, list_len, list_base;
+    bool no_more;
+    uint16_t* list;
+};
+
+RR_DEV void trav2_retire(const WfDev& wf, Query& q) {
+    if (q.pending) {
+        RaySlot* rs = ray_slot(wf, q.slot);
+        rs->t = q.tv.best_t;
+        rs->prim = q.tv.best_prim;
+        wf.state[q.slot] = q.tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
+        q.pending = false;
+    }
+}
+
+// idle queries of this kind (A or B) take rays from the wave's window list
+RR_DEV void trav2_refill(const SceneDev& sc, const WfDev& wf, WfCtl* ctl, WindowFeed& f, Query& q,
+                         unsigned long long& n_rays) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    bool need = !q.active;
+    unsigned long long need_mask = __ballot(need);
+    while (need_mask != 0ull) {
+        if (f.list_pos >= f.list_len) {
+            uint32_t w = f.static_next;
+            if (w < f.static_windows) {
+                f.static_next += f.n_waves;
+            } else {
+                if (lane == 0) w = f.static_windows + atomicAdd(&ctl->next_window, 1u);
+                w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+            }
+            if (w >= f.n_windows) {
+                f.no_more = true;
+                break;
+            }
+            f.list_base = w * WINDOW;
+            f.list_len = compact_window(wf, w, WF_READY, f.list);
+            f.list_pos = 0;
+            continue;
+        }
+        const uint32_t avail = f.list_len - f.list_pos;
+        const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+        if (need && rank < avail) {
+            q.slot = f.list_base + (uint32_t)f.list[f.list_pos + rank];
+            const RaySlot* rs = ray_slot(wf, q.slot);
+            q.o = mk(rs->o[0], rs->o[1], rs->o[2]);
+            q.d = mk(rs->d[0], rs->d[1], rs->d[2]);
+            n_rays++;
+            trav_init(sc, q.o, q.d, q.tv);
+            if (q.tv.cur == TRAV_DONE)
+                q.pending = true;  // missed the root box: retired at the next refill
+            else
+                q.active = true;
+            need = false;
+        }
+        const uint32_t wanted = (uint32_t)__popcll(need_mask);
+        f.list_pos += wanted < avail ? wanted : avail;
+        need_mask = __ballot(need);
+    }
+}
+
+RR_DEV V3 sel3(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+
+template <bool COMPACT, bool COUNT, int WPS>
+__global__ void __launch_bounds__(256, WPS) wf_trav2_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+    extern __shared__ uint32_t lds_dyn[];
+    WfCtl* ctl = wf.ctl;
+    if (ctl->live_slots == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    // dynamic LDS: per wave two stacks of (stack_lds + 1 spare) x 64 words (A then B), 4 window lists, hot records
+    const uint32_t stack_words = (sc.stack_lds + 1u) * 64u;
+    uint32_t* stack_a = lds_dyn + (size_t)wave * 2u * stack_words + lane;
+    const size_t spill_words = (size_t)(sc.stack_depth > sc.stack_lds ? sc.stack_depth - sc.stack_lds : 0u) * wf.trav_threads;
+    uint32_t* spill_a = wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x);
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 8u * (size_t)stack_words) + wave * WINDOW;
+    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 8u * (size_t)stack_words + 4u * WINDOW / 2u);
+    {
+        constexpr uint32_t G = COMPACT ? 8u : 16u;
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+        for (uint32_t i = threadIdx.x; i < sc.hot_records * G; i += 256u)
+            hot_lds[(i / G) * HotNodes::stride<COMPACT>() + i % G] = src[i];
+        __syncthreads();
+    }
+    const HotNodes hot{hot_lds, sc.hot_records};
+
+    WindowFeed feed;
+    feed.n_windows = wf.np / WINDOW;
+    feed.n_waves = gridDim.x * 4u;
+    feed.static_windows = ctl->live_slots < wf.np / 4u ? feed.n_windows : rp.static_windows;
+    feed.static_next = blockIdx.x * 4u + wave;
+    feed.list_pos = feed.list_len = feed.list_base = 0;
+    feed.no_more = false;
+    feed.list = list;
+
+    Query qa, qb;
+    qa.o = qb.o = mk(0, 0, 0), qa.d = qb.d = mk(0, 0, 1);
+    qa.tv.inv = qb.tv.inv = mk(0, 0, 0);
+    qa.tv.best_t = qb.tv.best_t = 0, qa.tv.best_prim = qb.tv.best_prim = 0xffffffffu;
+    qa.tv.cur = qb.tv.cur = TRAV_DONE, qa.tv.sp = qb.tv.sp = 0;
+    qa.slot = qb.slot = 0, qa.active = qb.active = false, qa.pending = qb.pending = false;
+    WorkCount wc{0, 0, 0, 0, 0};
+    unsigned long long n_rays = 0;
+    unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
+    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
+    const uint32_t refill_min2 = 2u * rp.refill_min;
+
+    for (;;) {
+        const bool a_int = qa.active && trav_at_interior(qa.tv), a_leaf = qa.active && !trav_at_interior(qa.tv);
+        const bool b_int = qb.active && trav_at_interior(qb.tv), b_leaf = qb.active && !trav_at_interior(qb.tv);
+        const bool l_int = a_int || b_int, l_leaf = a_leaf || b_leaf;
+        const int n_int = __popcll(__ballot(l_int));
+        const int n_leaf = __popcll(__ballot(l_leaf));
+        const uint32_t n_act = (uint32_t)__popcll(__ballot(qa.active)) + (uint32_t)__popcll(__ballot(qb.active));
+        if ((n_act < refill_min2 && !feed.no_more) || n_int + n_leaf == 0) {
+            trav2_retire(wf, qa);
+            trav2_retire(wf, qb);
+            if (feed.no_more) break;  // only reached with no query in flight
+            trav2_refill(sc, wf, ctl, feed, qa, n_rays);
+            if (!feed.no_more) trav2_refill(sc, wf, ctl, feed, qb, n_rays);
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_refill += now - tk_last, tk_last = now;
+            }
+            if (__ballot(qa.active || qa.pending || qb.active || qb.pending) == 0ull && feed.no_more) break;
+            continue;
+        }
+        if (n_leaf >= (int)rp.leaf_min || n_int == 0) {
+            // ---- leaf phase: a lane with a query on a leaf tests that leaf's primitives
+            if (COUNT) u_leaf_wave += 1, u_leaf_lane += l_leaf ? 1 : 0;
+            if (l_leaf) {
+                const bool ua = a_leaf;
+                const V3 o = sel3(ua, qa.o, qb.o), d = sel3(ua, qa.d, qb.d);
+                Trav tv;
+                tv.inv = mk(0, 0, 0);
+                tv.best_t = ua ? qa.tv.best_t : qb.tv.best_t;
+                tv.best_prim = ua ? qa.tv.best_prim : qb.tv.best_prim;
+                tv.cur = ua ? qa.tv.cur : qb.tv.cur;
+                tv.sp = ua ? qa.tv.sp : qb.tv.sp;
+                const LaneStack stack{stack_a + (ua ? 0u : stack_words), spill_a + (ua ? (size_t)0 : spill_words),
+                                      sc.stack_lds, wf.trav_threads};
+                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                const bool done = tv.cur == TRAV_DONE;
+                if (ua) {
+                    qa.tv.best_t = tv.best_t, qa.tv.best_prim = tv.best_prim, qa.tv.cur = tv.cur, qa.tv.sp = tv.sp;
+                    if (done) qa.active = false, qa.pending = true;
+                } else {
+                    qb.tv.best_t = tv.best_t, qb.tv.best_prim = tv.best_prim, qb.tv.cur = tv.cur, qb.tv.sp = tv.sp;
+                    if (done) qb.active = false, qb.pending = true;
+                }
+            }
+            if (COUNT) {
+                const unsigned long long now = clock64();
+                tk_leaf += now - tk_last, tk_last = now;
+            }
+        } else {
+            // ---- interior phase: one record for every lane with a query standing on one
+            if (COUNT) u_int_wave += 1, u_int_lane += l_int ? 1 : 0;
+            if (l_int) {
+                const bool ua = a_int;
+                const V3 o = sel3(ua, qa.o, qb.o);
+                Trav tv;
+                tv.inv = sel3(ua, qa.tv.inv, qb.tv.inv);
+                tv.best_t = ua ? qa.tv.best_t : qb.tv.best_t;
+                tv.best_prim = 0u;
+                tv.cur = ua ? qa.tv.cur : qb.tv.cur;
+                tv.sp = ua ? qa.tv.sp : qb.tv.sp;
+                const LaneStack stack{stack_a + (ua ? 0u : stack_words), spill_a + (ua ? (size_t)0 : spill_words),
+                                      sc.stack_lds, wf.trav_threads};
+                trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
+                const bool done = tv.cur == TRAV_DONE;
+                if (ua) {
+                    qa.tv.cur = tv.cur, qa.tv.sp = tv.sp;
+                    if (done) qa.active = false, qa.pending = true;
+                } else {
+                    qb.tv.cur = tv.cur, qb.tv.sp = tv.sp;
+                    if (done) qb.active = false, qb.pending = true;
+                }
             }
             if (COUNT) {
                 const unsigned long long now = clock64();
@@ -615,7 +869,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -688,11 +942,20 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             }
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
             if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
+            // the next query, answered here when it needs no walk (resolve_root)
+            uint8_t next_state = WF_READY;
+            double t_next = 0.0;
+            uint32_t prim_next = 0xffffffffu;
+            if (rp.early_resolve & 2u) {  // wave-uniform
+                const int q = goes_on ? resolve_root<COMPACT>(sc, position, dir, t_next, prim_next, sn.early) : RESOLVE_WALK;
+                if (q != RESOLVE_WALK) next_state = q == RESOLVE_HIT ? WF_HIT : WF_MISS, sn.resolved++;
+            }
             if (goes_on) {
                 RaySlot* rs = ray_slot(wf, slot);
                 rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
                 rs->d[0] = dir.x, rs->d[1] = dir.y, rs->d[2] = dir.z;
                 rs->bd = bd_next;
+                if (next_state == WF_HIT) rs->t = t_next, rs->prim = prim_next;
                 TailSlot* lt = tail_slot(wf, slot);
                 lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
                 const bool keep_light = !light_is_plus_zero(light);
@@ -701,7 +964,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     l[0] = light.x, l[1] = light.y, l[2] = light.z;
                 }
                 lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
-                wf.state[slot] = WF_READY;
+                wf.state[slot] = next_state;
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
@@ -710,7 +973,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
         rec_cur = rec_nxt;
@@ -741,7 +1004,7 @@ RR_DEV void load_miss_in(const WfDev& wf, MissIn& m) {  // idle lanes read slot 
     m.light = EAGER ? load_light(wf, m.slot) : mk(0.0, 0.0, 0.0);
 }
 
-template <bool EAGER>
+template <bool COMPACT, bool EAGER>
 __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     if (wf.ctl->live_slots == 0u) return;
@@ -750,7 +1013,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
@@ -773,7 +1036,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
         cur = nxt;
         have = have_next;
     }
@@ -785,8 +1048,8 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
 
 // ----------------------------------------------------------- launch glue
 
-static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
-    return 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
+static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records, bool two = false) {
+    return (two ? 2u : 1u) * 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
 }
 
 uint32_t wf_window_slots() { return WINDOW; }
@@ -796,17 +1059,29 @@ hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t wf_launch_gen(const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
+hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_gen_kernel, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    if (compact) hipLaunchKernelGGL(wf_gen_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else hipLaunchKernelGGL(wf_gen_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 
 template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
+    if (rp.trav_two) {
+        const uint32_t lds2 = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records, true);
+        if (rp.trav_two == 2u)
+            hipLaunchKernelGGL((wf_trav2_kernel<COMPACT, COUNT, 4>), dim3(blocks), dim3(256), lds2, stream, sc, rp, wf);
+        else
+            hipLaunchKernelGGL((wf_trav2_kernel<COMPACT, COUNT, 3>), dim3(blocks), dim3(256), lds2, stream, sc, rp, wf);
+        return hipGetLastError();
+    }
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (rp.leaf_single)
+        hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else
+        hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -819,18 +1094,47 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
                  : launch_trav_t<false, false>(sc, rp, wf, blocks, stream);
 }
 
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+template <bool COMPACT, bool COUNT, bool LEAF_ONE>
+static hipError_t trav_set_lds(uint32_t lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, LEAF_ONE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <bool COMPACT, bool COUNT, int WPS>
+static hipError_t trav2_set_lds(uint32_t lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav2_kernel<COMPACT, COUNT, WPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <bool COMPACT, int WPS>
+static hipError_t trav2_occupancy(uint32_t lds2, int* blocks_per_cu) {
+    hipError_t e;
+    if ((e = trav2_set_lds<COMPACT, false, WPS>(lds2)) != hipSuccess) return e;
+    if ((e = trav2_set_lds<COMPACT, true, WPS>(lds2)) != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav2_kernel<COMPACT, false, WPS>, 256, lds2);
+}
+
+// two_queries: 0 = wf_trav_kernel; 1 / 2 = wf_trav2_kernel built for three / four workgroups per CU
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, uint32_t two, int* blocks_per_cu) {
+    hipError_t e = hipSuccess;
+    if (two) {
+        const uint32_t lds2 = trav_lds_bytes(compact, stack_lds, hot_records, true);
+        if (compact) return two == 2u ? trav2_occupancy<true, 4>(lds2, blocks_per_cu) : trav2_occupancy<true, 3>(lds2, blocks_per_cu);
+        return two == 2u ? trav2_occupancy<false, 4>(lds2, blocks_per_cu) : trav2_occupancy<false, 3>(lds2, blocks_per_cu);
+    }
     const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
-    const void* fn = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, false>)
-                             : reinterpret_cast<const void*>(&wf_trav_kernel<false, false>);
-    const void* fnc = compact ? reinterpret_cast<const void*>(&wf_trav_kernel<true, true>)
-                              : reinterpret_cast<const void*>(&wf_trav_kernel<false, true>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (compact) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false>, 256, lds);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false>, 256, lds);
+    if (compact) {
+        if ((e = trav_set_lds<true, false, false>(lds)) != hipSuccess) return e;
+        if ((e = trav_set_lds<true, false, true>(lds)) != hipSuccess) return e;
+        if ((e = trav_set_lds<true, true, false>(lds)) != hipSuccess) return e;
+        if ((e = trav_set_lds<true, true, true>(lds)) != hipSuccess) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, true>, 256, lds);
+    }
+    if ((e = trav_set_lds<false, false, false>(lds)) != hipSuccess) return e;
+    if ((e = trav_set_lds<false, false, true>(lds)) != hipSuccess) return e;
+    if ((e = trav_set_lds<false, true, false>(lds)) != hipSuccess) return e;
+    if ((e = trav_set_lds<false, true, true>(lds)) != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, true>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
@@ -847,12 +1151,16 @@ hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, con
     return hipGetLastError();
 }
 
-hipError_t wf_launch_miss(bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
+hipError_t wf_launch_miss(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
                           const WfDev& wf, uint32_t blocks, hipStream_t stream) {
-    if (eager_light)
-        hipLaunchKernelGGL(wf_miss_kernel<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    if (compact && eager_light)
+        hipLaunchKernelGGL((wf_miss_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else if (compact)
+        hipLaunchKernelGGL((wf_miss_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else if (eager_light)
+        hipLaunchKernelGGL((wf_miss_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else
-        hipLaunchKernelGGL(wf_miss_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_miss_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 

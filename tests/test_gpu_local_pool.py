@@ -93,7 +93,7 @@ def test_horizon_and_sky_primary_rays():
     """Primary rays that miss the root Node's box (bvh.rs:394) never enter ISECT: they count as queries and as
     escaped paths, exactly as on the streaming route (direct_rays)."""
     cam_args, objs, heur = scenes.diffuse_single_sphere()
-    cam_args = ((0., 1., 10.), (0., 1., 0.), (0., 3., 0.), 70., 4., 3., 100)  # the horizon through the frame
+    cam_args = ((0., 5., 10.), (0., 1., 0.), (0., 5.5, 0.), 70., 4., 3., 100)  # the horizon through the frame
     (loc, lst), (stream, sst), (ref, ost) = frames(cam_args, objs, heur, 64, 48, 8, 50, 0)
     assert lst["direct_rays"] == sst["direct_rays"] > 0
     assert lst["rays"] == sst["rays"] == ost["rays"] and lst["escaped_paths"] == ost["escaped_paths"]
