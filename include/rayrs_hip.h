@@ -276,8 +276,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats);
  * the frame, which is copied to out_host.  A pixel is non-zero on exactly one rank, so the frame
  * equals the one-GPU frame bit for bit.  params->tile_rank / tile_ranks are ignored.  Handles on the
  * same device are allowed (rehearsal on one GPU): their buffers are summed on that device first.
- * RCCL is loaded at the first call; RAYRS_RCCL_ERROR if that or a collective fails.  stats: counters
- * summed over the ranks, times = the slowest rank's. */
+ * RCCL is loaded at the first call that spans more than one device; RAYRS_RCCL_ERROR if that or a collective
+ * fails.  stats: every counter summed over the ranks; times and kernel_launches = the slowest rank's. */
 int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camera* camera,
                        const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats);
 

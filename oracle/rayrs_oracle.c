@@ -1444,7 +1444,11 @@ typedef struct {
  * a primitive's computed t and the entry parameter of the box around it are rounded
  * independently, so a hit an ulp in front of its own box must not be lost
  * (rayrs_amd/csrc/device_path.h has the same constant; the counters only agree if both do). */
-#define TRAV_CULL_MARGIN (1.0 + 0x1p-40)
+/* the kernel's margin (device_path.h TRAV_CULL_MARGIN); orc_set_cull_margin swaps it for experiments
+ * (scripts/fuzz_traversal.py measures what a margin protects and what it costs) */
+static double g_cull_margin = 1.0 + 0x1p-10;
+void orc_set_cull_margin(double rel) { g_cull_margin = 1.0 + rel; }
+#define TRAV_CULL_MARGIN g_cull_margin
 
 /* The kernel's traversal, restated on the flattened tree: children tested at
  * the parent, near child first, far child pushed, boxes whose entry lies
@@ -1905,6 +1909,121 @@ int64_t orc_bvh_intersect(const orc_scene* s, const double o[3], const double d[
     if (!h.hit) return -1;
     *t = h.t;
     return h.obj;
+}
+
+/* ---- batches of queries (scripts/fuzz_traversal.py, tests): n rays, o and d as n*3 doubles ---- */
+
+typedef struct {
+    const orc_scene* s;
+    uint64_t n;
+    const double *o, *d;
+    double tmin, tmax;
+    int traversal, nthreads, index;
+    double* t_out;
+    int64_t* obj_out;
+    double* worst;   /* per thread: 3 doubles (margin probe) */
+} batch_job;
+
+static void* intersect_batch_worker(void* arg) {
+    batch_job* j = (batch_job*)arg;
+    for (uint64_t i = (uint64_t)j->index; i < j->n; i += (uint64_t)j->nthreads) {
+        double t = 0.0;
+        j->obj_out[i] = orc_bvh_intersect(j->s, j->o + 3 * i, j->d + 3 * i, j->tmin, j->tmax, j->traversal, &t);
+        j->t_out[i] = t;
+    }
+    return NULL;
+}
+
+/* orc_bvh_intersect for n rays on nthreads threads: t_out[i] and obj_out[i] (-1 = miss). */
+int orc_bvh_intersect_batch(const orc_scene* s, uint64_t n, const double* o, const double* d, double tmin, double tmax,
+                            int traversal, int nthreads, double* t_out, int64_t* obj_out) {
+    if (!s || !s->built) return -2;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    batch_job jobs[256];
+    pthread_t th[256];
+    for (int k = 0; k < nthreads; k++) {
+        batch_job j = {s, n, o, d, tmin, tmax, traversal, nthreads, k, t_out, obj_out, NULL};
+        jobs[k] = j;
+    }
+    for (int k = 1; k < nthreads; k++) pthread_create(&th[k], NULL, intersect_batch_worker, &jobs[k]);
+    intersect_batch_worker(&jobs[0]);
+    for (int k = 1; k < nthreads; k++) pthread_join(th[k], NULL);
+    return 0;
+}
+
+/* How far in front of the boxes around it can a primitive's computed t lie?  The traversal kernel skips a
+ * slot whose box is entered beyond closest_t * (1 + 2^-10) (TRAV_CULL_MARGIN; the reference never culls), which
+ * is exact as long as no accepted hit precedes the entry parameter of a box on its own root path by more than
+ * that margin.  This probe walks the product's wide tree WITHOUT culling and, for every accepted hit t behind
+ * boxes entered at e_1 <= ... (the slots on its path), records rel = (max e - t) / t:
+ *   out[0] = largest rel seen (<= 0: every hit lies at or behind its boxes' entries)
+ *   out[1] = number of accepted hits with rel > 0,  out[2] = number with rel > the margin in force */
+static void margin_probe_rec(const orc_scene* s, ray_t ray, v3 inv, double tmin, double tmax, uint32_t ref,
+                             double path_entry, double* out) {
+    if ((ref >> 30) == REF_KIND_INTERIOR) {
+        uint32_t rec = ref & 0x3fffffffu;
+        const uint32_t* refs = s->wide_ref + (size_t)rec * 4;
+        for (int c = 0; c < 4; c++) {
+            uint32_t kind = refs[c] >> 30;
+            double e;
+            if (kind == REF_KIND_NONE) continue;
+            if (kind != REF_KIND_SINGLE &&
+                !aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &e))
+                continue;
+            if (kind == REF_KIND_SINGLE) e = tmin;
+            margin_probe_rec(s, ray, inv, tmin, tmax, refs[c], e > path_entry ? e : path_entry, out);
+        }
+        return;
+    }
+    uint32_t first = (ref & 0x3fffffffu) >> 2, count = (ref & 3u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+        const shape_t* g = &s->objs[s->prim_object[first + k]].geom;
+        double t;
+        if (shape_intersect(g, ray, &t) && t > tmin && t < tmax) {
+            double rel = (path_entry - t) / t;
+            if (rel > out[0]) out[0] = rel;
+            if (rel > 0.0) out[1] += 1.0;
+            if (rel > g_cull_margin - 1.0) out[2] += 1.0;
+        }
+    }
+}
+
+static void* margin_probe_worker(void* arg) {
+    batch_job* j = (batch_job*)arg;
+    const orc_scene* s = j->s;
+    for (uint64_t i = (uint64_t)j->index; i < j->n; i += (uint64_t)j->nthreads) {
+        ray_t r = {v_from(j->o + 3 * i), v_from(j->d + 3 * i)};
+        v3 inv = V(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+        double e;
+        if (!aabb_intersect_entry(s->finfo.root_box, r, inv, j->tmin, j->tmax, &e)) continue;
+        margin_probe_rec(s, r, inv, j->tmin, j->tmax, s->finfo.wide_root_ref, e, j->worst);
+    }
+    return NULL;
+}
+
+int orc_cull_margin_probe(const orc_scene* s, uint64_t n, const double* o, const double* d, double tmin, double tmax,
+                          int nthreads, double out[3]) {
+    if (!s || !s->built || !s->have_wide) return -2;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    batch_job jobs[256];
+    pthread_t th[256];
+    static double worst[256][3];
+    for (int k = 0; k < nthreads; k++) {
+        worst[k][0] = -1.0, worst[k][1] = worst[k][2] = 0.0;
+        batch_job j = {s, n, o, d, tmin, tmax, 2, nthreads, k, NULL, NULL, worst[k]};
+        jobs[k] = j;
+    }
+    for (int k = 1; k < nthreads; k++) pthread_create(&th[k], NULL, margin_probe_worker, &jobs[k]);
+    margin_probe_worker(&jobs[0]);
+    for (int k = 1; k < nthreads; k++) pthread_join(th[k], NULL);
+    out[0] = -1.0, out[1] = out[2] = 0.0;
+    for (int k = 0; k < nthreads; k++) {
+        if (worst[k][0] > out[0]) out[0] = worst[k][0];
+        out[1] += worst[k][1], out[2] += worst[k][2];
+    }
+    return 0;
 }
 
 int orc_material_evaluate(const orc_material* m, const double position[3], const double normal[3],

@@ -202,6 +202,17 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);
 
+/* orc_bvh_intersect for n rays (o, d: n*3 doubles) on nthreads threads: t_out[i], obj_out[i] (-1 = miss). */
+int orc_bvh_intersect_batch(const orc_scene* s, uint64_t n, const double* o, const double* d, double tmin, double tmax,
+                            int traversal, int nthreads, double* t_out, int64_t* obj_out);
+/* How far in front of the boxes around it a primitive's computed t lies, over n rays on the product's walk tree
+ * (orc_set_wide), walked without culling: out[0] = largest (entry - t) / t over accepted hits and the boxes on
+ * their root paths, out[1] = hits with a positive value, out[2] = hits beyond the cull margin in force (2^-10). */
+/* experiments only: the relative margin of traversal 1 / 2's closest-hit culling (default: the kernel's) */
+void orc_set_cull_margin(double rel);
+int orc_cull_margin_probe(const orc_scene* s, uint64_t n, const double* o, const double* d, double tmin, double tmax,
+                          int nthreads, double out[3]);
+
 #ifdef __cplusplus
 }
 #endif

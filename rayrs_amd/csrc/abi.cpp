@@ -210,6 +210,8 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
             if (e) (void)hipEventDestroy(e);
     }
     if (s->d_next_item) (void)hipFree(s->d_next_item);
+    if (s->multi_out) (void)hipFree(s->multi_out);
+    if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
     if (s->d_local_light) (void)hipFree(s->d_local_light);
     if (s->d_local_items) (void)hipFree(s->d_local_items);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);

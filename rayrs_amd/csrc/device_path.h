@@ -269,7 +269,17 @@ RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 // fetched whole, with loads that do not depend on its contents, before anything
 // is decided from it.
 constexpr uint32_t TRAV_DONE = 0xffffffffu;
-constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-40;  // see trav_interior_step; t > t0 >= 0 (lib.rs:234)
+// Closest-hit culling is the one place where the walk is exact in practice, not by construction (the reference
+// never culls): a slot is skipped when its box is entered beyond best_t * TRAV_CULL_MARGIN, which loses a hit
+// only if a primitive's computed t lies in front of the entry parameter of a box around it by more than the
+// margin AND another accepted hit falls in between.  Moeller-Trumbore's t has a relative error of about
+// eps * (distance / size) / (grazing angle), so no fixed margin covers every ray.  Measured with
+// scripts/fuzz_traversal.py (60 M rays on sliver meshes and nearly flat sheets, origins up to 10^6 scene sizes
+// away): rays at 10^-7 rad and more off a triangle's plane put t at most 2^-44.8 in front of a box; rays aimed
+// along the plane itself broke a margin of 2^-40 in 59 of 1.6 M cases at 10^-5..10^-3 rad, 2^-24 in 7, 2^-16 and
+// 2^-10 in none; 2^-10 failed once in 1.6 M at less than 10^-11 rad.  2^-10 costs 0.4 % more record visits and
+// 0.7 % more primitive tests on the headline scene (2^-40: round 2's value).  t > t0 >= 0 (lib.rs:234).
+constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-10;
 
 // A lane's traversal stack.  Entry k lives in LDS at lds[k * 64] while k < cap; deeper
 // entries, which only the worst-case visit order of a deep tree reaches, go to a per-lane
@@ -406,9 +416,9 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     // Unused slots need no special case here: they carry the inverted box (scene_host.cpp), for
     // which the slab test above says "missed".  Boxes entered beyond the closest hit so far are
-    // skipped -- beyond it by a margin of 2^-40 relative: a primitive's computed t and the entry
-    // parameter of the box around it are rounded independently, so a hit an ulp or two in front
-    // of its own box must not be lost to a farther one (every primitive that is tested is judged
+    // skipped -- beyond it by TRAV_CULL_MARGIN: a primitive's computed t and the entry parameter of the
+    // box around it are rounded independently (and t badly so on grazing rays), so a hit computed in
+    // front of its own box must not be lost to a farther one (every primitive that is tested is judged
     // by the reference's rule, so a wider margin only costs visits, never the answer).
     const double cull = tv.best_t * TRAV_CULL_MARGIN;
     h0 = h0 && !(e0 > cull);

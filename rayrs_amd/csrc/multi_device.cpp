@@ -132,9 +132,18 @@ void render_rank(Rank& r, const rayrs_camera* camera, rayrs_render_params params
         r.status = st;
         r.error = rayrs_last_error();  // this thread's text
     };
-    hipError_t e = hipSetDevice(r.scene->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&r.d_out, bytes);
+    // the rank's stream and framebuffer live in the scene handle: a frame of a few milliseconds (the sphere scenes)
+    // would otherwise spend as long creating and freeing them as rendering
+    rayrs_scene* s = r.scene;
+    hipError_t e = hipSetDevice(s->device);
+    if (e == hipSuccess && !s->multi_stream) e = hipStreamCreateWithFlags(&s->multi_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && s->multi_out_bytes < bytes) {
+        if (s->multi_out) (void)hipFree(s->multi_out);
+        s->multi_out = nullptr, s->multi_out_bytes = 0;
+        e = hipMalloc(&s->multi_out, bytes);
+        if (e == hipSuccess) s->multi_out_bytes = bytes;
+    }
+    r.stream = s->multi_stream, r.d_out = s->multi_out;
     if (e == hipSuccess) e = hipMemsetAsync(r.d_out, 0, bytes, r.stream);  // the tiles of the other ranks stay exact zeros
     if (e != hipSuccess) return fail(hip_fail(e, "rayrs_render_multi: device setup"));
     int st = rayrs_render_launch(r.scene, camera, &params, r.d_out, r.stream);
@@ -161,6 +170,14 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
         // ---- every rank renders its tiles on its own host thread and stream
         std::vector<Rank> ranks(n);
         std::vector<std::thread> threads;
+        threads.reserve(n);
+        struct JoinAll {  // a std::system_error from a later emplace_back must not destroy joinable threads (std::terminate)
+            std::vector<std::thread>& t;
+            ~JoinAll() {
+                for (auto& x : t)
+                    if (x.joinable()) x.join();
+            }
+        } join_all{threads};
         for (uint32_t i = 0; i < n; i++) {
             ranks[i].scene = scenes[i];
             rayrs_render_params p = *params;
@@ -195,14 +212,15 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 }
             }
         }
-        if (st == RAYRS_OK && n > 1) st = rccl_reduce_to_first(devs, bufs, streams, count, f64);
+        // one device (a rehearsal with several handles on it): everything is summed already, no collective, no RCCL
+        if (st == RAYRS_OK && devs.size() > 1) st = rccl_reduce_to_first(devs, bufs, streams, count, f64);
         if (st == RAYRS_OK) {
             hipError_t e = hipSetDevice(devs[0]);
             if (e == hipSuccess) e = hipMemcpy(out_host, bufs[0], bytes, hipMemcpyDeviceToHost);
             if (e != hipSuccess) st = hip_fail(e, "rayrs_render_multi: hipMemcpy(out D2H)");
         }
         if (st == RAYRS_OK && stats) {
-            *stats = ranks[0].stats;  // times of rank 0; counters summed over the ranks
+            *stats = ranks[0].stats;  // every counter summed over the ranks; times and launches: the slowest rank's
             for (uint32_t i = 1; i < n; i++) {
                 const rayrs_render_stats& s = ranks[i].stats;
                 stats->rays += s.rays, stats->paths += s.paths, stats->nan_pixels += s.nan_pixels;
@@ -210,15 +228,18 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->interior_visits += s.interior_visits, stats->tri_tests += s.tri_tests;
                 stats->sphere_tests += s.sphere_tests, stats->plane_tests += s.plane_tests;
                 stats->direct_rays += s.direct_rays;
+                stats->step_wave += s.step_wave, stats->step_lane += s.step_lane;
+                stats->inner_wave += s.inner_wave, stats->leaf_wave += s.leaf_wave;
+                stats->interior_ticks += s.interior_ticks, stats->leaf_ticks += s.leaf_ticks;
+                stats->refill_ticks += s.refill_ticks;
+                for (int k = 0; k < 8; k++) stats->surface_hits[k] += s.surface_hits[k];
+                stats->early_visits += s.early_visits, stats->early_tri_tests += s.early_tri_tests;
+                stats->early_sphere_tests += s.early_sphere_tests, stats->early_plane_tests += s.early_plane_tests;
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
                 if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
                 if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;
+                if (s.kernel_launches > stats->kernel_launches) stats->kernel_launches = s.kernel_launches;
             }
-        }
-        for (auto& r : ranks) {
-            if (r.scene->device >= 0) (void)hipSetDevice(r.scene->device);
-            if (r.d_out) (void)hipFree(r.d_out);
-            if (r.stream) (void)hipStreamDestroy(r.stream);
         }
         return st;
     })

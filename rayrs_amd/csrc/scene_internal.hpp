@@ -66,6 +66,10 @@ struct rayrs_scene {
     double* d_local_light = nullptr;  // 4 doubles per resident path
     size_t local_light_paths = 0;
     unsigned long long* d_local_items = nullptr;  // one item counter per launch segment
+    // rayrs_render_multi: this rank's stream and zeroed full-size framebuffer, kept between calls
+    hipStream_t multi_stream = nullptr;
+    void* multi_out = nullptr;
+    size_t multi_out_bytes = 0;
     rayrs_tuning tuning = {};  // zeros = defaults (rayrs_scene_set_tuning)
 };
 

@@ -1,5 +1,9 @@
-"""One-off stress of the parity claim: many random scenes (tests/test_gpu_render.py::_random_scene) rendered on
-the GPU and by the oracle, frames compared bit for bit, ray and work counts compared.  GPU box only.
+"""Stress of the parity claim: many random scenes (tests/test_gpu_render.py::_random_scene) rendered on the GPU
+and by the oracle TWICE -- with the reference's recursion (traversal=0: BvhTree::intersect, bvh.rs:391-415, on the
+oracle's own restatement of the reference's tree; frame bits, ray / path / escaped-path counts) and with the
+kernel's walk on the product's exported records (traversal=2; the work counters too).  The first comparison is
+the parity claim; the second only says the counters of the roofline are the walk's.  Every third scene is also
+rendered on the other route (rayrs_tuning.local_pool toggled) when the scene qualifies.  GPU box only.
 usage: python scripts/fuzz_parity.py [first_seed] [count]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +17,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 HDRI = procedural.make_hdri(256, 128)
 bad = 0
+n_both = 0
 t0 = time.time()
 for seed in range(first, first + count):
     r = np.random.default_rng(seed ^ 0xABCDEF)
@@ -21,6 +26,8 @@ for seed in range(first, first + count):
     chunk = int(r.choice([0, 1, 3, 4, 5]))
     mb = int(r.choice([1, 2, 5, 50]))
     cam_args, objs, heur = T._random_scene(seed)
+    if seed % 4 == 2:  # a handful of primitives: at most one walk-tree record, rendered by the local pool
+        objs = objs[:int(r.integers(2, 10))]
     if seed % 3 == 0:  # no emitters: the one-line slot
         from rayrs_amd.api import Emission, Object
         for o in objs:
@@ -33,14 +40,23 @@ for seed in range(first, first + count):
     if seed % 5 == 0:
         scene.set_tuning(pool_slots=int(r.integers(1, 40)) * 1024)
     img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
+    ref0, ost0 = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)   # the reference's recursion
+    ok = np.array_equal(img.view(np.uint64), ref0.view(np.uint64))
+    for k in ("rays", "paths", "escaped_paths"):
+        ok = ok and st[k] == ost0[k]
     ref, ost = osc.use_walk_tree(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
-    ok = np.array_equal(img.view(np.uint64), ref.view(np.uint64))
+    ok = ok and np.array_equal(img.view(np.uint64), ref.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
         ok = ok and st[k] == ost[k]
+    if seed % 3 == 1 and scene.info()["local_pool"]:  # the streaming kernels on a scene the local pool renders
+        scene.set_tuning(local_pool=1)
+        img2, st2 = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
+        ok = ok and np.array_equal(img2.view(np.uint64), ref0.view(np.uint64)) and st2["rays"] == ost0["rays"]
+        n_both += 1
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, w, h, spp, chunk, mb, {k: (st[k], ost[k]) for k in ("rays", "interior_visits")}, flush=True)
     if (seed - first) % 20 == 19:
         print(f"{seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print("done:", count, "scenes,", bad, "mismatches")
+print("done:", count, "scenes,", bad, "mismatches;", n_both, "scenes rendered on both routes")
 sys.exit(1 if bad else 0)

@@ -1,0 +1,144 @@
+"""CPU-only fuzz of the claim the traversal kernel rests on: the walk over the product's four-slot records
+(oracle traversal=2: nearest-first order, slots entered beyond closest_t * TRAV_CULL_MARGIN = 1 + 2^-10 culled)
+returns the hit of the reference's recursion (traversal=0: BvhTree::intersect, bvh.rs:391-415, which never
+culls) -- on the geometry and rays where Moeller-Trumbore's t is least accurate: sliver triangles, nearly
+coplanar tessellated sheets whose group boxes are almost flat (hits sit on box faces), origins up to 1e6 scene
+sizes away, and two families of directions:
+  general   elevations 1e-7 .. 1 rad over the sheet's mean plane, axis-aligned directions (0 * inf in the slab test)
+  grazing   IN the plane of a chosen triangle plus 1e-13 .. 1e-3 of its normal, aimed at a point inside it
+The culling is exact in practice, not by construction: the walk is REQUIRED to match on the general family and on
+grazing rays 1e-7 rad and more off the plane (exit code); closer than that mismatches are counted and reported
+(the error of t grows like eps * distance / triangle size / angle: at 1e-9 rad and 5000 triangle sizes it reaches the margin).
+Also measures the margin itself: the largest (box entry - t) / t over all accepted hits and the boxes on their
+root paths (oracle: orc_cull_margin_probe), per family.
+
+usage: python scripts/fuzz_traversal.py [rays_in_millions=10] [first_seed=1]
+No GPU: the product's walk tree comes from a host-only scene (device = -1)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import _oracle, rayrs_amd
+from rayrs_amd.api import BvhHeuristic, Emission, Material, Object
+
+MAT = Material.LambertianDiffuse((0.5, 0.5, 0.5))
+
+
+def sheet(rng, n, tilt, sliver):
+    """(n x n) quads of a nearly planar sheet y = tilt * (ax + bz) + c as f32 vertices; `sliver` squeezes every
+    other column of vertices towards its neighbour (aspect ratios up to 1 / sliver)."""
+    u = np.linspace(-1.0, 1.0, n + 1)
+    x, z = np.meshgrid(u, u, indexing="ij")
+    x = x.copy()
+    x[1::2, :] = x[0:-1:2, :][: x[1::2, :].shape[0]] + sliver * (2.0 / n)
+    a, b = rng.normal(size=2)
+    y = tilt * (a * x + b * z) + rng.uniform(-0.5, 0.5)
+    verts = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    idx = []
+    for i in range(n):
+        for j in range(n):
+            p = i * (n + 1) + j
+            idx += [(p, p + 1, p + n + 1), (p + 1, p + n + 2, p + n + 1)]
+    return verts, np.array(idx, dtype=np.uint32)
+
+
+def scene_for(seed):
+    rng = np.random.default_rng(seed)
+    kind = seed % 4
+    tilt = [0.0, 1e-6, 1e-3, 0.3][kind] if seed % 8 < 4 else float(10.0 ** rng.uniform(-7, -1))
+    sliver = float(10.0 ** rng.uniform(-6, 0)) if seed % 3 else 1.0
+    n = int(rng.integers(6, 40))
+    verts, idx = sheet(rng, n, tilt, min(sliver, 1.0))
+    scale = float(10.0 ** rng.uniform(-3, 3)) if seed % 5 == 0 else 1.0
+    verts = (verts * scale).astype(np.float32)
+    objs = Object.from_triangles(verts, idx, MAT, Emission.Dark())
+    if seed % 7 == 0:  # a second sheet crossing the first: coincident / abutting hits
+        v2, i2 = sheet(rng, max(4, n // 2), tilt * 3.0 + 1e-4, 1.0)
+        objs += Object.from_triangles((v2 * scale).astype(np.float32), i2, MAT, Emission.Dark())
+    heur = BvhHeuristic.Sah(int(rng.choice([4, 32, 1000]))) if seed % 2 else BvhHeuristic.Midpoint
+    return objs, heur, scale, verts, idx
+
+
+def grazing_rays(rng, verts, idx, scale, n):
+    """Rays aimed at a point inside a chosen triangle, their direction in that triangle's own plane plus a
+    component 10^-13 .. 10^-3 along its normal: Moeller-Trumbore's denominator P.e1 is then all cancellation."""
+    v = verts.astype(np.float64)
+    tri = idx[rng.integers(0, len(idx), size=n)]
+    p1, p2, p3 = v[tri[:, 0]], v[tri[:, 1]], v[tri[:, 2]]
+    nrm = np.cross(p2 - p1, p3 - p1)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    b = rng.dirichlet((1.0, 1.0, 1.0), size=n)
+    target = b[:, :1] * p1 + b[:, 1:2] * p2 + b[:, 2:] * p3
+    inplane = (p2 - p1) * rng.normal(size=(n, 1)) + (p3 - p1) * rng.normal(size=(n, 1))
+    inplane /= np.maximum(np.linalg.norm(inplane, axis=1, keepdims=True), 1e-300)
+    eps = 10.0 ** rng.uniform(-13, -3, size=(n, 1))
+    d = inplane + eps * rng.choice([-1.0, 1.0], size=(n, 1)) * nrm
+    dist = scale * 10.0 ** rng.uniform(-3, 6, size=(n, 1))
+    o = target - d * dist
+    return o, d * 10.0 ** rng.uniform(-3, 3, size=(n, 1)), eps[:, 0]
+
+
+def rays_for(rng, verts, scale, n):
+    """Targets on the mesh (vertices, edge midpoints, random points of the bounding rectangle), directions grazing
+    the sheet at angles 1e-7 .. 1 rad, origins 1e-3 .. 1e6 scene sizes back along the direction."""
+    lo, hi = verts.min(axis=0).astype(np.float64), verts.max(axis=0).astype(np.float64)
+    pick = rng.integers(0, len(verts), size=n)
+    target = verts[pick].astype(np.float64)
+    jitter = rng.uniform(-1, 1, size=(n, 3)) * (hi - lo + 1e-30) * (10.0 ** rng.uniform(-9, -1, size=(n, 1)))
+    target = np.where(rng.random((n, 1)) < 0.5, target + jitter, rng.uniform(lo, hi, size=(n, 3)))
+    ang = 10.0 ** rng.uniform(-7, 0, size=n)
+    phi = rng.uniform(0, 2 * np.pi, size=n)
+    d = np.stack([np.cos(phi) * np.cos(ang), np.sin(ang) * rng.choice([-1.0, 1.0], size=n), np.sin(phi) * np.cos(ang)], axis=1)
+    axis_aligned = rng.random(n) < 0.05  # exact zeros in the direction: 0 * inf in the slab test
+    d[axis_aligned] = np.eye(3)[rng.integers(0, 3, size=int(axis_aligned.sum()))] * rng.choice([-1.0, 1.0], size=(int(axis_aligned.sum()), 1))
+    dist = scale * 10.0 ** rng.uniform(-3, 6, size=(n, 1))
+    o = target - d * dist
+    d = d * 10.0 ** rng.uniform(-3, 3, size=(n, 1))  # directions are not unit in the reference (lib.rs:202-210)
+    return o, d
+
+
+def main():
+    millions = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    per_scene = 250_000
+    n_scenes = max(1, int(millions * 1e6 / per_scene))
+    hdri = np.zeros((2, 2, 3), dtype=np.float32)
+    fam = {k: dict(rays=0, hits=0, bad=0, worst=-1.0, in_front=0, beyond=0) for k in ("general", "grazing >= 1e-7", "grazing 1e-9..1e-7", "grazing < 1e-9")}
+    t0 = time.time()
+    for seed in range(first, first + n_scenes):
+        objs, heur, scale, verts, idx = scene_for(seed)
+        tmin, tmax = 1e-6 * scale, 1e9 * scale
+        prod = rayrs_amd.Scene(objs, tmin, tmax, heur, hdri, device=-1)
+        osc = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod)
+        rr = np.random.default_rng(seed * 7919 + 1)
+        og, dg = rays_for(rr, verts, scale, per_scene // 2)
+        oz, dz, eps = grazing_rays(rr, verts, idx, scale, per_scene - per_scene // 2)
+        far, near = eps >= 1e-7, eps < 1e-9
+        mid = ~far & ~near
+        for name, o, d in (("general", og, dg), ("grazing >= 1e-7", oz[far], dz[far]), ("grazing 1e-9..1e-7", oz[mid], dz[mid]),
+                           ("grazing < 1e-9", oz[near], dz[near])):
+            f = fam[name]
+            ta, oa = osc.intersect_batch(o, d, tmin, tmax, traversal=0)
+            tb, ob = osc.intersect_batch(o, d, tmin, tmax, traversal=2)
+            bad = (oa != ob) | (ta.view(np.uint64) != tb.view(np.uint64))
+            w, nf, nb = osc.cull_margin_probe(o, d, tmin, tmax)
+            f["rays"] += len(o); f["hits"] += int((oa >= 0).sum()); f["bad"] += int(bad.sum())
+            f["worst"] = max(f["worst"], w); f["in_front"] += nf; f["beyond"] += nb
+            if bad.any() and name in ("general", "grazing >= 1e-7"):
+                i = int(np.argmax(bad))
+                print(f"MISMATCH ({name}) seed {seed}: o={o[i].tolist()} d={d[i].tolist()} reference=({oa[i]}, {ta[i]!r}) "
+                      f"walk=({ob[i]}, {tb[i]!r})", flush=True)
+        if (seed - first) % 16 == 15 or seed == first + n_scenes - 1:
+            for name, f in fam.items():
+                lw = np.log2(f["worst"]) if f["worst"] > 0 else float("-inf")
+                print(f"{name:18s} {f['rays'] / 1e6:7.2f} M rays {f['hits'] / 1e6:7.2f} M hits  mismatches {f['bad']:5d}  largest (entry - t)/t "
+                      f"{f['worst']:.3e} (2^{lw:.1f})  hits in front of a box {f['in_front']}, beyond the margin {f['beyond']}", flush=True)
+            print(f"  {time.time() - t0:.0f} s", flush=True)
+    required = fam["general"]["bad"] + fam["grazing >= 1e-7"]["bad"]
+    print("done:", sum(f["rays"] for f in fam.values()), "rays; mismatches where the walk must match:", required,
+          "; at 1e-9..1e-7 rad off a triangle's plane:", fam["grazing 1e-9..1e-7"]["bad"], "; closer:", fam["grazing < 1e-9"]["bad"])
+    sys.exit(1 if required else 0)
+
+
+if __name__ == "__main__":
+    main()

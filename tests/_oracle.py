@@ -100,6 +100,10 @@ def lib():
     L.orc_orthonormal_basis.restype = None
     L.orc_aabb_expand.argtypes = [dp, dp, dp]
     L.orc_aabb_expand.restype = None
+    L.orc_bvh_intersect_batch.argtypes = [vp, C.c_uint64, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
+    L.orc_cull_margin_probe.argtypes = [vp, C.c_uint64, vp, vp, C.c_double, C.c_double, C.c_int, vp]
+    L.orc_set_cull_margin.argtypes = [C.c_double]
+    L.orc_set_cull_margin.restype = None
     L.orc_set_math_mode.argtypes = [C.c_int]
     L.orc_set_math_mode.restype = None
     _lib = L
@@ -128,6 +132,11 @@ def emis_desc(e) -> OrcEmission:
     d.strength = e.strength
     d.color[:] = e.color
     return d
+
+
+def set_cull_margin(rel: float):
+    """Experiments only: the relative margin of the ordered walks' closest-hit culling (default: the kernel's, 2^-10)."""
+    lib().orc_set_cull_margin(float(rel))
 
 
 def set_math_mode(libm: bool):
@@ -257,6 +266,31 @@ class OracleScene:
             objs[i] = ob
             ts[i] = t if ob >= 0 else 0.0
         return ts, objs
+
+    def intersect_batch(self, o, d, tmin, tmax, traversal=0, nthreads=None):
+        """Bvh::intersect for n rays in one call, on all cores: (t[n], object[n]) with -1 for a miss."""
+        o = np.ascontiguousarray(o, dtype=np.float64)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        n = len(o)
+        ts = np.zeros(n)
+        objs = np.full(n, -1, dtype=np.int64)
+        rc = self._L.orc_bvh_intersect_batch(self._h, n, o.ctypes.data, d.ctypes.data, float(tmin), float(tmax),
+                                             int(traversal), int(nthreads or os.cpu_count() or 1), ts.ctypes.data,
+                                             objs.ctypes.data)
+        assert rc == 0
+        ts[objs < 0] = 0.0
+        return ts, objs
+
+    def cull_margin_probe(self, o, d, tmin, tmax, nthreads=None):
+        """(largest (box entry - t) / t over accepted hits and the boxes around them, hits in front of a box of
+        theirs, hits beyond the kernel's cull margin) on the product's walk tree (use_walk_tree first)."""
+        o = np.ascontiguousarray(o, dtype=np.float64)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        out = np.zeros(3)
+        rc = self._L.orc_cull_margin_probe(self._h, len(o), o.ctypes.data, d.ctypes.data, float(tmin), float(tmax),
+                                           int(nthreads or os.cpu_count() or 1), out.ctypes.data)
+        assert rc == 0
+        return float(out[0]), int(out[1]), int(out[2])
 
     def background(self, dirs):
         dirs = np.asarray(dirs, dtype=np.float64)
