@@ -5,19 +5,20 @@ configuration (configs[4]: floor + 1,310,720-triangle mesh, 2048x2048, 1024 spp,
 
 One step = one full frame: every 8x8 image tile of this rank pushed through the
 gfx950 path pipeline (persistent traversal kernel + hit/miss kernels, one round
-per bounce), the per-pixel resolve, and (N > 1) one RCCL reduce of the f32x3
-framebuffer to rank 0.  Tiles are interleaved over ranks (tile t ->
+per bounce; scenes of at most one walk-tree record -- configs 1, 2, 4 -- through the
+local-pool kernel instead, every path resident in LDS), the per-pixel resolve, and
+(N > 1) one RCCL reduce of the f32x3 framebuffer to rank 0.  Tiles are interleaved over ranks (tile t ->
 rank t % N), the scene is replicated, total work is fixed: strong scaling.
 `value` = BVH queries of all ranks / max-over-ranks wall time (scene build,
 upload and file I/O excluded -- the region the reference times, main.rs:59-100).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline     -- the dominant kernel (wf_trav_kernel) against the ceiling that binds it, FP64 vector
-                  issue: useful f64 lane-operations per launch (the kernel's own work counters x the
-                  operation model below) / its HIP-event duration / (256 CU x 4 SIMD x 16 lanes x
-                  2.4 GHz).  Beside it: algorithmic bytes and, from the PMC passes of
-                  scripts/profile_round.sh when they were taken on THIS source tree, fabric traffic and
-                  VALU occupancy;
+  roofline     -- the kernel with the largest share of the step (named in `kernel`; every kernel's share and
+                  fraction is in `kernels`) against the ceiling that binds it, FP64-rate vector issue: useful
+                  lane-operations per launch (the frame's work counters x the operation model below) / its
+                  HIP-event duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz).  Beside it: algorithmic bytes
+                   and, from the PMC passes of scripts/profile_round.sh when they were taken
+                  on THIS source tree, fabric traffic and VALU occupancy of that kernel;
   ray_shares   -- what the frame's BVH queries hit (floor / mesh / nothing ...);
   cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed traversal over a pointer
                   tree, rayrs-lib's algorithm) timed on this box's host cores on a bounded band of the
@@ -56,13 +57,60 @@ OPS_PLANE = 26             # geometry.rs:229-271: 1 div x 11, 1 sub, 3 mul, 3 ad
 OPS_RAY = 54               # 1/d (3 div x 11) + the root box test (21)
 
 
-def useful_f64_ops(stats, info):
-    """Of the traversal kernel.  Primary rays that miss the root box never reach it (direct_rays: the kernel
-    that makes them finishes their sample)."""
+# Vector instructions one evaluation of a shading unit costs when the unit is compiled alone and all 64 lanes work:
+# SQ_INSTS_VALU x 64 / evaluations of rayrs_test_material / rayrs_test_background on 2 M random tuples each, minus
+# the test kernel's own loads and stores (scripts/op_model.sh; profiles/r03_op_model.json).  The dielectrics are
+# evaluated with half of the hits from inside the medium; their arms branch (reflect / refract / total internal
+# reflection), and a wave runs every branch one of its lanes takes -- that is part of what the arm costs.
+OPS_MATERIAL = {
+    "lambertian": 317, "reflect": 30, "refract": 136, "glass": 248, "cook_torrance": 831,
+    "cook_torrance_refract": 1120, "cook_torrance_glass": 2120, "plastic": 1187, "no_reflect": 0,
+}
+OPS_BACKGROUND = 495       # Scene::background: unit, atan2, acos, the 2x2 footprint, 12 products (lib.rs:254-285)
+# counted in the source (rayrs_amd/csrc/wavefront.hip, device_path.h), like the traversal units:
+OPS_HIT_FIXED = 150        # position 6, view 32, normal ~32, emission and throughput 9, max 2, roulette draw ~30, 3 div x 11, compares
+OPS_SAMPLE = 180           # a new sample: path key ~40, two draws ~60, primary ray ~25, 1/d and the root box test 54
+MATERIAL_UNIT = ["lambertian", "reflect", "refract", "glass", "cook_torrance", "cook_torrance_refract",
+                 "cook_torrance_glass", "plastic", "no_reflect"]   # by RAYRS_MAT_*
+
+
+def traversal_ops(stats, info, early=False):
+    """Useful f64-rate lane operations of BVH queries: of the whole frame, or (early) of the part answered outside
+    the traversal kernel.  Primary rays that miss the root box cost their ray setup where they are made."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
-    return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
-            + stats["plane_tests"] * OPS_PLANE + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY)
+    k = "early_" if early else ""
+    visits = stats["early_visits"] if early else stats["interior_visits"]
+    return (visits * rec + stats[k + "tri_tests"] * tri + stats[k + "sphere_tests"] * OPS_SPHERE
+            + stats[k + "plane_tests"] * OPS_PLANE)
+
+
+def useful_f64_ops(stats, info):
+    """Of the traversal kernel: the frame's walk minus what other kernels answered, plus the setup of the rays it took."""
+    return (traversal_ops(stats, info) - traversal_ops(stats, info, early=True)
+            + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY)
+
+
+def surface_units(objs):
+    """Material unit of every (Material, Emission) row, in insertion order (what surface_hits is indexed by)."""
+    from rayrs_amd.api import flatten_objects
+    rows = []
+    for o in flatten_objects(objs):
+        key = (o.mat, o.emission)
+        if key not in rows:
+            rows.append(key)
+    return [MATERIAL_UNIT[m.kind] for m, _ in rows]
+
+
+def shading_ops(stats, units):
+    """(hit side, miss side, new samples) useful lane operations of a frame from its counters: closest hits per
+    surface row x that row's material unit; escaped paths x Scene::background; samples started."""
+    hits = stats["surface_hits"]
+    ops_hit = 0
+    for k, n in enumerate(hits):
+        unit = units[k] if k < len(units) else units[-1]
+        ops_hit += n * (OPS_MATERIAL[unit] + OPS_HIT_FIXED)
+    return ops_hit, stats["escaped_paths"] * OPS_BACKGROUND, stats["paths"] * OPS_SAMPLE
 
 
 def algorithmic_bytes(stats, info):
@@ -256,11 +304,11 @@ def main():
         fence()
         t_begin = time.perf_counter()
         rays = 0
-        kernel_ms = []
+        kernel_ms, hit_ms, miss_ms = [], [], []
         for _ in range(steps):
             st = step()
             rays += st["rays"]
-            kernel_ms.append(st["kernel_ms"])
+            kernel_ms.append(st["kernel_ms"]), hit_ms.append(st["hit_ms"]), miss_ms.append(st["miss_ms"])
         fence()
         elapsed = time.perf_counter() - t_begin
 
@@ -289,42 +337,77 @@ def main():
             cst = rayrs_amd.render_finish(scene)
             assert cst["rays"] == st["rays"], "counting launch traced a different frame"
             shares = ray_shares(cst, args.config, info["n_surfaces"])
-            launches = st["kernel_launches"]                          # traversal launches = path rounds
+            launches = st["kernel_launches"]                          # traversal launches = path rounds (local pool: segments)
             step_ms = max_elapsed / steps * 1e3
-            trav_ms = sum(kernel_ms) / len(kernel_ms)                 # per step, HIP events on the render stream
-            avg_ms = trav_ms / launches
-            ops = useful_f64_ops(cst, info)
-            achieved = ops / (trav_ms * 1e-3) / 1e12
+            n_st = len(kernel_ms)
+            units = surface_units(objs)
+            ops_hit, ops_miss, ops_gen = shading_ops(cst, units)
+            paths_end_in_miss = cst["escaped_paths"]
+            share_miss = paths_end_in_miss / max(cst["paths"], 1)
+            # every kernel of the frame: its HIP-event time per step (on the render stream) and the useful lane
+            # operations it is charged with; the roofline is the one with the largest share of the step
+            if st["local_pool"]:
+                kern = {"lp_path_kernel": {"ms": sum(kernel_ms) / n_st,
+                                           "ops": traversal_ops(cst, info) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
+            else:
+                kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info)},
+                        "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)
+                                          + 0.0},
+                        "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss}}
+                early = traversal_ops(cst, info, early=True)          # queries answered by the kernels that made the rays
+                kern["wf_hit_kernel"]["ops"] += early * (1.0 - share_miss)
+                kern["wf_miss_kernel"]["ops"] += early * share_miss
+            for k in kern.values():
+                k["share_of_step"] = round(k["ms"] / step_ms, 3)
+                k["achieved_Tops"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9, 3)
+                k["frac"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9 / F64_PEAK_TOPS, 4)
+                k["ms"] = round(k["ms"], 3)
+                k["ops"] = int(k["ops"])
+            dom = max(kern, key=lambda n: kern[n]["ms"])
+            dom_ms = kern[dom]["ms"]
+            avg_ms = dom_ms / launches
+            ops = kern[dom]["ops"]
+            achieved = ops / (dom_ms * 1e-3) / 1e12
             abytes = algorithmic_bytes(cst, info)
             prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
             pmc = find_pmc_profile(workload_key(W, H, chunk))
             traffic = fabric_gbs = valu_busy = valu_per_ray = pmc_src = None
             if pmc is not None:
                 pmc_src, pj = pmc
-                k = pj["kernels"].get("wf_trav_kernel")
+                k = pj["kernels"].get(dom)
                 if k and k["launches"] == launches:
                     traffic = int(k["fabric_bytes"] / launches)
-                    fabric_gbs = round(k["fabric_bytes"] / (trav_ms * 1e-3) / 1e9, 1)
+                    fabric_gbs = round(k["fabric_bytes"] / (dom_ms * 1e-3) / 1e9, 1)
                     valu_busy = k.get("valu_busy")
                     valu_per_ray = round(k["valu_wave_instructions"] / max(cst["rays"], 1), 2)
+            if st["local_pool"]:
+                util = {"all phases": round(cst["step_lane"] / max(cst["step_wave"], 1), 3)}
+                tk = max(cst["interior_ticks"] + cst["leaf_ticks"] + cst["refill_ticks"], 1)
+                util["wave time: intersect / shade / generate+background"] = [
+                    round(cst["interior_ticks"] / tk, 3), round(cst["leaf_ticks"] / tk, 3), round(cst["refill_ticks"] / tk, 3)]
+            else:
+                util = {"interior": round(cst["step_lane"] / max(cst["step_wave"], 1), 3),
+                        "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)}
             roofline = {
                 "bound": "fp64_valu", "achieved": round(achieved, 3), "peak": round(F64_PEAK_TOPS, 2),
                 "unit": "TFLOP/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
-                "kernel": "wf_trav_kernel", "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
-                "kernel_share_of_step": round(trav_ms / step_ms, 3),
-                "definition": "useful f64 lane-operations of the traversal kernel (its own record / primitive / ray "
-                              "counters x the per-unit operation counts of bench.py) / its HIP-event time / "
-                              "(256 CU x 4 SIMD x 16 lanes x 2.4 GHz); no FMA: the reference's arithmetic is unfused",
-                "useful_f64_ops_per_launch": int(ops / launches), "useful_f64_ops_per_ray": round(ops / max(cst["rays"], 1), 1),
+                "kernel": dom, "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
+                "kernel_share_of_step": round(dom_ms / step_ms, 3),
+                "definition": "the kernel with the largest share of the step: useful lane operations it is charged with "
+                              "(traversal: record / primitive / ray counters x the f64 operations per unit counted in "
+                              "device_path.h; shading: closest hits per material, escaped paths and samples x the vector "
+                              "instructions of that unit compiled alone, profiles/r03_op_model.json) / its HIP-event time / "
+                              "(256 CU x 4 SIMD x 16 lanes x 2.4 GHz); no FMA credit: the reference's arithmetic is unfused",
+                "kernels": kern,
+                "useful_ops_per_launch": int(ops / launches), "useful_ops_per_ray": round(ops / max(cst["rays"], 1), 1),
                 "records_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
                 "prim_tests_per_ray": round(prims / max(cst["rays"], 1), 2),
-                "lane_utilisation": {"interior": round(cst["step_lane"] / max(cst["step_wave"], 1), 3),
-                                     "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)},
-                # SURVEY.md 8(d)'s figure: record fetches of an incoherent walk over a 97 MB scene, served by
-                # LDS / L1 / L2 / Infinity Cache -- it can exceed the HBM peak and bounds nothing; kept for comparison
+                "lane_utilisation": util,
+                # SURVEY.md 8(d)'s figure: record fetches of an incoherent walk, served by LDS / L1 / L2 / Infinity
+                # Cache -- it can exceed the HBM peak and bounds nothing; kept for comparison
                 "algorithmic_bytes_per_launch": int(abytes / launches),
                 "algorithmic_bytes_per_ray": round(abytes / max(cst["rays"], 1), 1),
-                "algorithmic_GBps": round(abytes / (trav_ms * 1e-3) / 1e9, 1),
+                "algorithmic_GBps": round(abytes / (dom_ms * 1e-3) / 1e9, 1),
                 # from the PMC passes of scripts/profile_round.sh, only when taken on this very source tree and
                 # workload: bytes between L2 and the fabric (32 B x TCC_EA0_RDREQ_DRAM_32B + WRREQ_WRITE_DRAM_32B,
                 # Infinity-Cache hits included; calibrated exact on 64/128/192-byte records, profiles/) and the

@@ -224,7 +224,8 @@ typedef struct {
     /* shader-clock ticks the traversal kernel's waves spent in interior steps, in leaf steps
      * and in retiring/refilling (count_work only), summed over waves */
     uint64_t interior_ticks, leaf_ticks;
-    double kernel_ms;       /* summed HIP-event time of the traversal kernel's launches on its stream */
+    double kernel_ms;       /* summed HIP-event time of the traversal kernel's launches on its stream (the local-pool
+                               kernel's when local_pool is set) */
     double total_ms;        /* all kernels of the render: path rounds + resolve */
     uint64_t kernel_launches; /* launches of the traversal kernel (= path rounds) */
     double trace_ms;        /* all path rounds (gen + traversal + hit + miss kernels) */
@@ -241,6 +242,10 @@ typedef struct {
     /* of interior_visits / tri_tests / sphere_tests / plane_tests, the part done outside the traversal kernel, by
      * the kernels that make the rays (queries that need no walk: rayrs_tuning.early_resolve); count_work only */
     uint64_t early_visits, early_tri_tests, early_sphere_tests, early_plane_tests;
+    double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
+                               kernel's, or the local-pool kernel's, which is then the only one) */
+    uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
+    uint32_t pad;
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:

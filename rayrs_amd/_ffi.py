@@ -70,7 +70,8 @@ class RenderStats(C.Structure):
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64),
                 ("early_visits", C.c_uint64), ("early_tri_tests", C.c_uint64), ("early_sphere_tests", C.c_uint64),
-                ("early_plane_tests", C.c_uint64)]
+                ("early_plane_tests", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
+                ("local_pool", C.c_uint32), ("pad", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -465,7 +465,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 26);
+    RAYRS_STRUCT(rayrs_render_stats, 30);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -479,6 +479,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, early_visits), RAYRS_FIELD(rayrs_render_stats, early_tri_tests);
     RAYRS_FIELD(rayrs_render_stats, early_sphere_tests), RAYRS_FIELD(rayrs_render_stats, early_plane_tests);
+    RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
+    RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, pad);
     RAYRS_STRUCT(rayrs_tuning, 13);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
@@ -714,8 +716,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         scene->n_pipes = 1;
         pl.timed_rounds = 0;
         const uint64_t n_seg = (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS;
-        // two workgroups of four waves per CU; fewer when the frame has fewer items than resident paths
-        uint32_t blocks = (uint32_t)scene->cu_count * 2u;
+        // LP_WPS workgroups of four waves per CU; fewer when the frame has fewer items than resident paths
+        uint32_t blocks = (uint32_t)scene->cu_count * (uint32_t)LP_WPS;
         {
             const uint64_t seg_items = rp.total_items < LOCAL_SEGMENT_ITEMS ? rp.total_items : LOCAL_SEGMENT_ITEMS;
             const uint64_t want = (seg_items + 4u * LP_PATHS_PER_WAVE - 1) / (4u * LP_PATHS_PER_WAVE);
@@ -736,14 +738,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             lp.item_base = seg * LOCAL_SEGMENT_ITEMS;
             lp.item_count = rp.total_items - lp.item_base < LOCAL_SEGMENT_ITEMS ? rp.total_items - lp.item_base
                                                                                  : LOCAL_SEGMENT_ITEMS;
-            while (pl.ev_trav.size() < 2 * (size_t)(seg + 1)) {
+            while (pl.ev_trav.size() < 4 * (size_t)(seg + 1)) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
                 pl.ev_trav.push_back(e);
             }
-            HIP_TRY(hipEventRecord(pl.ev_trav[2 * seg], stream));
+            HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg], stream));
             HIP_TRY(lp_launch(compact, count, sc, scene->local, cam, rp, lp, blocks, stream));
-            HIP_TRY(hipEventRecord(pl.ev_trav[2 * seg + 1], stream));
+            HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg + 1], stream));
             pl.timed_rounds = (uint32_t)seg + 1;
         }
         scene->rounds = (uint32_t)n_seg;
@@ -771,22 +773,25 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                     hipStream_t st = streams[p];
                     if (p == 1 && it == 0) HIP_TRY(hipStreamWaitEvent(st, scene->ev_stagger, 0));  // half a round behind
                     const bool timed = it < MAX_TIMED;
+                    // four events per round: before the traversal kernel, after it, after the hit kernel, after the miss kernel
                     if (timed) {
-                        while (pl.ev_trav.size() < 2 * (size_t)(it + 1)) {
+                        while (pl.ev_trav.size() < 4 * (size_t)(it + 1)) {
                             hipEvent_t e;
                             HIP_TRY(hipEventCreate(&e));
                             pl.ev_trav.push_back(e);
                         }
-                        HIP_TRY(hipEventRecord(pl.ev_trav[2 * it], st));
+                        HIP_TRY(hipEventRecord(pl.ev_trav[4 * it], st));
                     }
                     HIP_TRY(wf_launch_trav(compact, count, sc, rps[p], wfs[p], trav_blocks, st));
-                    if (timed) {
-                        HIP_TRY(hipEventRecord(pl.ev_trav[2 * it + 1], st));
-                        pl.timed_rounds = it + 1;
-                    }
+                    if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 1], st));
                     if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
                     HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 2], st));
                     HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    if (timed) {
+                        HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 3], st));
+                        pl.timed_rounds = it + 1;
+                    }
                 }
             }
             for (uint32_t p = 0; p < n_pipes; p++) {
@@ -857,19 +862,29 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->trace_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[2]));
         stats->total_ms = ms;
-        double trav = 0.0;
+        double trav = 0.0, hit = 0.0, miss = 0.0;
         for (uint32_t p = 0; p < scene->n_pipes; p++) {
             const rayrs_scene::Pipeline& pl = scene->pipe[p];
-            double t = 0.0;
+            double t = 0.0, h = 0.0, m = 0.0;
             for (uint32_t r = 0; r < pl.timed_rounds; r++) {
-                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[2 * r], pl.ev_trav[2 * r + 1]));
+                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r], pl.ev_trav[4 * r + 1]));
                 t += ms;
+                if (scene->last_local) continue;  // one kernel per segment
+                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r + 1], pl.ev_trav[4 * r + 2]));
+                h += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r + 2], pl.ev_trav[4 * r + 3]));
+                m += ms;
             }
             // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
-            if (pl.timed_rounds && scene->rounds > pl.timed_rounds) t *= (double)scene->rounds / (double)pl.timed_rounds;
-            trav += t;
+            if (pl.timed_rounds && scene->rounds > pl.timed_rounds) {
+                const double f = (double)scene->rounds / (double)pl.timed_rounds;
+                t *= f, h *= f, m *= f;
+            }
+            trav += t, hit += h, miss += m;
         }
         stats->kernel_ms = trav;
+        stats->hit_ms = hit, stats->miss_ms = miss;
+        stats->local_pool = scene->last_local ? 1u : 0u;
         stats->kernel_launches = (uint64_t)scene->rounds * scene->n_pipes;
     }
     return RAYRS_OK;

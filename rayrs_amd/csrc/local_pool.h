@@ -9,7 +9,13 @@ namespace rayrs {
 
 constexpr uint32_t LP_MAX_GATES = 4;   // leaf slots of the one wide record
 constexpr uint32_t LP_MAX_PRIMS = 16;  // 4 gates x 4 primitives
-constexpr uint32_t LP_PATHS_PER_WAVE = 128;
+#ifndef LP_P
+#define LP_P 112   // paths per wave (64 < LP_P <= 128); with LP_WPS, an experiment's knob (-DLP_P=.. -DLP_WPS=..)
+#endif
+#ifndef LP_WPS
+#define LP_WPS 3   // workgroups per CU the kernel is built for (= waves per SIMD)
+#endif
+constexpr uint32_t LP_PATHS_PER_WAVE = LP_P;
 
 // The scene's gating boxes as kernel arguments: what is left of the BVH when the walk tree has at most one
 // record.  Gate g is one leaf group of the reference's tree (primitives first .. first + count - 1 in
@@ -31,7 +37,7 @@ struct LocalDev {
     uint64_t item_count;            // items in the segment
 };
 
-uint32_t lp_lds_bytes();
+uint32_t lp_lds_bytes(uint32_t n_prims, uint32_t n_surfaces);
 hipError_t lp_configure();  // raises the kernels' dynamic LDS limit; once per device
 hipError_t lp_launch(bool compact, bool count, const SceneDev& sc, const LocalScene& ls, const CameraDev& cam,
                      const RenderDev& rp, const LocalDev& lp, uint32_t blocks, hipStream_t stream);

@@ -7,9 +7,10 @@
 // scenes: a floor and one to seven spheres, test_scenes.rs:14-256 -- a BVH query is a loop over at most
 // four gating boxes and sixteen primitives, all wave-uniform data.  So here one launch renders the frame:
 //
-//   * each wave owns a pool of LP_PATHS_PER_WAVE paths in LDS (structure of arrays: 13 doubles and
-//     8 words per path, one state byte) -- the reference keeps a path in locals for its whole life
-//     (lib.rs:521-560); this is the same thing for 128 paths per wave;
+//   * each wave owns a pool of LP_PATHS_PER_WAVE paths in LDS (structure of arrays: 12 doubles and
+//     4 words per path, one state byte: 112 bytes, which is what lets three workgroups of four such
+//     waves share a CU's 160 KiB) -- the reference keeps a path in locals for its whole life
+//     (lib.rs:521-560); this is the same thing for 112 paths per wave;
 //   * a wave repeatedly picks the phase most of its paths wait for, compacts up to 64 of them into its
 //     lanes (__ballot + popcount rank, the list in LDS), loads their state, runs the phase on all lanes
 //     and stores the state back:
@@ -34,16 +35,26 @@ namespace rayrs {
 namespace {
 
 constexpr uint32_t P = LP_PATHS_PER_WAVE;
-static_assert(P == 128, "two state bytes per lane");
+static_assert(P > 64 && P <= 128 && P % 16 == 0, "two state bytes per lane");
 
 // a path's fields in LDS: field f of path p at [f * P + p]
-enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TX, F_TY, F_TZ, F_AX, F_AY, F_AZ, F_T, LP_NF64 };
-enum { U_PRIM, U_BD, U_ITEM, U_SCUR, U_SEND, U_PIX, U_KLO, U_KHI, LP_NU32 };
+// F_O: the ray's origin while the path waits for ISECT; the hit POSITION o + d * t once ISECT has found one
+// (lib.rs:528: nothing else of o and t is used after the query).  What can be recomputed is not kept: the
+// item's pixel and last sample follow from the item number, the sample's RNG key from pixel and sample.
+enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_TX, F_TY, F_TZ, F_AX, F_AY, F_AZ, LP_NF64 };
+enum { U_PRIM, U_BD, U_ITEM, U_SCUR, LP_NU32 };
 constexpr uint32_t LP_WAVE_BYTES = P * (LP_NF64 * 8u + LP_NU32 * 4u) + P + 64u;  // fields, state bytes, list
 static_assert(LP_WAVE_BYTES % 16u == 0, "pools stay 16-byte aligned");
 constexpr uint32_t LP_PRIM_GRANULES = 5;  // 16-byte granules per primitive record in LDS (either layout)
-constexpr uint32_t LP_BLOCK_BYTES =
-    4u * LP_WAVE_BYTES + LP_MAX_PRIMS * (uint32_t)sizeof(SurfaceDev) + LP_MAX_PRIMS * LP_PRIM_GRANULES * 16u;
+// after the four pools: the LocalScene, n_prims + 4 primitive records (ISECT requests one record ahead, and never
+// uses what lies beyond a group's end), n_surfaces surface rows -- sized per scene at launch
+RR_DEV uint32_t lp_scene_bytes_dev(uint32_t n_prims) {
+    return (uint32_t)sizeof(LocalScene) + (n_prims + 4u) * LP_PRIM_GRANULES * 16u;
+}
+static inline uint32_t lp_block_bytes(uint32_t n_prims, uint32_t n_surfaces) {
+    return 4u * LP_WAVE_BYTES + (uint32_t)sizeof(LocalScene) + (n_prims + 4u) * LP_PRIM_GRANULES * 16u +
+           n_surfaces * (uint32_t)sizeof(SurfaceDev);
+}
 
 // path states = the phase a path waits for
 constexpr uint32_t LP_GEN = 0, LP_ISECT = 1, LP_BG = 2, LP_SHADE0 = 3;  // LP_SHADE0 + RAYRS_MAT_* (0..8)
@@ -90,15 +101,24 @@ RR_DEV double* lp_light(const LocalDev& lp, uint32_t p) {
     return lp.light + ((size_t)wave_global * P + p) * 4u;
 }
 
+// n / d and n % d for a launch-constant d with 1/d at hand (wavefront.hip udiv_by): the quotient of the f64
+// product is within one of the true one (n < 2^32), and the remainder says which
+RR_DEV uint32_t lp_udiv_by(uint32_t n, uint32_t d, double inv_d, uint32_t& rem) {
+    uint32_t q = (uint32_t)((double)n * inv_d);
+    int32_t r = (int32_t)(n - q * d);
+    if (r < 0) q--, r += (int32_t)d;
+    else if ((uint32_t)r >= d) q++, r -= (int32_t)d;
+    rem = (uint32_t)r;
+    return q;
+}
+
+// the item numbering of wavefront.hip item_geometry: 64 pixels of a tile x the tile's chunks
 RR_DEV void lp_item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
                              uint32_t& s_end) {
-    // the item numbering of wavefront.hip item_geometry: 64 pixels of a tile x the tile's chunks
     const uint32_t pit = item & 63u;
-    const uint32_t tc = item >> 6;
-    const uint32_t lt = tc / rp.nchunks, chunk = tc - lt * rp.nchunks;
-    const uint32_t tile = lt * rp.tile_ranks + rp.tile_rank;
-    const uint32_t ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
-    row = ty * 8u + (pit >> 3);
+    uint32_t chunk, tx;
+    const uint32_t tile = lp_udiv_by(item >> 6, rp.nchunks, rp.inv_nchunks, chunk) * rp.tile_ranks + rp.tile_rank;
+    row = lp_udiv_by(tile, rp.tiles_x, rp.inv_tiles_x, tx) * 8u + (pit >> 3);
     col = tx * 8u + (pit & 7u);
     s_begin = chunk * rp.chunk;
     s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
@@ -114,9 +134,9 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     const uint32_t w = pl.u(U_SCUR, p);
     bool has_item = valid && (w >> 31) != 0u;
-    uint32_t s_cur = w & SLOT_SAMPLE_MASK, s_end = pl.u(U_SEND, p), item = pl.u(U_ITEM, p);
-    const uint32_t pix = pl.u(U_PIX, p);
-    uint32_t row = pix >> 16, col = pix & 0xffffu;
+    uint32_t s_cur = w & SLOT_SAMPLE_MASK, item = pl.u(U_ITEM, p);
+    uint32_t row, col, s_end, s_first;
+    lp_item_geometry(rp, item, row, col, s_first, s_end);  // (of no meaning without an item)
     if (has_item && s_cur >= s_end) {  // the item's sum goes to the resolve kernel
         double* dst = rp.partial + (size_t)item * 3;
         dst[0] = pl.f(F_AX, p), dst[1] = pl.f(F_AY, p), dst[2] = pl.f(F_AZ, p);
@@ -179,9 +199,8 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
         pl.set_v3(F_TX, p, mk(1.0, 1.0, 1.0));  // throughput 1, light 0 (lib.rs:522-523)
         pl.u(U_BD, p) = 1u | (enters ? 0u : LP_DIRECT_BIT) | (rng.draw << 16);
         pl.u(U_SCUR, p) = s_cur | SLOT_ITEM_BIT;
-        pl.u(U_KLO, p) = (uint32_t)rng.key, pl.u(U_KHI, p) = (uint32_t)(rng.key >> 32);
         if (fresh) {
-            pl.u(U_ITEM, p) = item, pl.u(U_SEND, p) = s_end, pl.u(U_PIX, p) = row << 16 | col;
+            pl.u(U_ITEM, p) = item;
             pl.set_v3(F_AX, p, mk(0.0, 0.0, 0.0));
         }
         ns = enters ? LP_ISECT : LP_BG;
@@ -196,7 +215,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
 // arrive through the scalar cache.
 template <bool COMPACT, bool COUNT>
 RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, const SceneDev& sc, const LocalScene& ls,
-                         const SurfaceDev* s_surf, LpCount& n) {
+                         const SurfaceDev* s_surf, const uint4* s_prims, LpCount& n) {
     const V3 o = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
     const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const bool in = valid && root_box_hit(sc, o, inv);
@@ -211,10 +230,14 @@ RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, const SceneDev&
         const bool pass = in && slab(nx ? b[1] : b[0], nx ? b[0] : b[1], ny ? b[3] : b[2], ny ? b[2] : b[3],
                                      nz ? b[5] : b[4], nz ? b[4] : b[5], o, inv, sc.t0, sc.t1, entry);
         if (__ballot(pass) == 0ull) continue;
+        // the records wait in LDS (every lane reads the same address: a broadcast); the next one is requested
+        // before this one is worked on -- at two waves per SIMD nothing else would hide the wait
         const uint32_t first = ls.first[g], count = ls.count[g];
+        PrimRec<COMPACT> ahead = load_prim_lds<COMPACT>(s_prims, first);
         for (uint32_t k = 0; k < count; k++) {
             const uint32_t pr = first + k;
-            const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, pr);
+            const PrimRec<COMPACT> r = ahead;
+            ahead = load_prim_lds<COMPACT>(s_prims, pr + 1u);
             if (pass) {
                 if (COUNT) {
                     const uint32_t kind = r.tag() & 3u;
@@ -232,11 +255,11 @@ RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, const SceneDev&
         }
     }
     uint32_t ns = LP_BG;
-    if (valid) {
-        pl.f(F_T, p) = best_t;
+    if (best_prim != 0xffffffffu) {  // (never for a lane without a path: `in` is false there)
+        pl.set_v3(F_OX, p, v_add(o, v_scale(d, best_t)));  // position, lib.rs:528
         pl.u(U_PRIM, p) = best_prim;
+        ns = LP_SHADE0 + (uint32_t)s_surf[best_tag >> 8].kind;
     }
-    if (best_prim != 0xffffffffu) ns = LP_SHADE0 + (uint32_t)s_surf[best_tag >> 8].kind;
     return ns;
 }
 
@@ -261,22 +284,23 @@ RR_DEV uint32_t lp_background(const Pool& pl, bool valid, uint32_t p, const Scen
 
 // ---- SHADE_k: lib.rs:528-551 for a closest hit on a surface of material kind k (wave-uniform).
 template <bool COMPACT>
-RR_DEV uint32_t lp_shade(const Pool& pl, bool valid, uint32_t p, int kind, const RenderDev& rp, const LocalDev& lp,
-                         const SurfaceDev* s_surf, const uint4* s_prims, uint32_t& hit_sid) {
-    const V3 o = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
+RR_DEV uint32_t lp_shade(const Pool& pl, bool valid, uint32_t p, int kind, const CameraDev& cam, const RenderDev& rp,
+                         const LocalDev& lp, const SurfaceDev* s_surf, const uint4* s_prims, uint32_t& hit_sid) {
+    const V3 position = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
     V3 thr = pl.v3(F_TX, p);
-    const double t = pl.f(F_T, p);
     const uint32_t prim = valid ? pl.u(U_PRIM, p) : 0u;
     const uint32_t bd = pl.u(U_BD, p), w = pl.u(U_SCUR, p);
     const uint32_t bounce = bd & LP_BOUNCE_MASK;
-    Rng rng{((uint64_t)pl.u(U_KHI, p) << 32) | pl.u(U_KLO, p), bd >> 16};
+    // the RNG key of the sample in flight: the item's pixel and the sample before the cursor
+    uint32_t row, col, s_first, s_end;
+    lp_item_geometry(rp, pl.u(U_ITEM, p), row, col, s_first, s_end);
+    Rng rng{rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)((w & SLOT_SAMPLE_MASK) - 1u)), bd >> 16};
     V3 light = mk(0.0, 0.0, 0.0);
     if (valid && ((w >> 30) & 1u)) {
         const double* l = lp_light(lp, p);
         light = mk(l[0], l[1], l[2]);
     }
     const PrimRec<COMPACT> rec = load_prim_lds<COMPACT>(s_prims, prim);
-    const V3 position = v_add(o, v_scale(d, t));
     const V3 normal = prim_normal<COMPACT>(rec, position);
     const V3 view = v_unit(v_scale(d, -1.0));
     const uint32_t sid = rec.tag() >> 8;
@@ -329,7 +353,7 @@ RR_DEV void lp_wave_add(unsigned long long* dst, unsigned long long v) {
 }  // namespace
 
 template <bool COMPACT, bool COUNT>
-__global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene ls, CameraDev cam, RenderDev rp,
+__global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, LocalScene ls, CameraDev cam, RenderDev rp,
                                                          LocalDev lp) {
     extern __shared__ __align__(16) unsigned char lp_lds[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -341,9 +365,12 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
     pl.u32 = reinterpret_cast<uint32_t*>(base + P * LP_NF64 * 8u);
     pl.state = reinterpret_cast<uint8_t*>(pl.u32 + P * LP_NU32);
     pl.list = pl.state + P;
-    SurfaceDev* s_surf = reinterpret_cast<SurfaceDev*>(lp_lds + 4u * LP_WAVE_BYTES);
-    uint4* s_prims = reinterpret_cast<uint4*>(lp_lds + 4u * LP_WAVE_BYTES + LP_MAX_PRIMS * sizeof(SurfaceDev));
+    LocalScene* s_ls = reinterpret_cast<LocalScene*>(lp_lds + 4u * LP_WAVE_BYTES);
+    uint4* s_prims = reinterpret_cast<uint4*>(lp_lds + 4u * LP_WAVE_BYTES + sizeof(LocalScene));
+    SurfaceDev* s_surf = reinterpret_cast<SurfaceDev*>(lp_lds + 4u * LP_WAVE_BYTES + lp_scene_bytes_dev(ls.n_prims));
     {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(LocalScene) / 4); i += 256u)
+            reinterpret_cast<uint32_t*>(s_ls)[i] = reinterpret_cast<const uint32_t*>(&ls)[i];
         const uint32_t n_surf = sc.n_surfaces < LP_MAX_PRIMS ? sc.n_surfaces : LP_MAX_PRIMS;
         for (uint32_t i = threadIdx.x; i < n_surf * (uint32_t)(sizeof(SurfaceDev) / 4); i += 256u)
             reinterpret_cast<uint32_t*>(s_surf)[i] = reinterpret_cast<const uint32_t*>(sc.surfaces)[i];
@@ -376,7 +403,7 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
             if (cnt[s] > most) most = cnt[s], ph = s;
         if (most == 0u) break;
         // up to 64 of its paths, lowest first, into the lanes
-        const uint32_t st0 = pl.state[lane], st1 = pl.state[lane + 64u];
+        const uint32_t st0 = pl.state[lane], st1 = lane + 64u < P ? pl.state[lane + 64u] : LP_DEAD;
         const bool m0 = st0 == ph, m1 = st1 == ph;
         const unsigned long long mask0 = __ballot(m0), mask1 = __ballot(m1);
         const uint32_t n0 = (uint32_t)__popcll(mask0);
@@ -392,12 +419,12 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
         if (ph == LP_GEN) {
             ns = lp_gen(pl, valid, p, sc, cam, rp, lp, range, n);
         } else if (ph == LP_ISECT) {
-            ns = lp_isect<COMPACT, COUNT>(pl, valid, p, sc, ls, s_surf, n);
+            ns = lp_isect<COMPACT, COUNT>(pl, valid, p, sc, *s_ls, s_surf, s_prims, n);
         } else if (ph == LP_BG) {
             ns = lp_background(pl, valid, p, sc, lp, n);
         } else {
             uint32_t hit_sid = 8u;
-            ns = lp_shade<COMPACT>(pl, valid, p, (int)(ph - LP_SHADE0), rp, lp, s_surf, s_prims, hit_sid);
+            ns = lp_shade<COMPACT>(pl, valid, p, (int)(ph - LP_SHADE0), cam, rp, lp, s_surf, s_prims, hit_sid);
             if (COUNT) {  // what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
                 for (uint32_t k = 0; k < 8u; k++) {
@@ -440,32 +467,35 @@ __global__ void __launch_bounds__(256, 2) lp_path_kernel(SceneDev sc, LocalScene
     }
 }
 
-uint32_t lp_lds_bytes() { return LP_BLOCK_BYTES; }
+uint32_t lp_lds_bytes(uint32_t n_prims, uint32_t n_surfaces) { return lp_block_bytes(n_prims, n_surfaces); }
 
 hipError_t lp_configure() {
+    const int most = (int)lp_block_bytes(LP_MAX_PRIMS, LP_MAX_PRIMS);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_path_kernel<true, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LP_BLOCK_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, most);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_path_kernel<true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LP_BLOCK_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, most);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_path_kernel<false, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LP_BLOCK_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, most);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_path_kernel<false, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LP_BLOCK_BYTES);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, most);
 }
 
 hipError_t lp_launch(bool compact, bool count, const SceneDev& sc, const LocalScene& ls, const CameraDev& cam,
                      const RenderDev& rp, const LocalDev& lp, uint32_t blocks, hipStream_t stream) {
+    const uint32_t n_surf = sc.n_surfaces < LP_MAX_PRIMS ? sc.n_surfaces : LP_MAX_PRIMS;
+    const uint32_t lds = lp_block_bytes(ls.n_prims < LP_MAX_PRIMS ? ls.n_prims : LP_MAX_PRIMS, n_surf);
     if (compact && count)
-        hipLaunchKernelGGL((lp_path_kernel<true, true>), dim3(blocks), dim3(256), LP_BLOCK_BYTES, stream, sc, ls, cam, rp, lp);
+        hipLaunchKernelGGL((lp_path_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, sc, ls, cam, rp, lp);
     else if (compact)
-        hipLaunchKernelGGL((lp_path_kernel<true, false>), dim3(blocks), dim3(256), LP_BLOCK_BYTES, stream, sc, ls, cam, rp, lp);
+        hipLaunchKernelGGL((lp_path_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, sc, ls, cam, rp, lp);
     else if (count)
-        hipLaunchKernelGGL((lp_path_kernel<false, true>), dim3(blocks), dim3(256), LP_BLOCK_BYTES, stream, sc, ls, cam, rp, lp);
+        hipLaunchKernelGGL((lp_path_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, sc, ls, cam, rp, lp);
     else
-        hipLaunchKernelGGL((lp_path_kernel<false, false>), dim3(blocks), dim3(256), LP_BLOCK_BYTES, stream, sc, ls, cam, rp, lp);
+        hipLaunchKernelGGL((lp_path_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, sc, ls, cam, rp, lp);
     return hipGetLastError();
 }
 

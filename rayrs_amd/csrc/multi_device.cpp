@@ -238,6 +238,8 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
                 if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
                 if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;
+                if (s.hit_ms > stats->hit_ms) stats->hit_ms = s.hit_ms;
+                if (s.miss_ms > stats->miss_ms) stats->miss_ms = s.miss_ms;
                 if (s.kernel_launches > stats->kernel_launches) stats->kernel_launches = s.kernel_launches;
             }
         }

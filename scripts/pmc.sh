@@ -34,7 +34,7 @@ for f in glob.glob(out + "/p1/*/*kernel_trace.csv"):
         k = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('rayrs::', '')[:28]
         dur[k] += int(row['End_Timestamp']) - int(row['Start_Timestamp'])
 for k in sorted(agg, key=lambda k: -dur[k]):
-    if not k.startswith('wf_'): continue
+    if not k.startswith(('wf_', 'lp_')): continue
     print(f"== {k}: {len(disp[k])} dispatches, {dur[k]/1e6:.1f} ms (pass 1) :: " + " ".join(f"{c}={agg[k][c]:.5g}" for c in sorted(agg[k])))
 PY
 find $OUT -name "*.csv" -size +20M -delete

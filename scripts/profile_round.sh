@@ -41,7 +41,7 @@ for which in ("pmc_mem", "pmc_sq"):
             disp[k].add((which, row["Dispatch_Id"]))
 res = {}
 for k, c in agg.items():
-    if not k.startswith(("wf_", "resolve")): continue
+    if not k.startswith(("wf_", "lp_", "resolve")): continue
     n = len({d for w, d in disp[k] if w == "pmc_sq"})
     simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 1024
     rd, wr = c["TCC_EA0_RDREQ_DRAM_32B_sum"] * 32, c["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] * 32
