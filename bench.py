@@ -74,21 +74,18 @@ MATERIAL_UNIT = ["lambertian", "reflect", "refract", "glass", "cook_torrance", "
                  "cook_torrance_glass", "plastic", "no_reflect"]   # by RAYRS_MAT_*
 
 
-def traversal_ops(stats, info, early=False):
-    """Useful f64-rate lane operations of BVH queries: of the whole frame, or (early) of the part answered outside
-    the traversal kernel.  Primary rays that miss the root box cost their ray setup where they are made."""
+def traversal_ops(stats, info):
+    """Useful f64-rate lane operations of the frame's BVH walks (records entered, primitives tested)."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
-    k = "early_" if early else ""
-    visits = stats["early_visits"] if early else stats["interior_visits"]
-    return (visits * rec + stats[k + "tri_tests"] * tri + stats[k + "sphere_tests"] * OPS_SPHERE
-            + stats[k + "plane_tests"] * OPS_PLANE)
+    return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
+            + stats["plane_tests"] * OPS_PLANE)
 
 
 def useful_f64_ops(stats, info):
-    """Of the traversal kernel: the frame's walk minus what other kernels answered, plus the setup of the rays it took."""
-    return (traversal_ops(stats, info) - traversal_ops(stats, info, early=True)
-            + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY)
+    """Of the traversal kernel: the walks plus the setup of the rays it took.  Primary rays that miss the root box
+    never reach it (direct_rays: the kernel that makes them finishes their sample)."""
+    return traversal_ops(stats, info) + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY
 
 
 def surface_units(objs):
@@ -351,12 +348,8 @@ def main():
                                            "ops": traversal_ops(cst, info) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
             else:
                 kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info)},
-                        "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)
-                                          + 0.0},
+                        "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)},
                         "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss}}
-                early = traversal_ops(cst, info, early=True)          # queries answered by the kernels that made the rays
-                kern["wf_hit_kernel"]["ops"] += early * (1.0 - share_miss)
-                kern["wf_miss_kernel"]["ops"] += early * share_miss
             for k in kern.values():
                 k["share_of_step"] = round(k["ms"] / step_ms, 3)
                 k["achieved_Tops"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9, 3)

@@ -32,7 +32,9 @@ typedef enum {
     RAYRS_HIP_ERROR = -2,   /* a HIP runtime call failed (see rayrs_last_error) */
     RAYRS_OOM = -3,
     RAYRS_NO_DEVICE = -4,   /* scene was created host-only or no GPU present */
-    RAYRS_UNSUPPORTED = -5, /* more than 2^32 (pixel, sample chunk) items on a rank, max_bounces > 8000, an image side > 65535 */
+    RAYRS_UNSUPPORTED = -5, /* more than 2^32 (pixel, sample chunk) items on a rank; max_bounces > 8000 (8000 itself is
+                               accepted: bounce count and draw index travel as 16 bits, a bounce draws at most four
+                               numbers); an image side > 65535; a walk tree that needs more than 4096 stack entries */
     RAYRS_IO_ERROR = -6,    /* file missing or malformed (see rayrs_io_last_error) */
     RAYRS_RCCL_ERROR = -7   /* the RCCL library could not be loaded, or one of its calls failed (rayrs_render_multi) */
 } rayrs_status;
@@ -234,14 +236,10 @@ typedef struct {
      * the k-th distinct (Material, Emission) pair in object insertion order, pairs 7 and up together;
      * rays - sum(surface_hits) = queries that found nothing (Scene::background) */
     uint64_t surface_hits[8];
-    /* queries answered by the kernel that made the ray, without a trip through the traversal kernel: rays that miss
-     * the root Node's box (bvh.rs:394: a Miss before anything else is looked at) and rays that enter no interior
-     * slot of the walk tree's root record (their walk is that record and the leaf groups entered: device_path.h
-     * resolve_root).  They are part of `rays`. */
+    /* primary rays that missed the root Node's box (bvh.rs:394: a Miss before anything else is looked at): their
+     * samples are finished by the kernel that made the ray, without a trip through the traversal and miss
+     * kernels.  They are part of `rays` and of `escaped_paths`. */
     uint64_t direct_rays;
-    /* of interior_visits / tri_tests / sphere_tests / plane_tests, the part done outside the traversal kernel, by
-     * the kernels that make the rays (queries that need no walk: rayrs_tuning.early_resolve); count_work only */
-    uint64_t early_visits, early_tri_tests, early_sphere_tests, early_plane_tests;
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
     uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
@@ -305,14 +303,13 @@ typedef struct {
                                scenes) is rendered by ONE launch that keeps every path in LDS from its first ray
                                to its last (local_pool.hip) instead of three launches per bounce over a pool in
                                HBM; same arithmetic, same bits.  0 = do so, 1 = never (the streaming kernels) */
-    /* The next three are experiments of round 3, measured slower or no faster on the headline frame (DESIGN.md
+    /* The next three are experiments of round 3, measured slower on the headline frame (DESIGN.md
      * section 4) and kept selectable because they are tested bit-identical: */
     uint32_t leaf_group;    /* traversal: 0 = a leaf phase tests the lane's whole group of 1..4 primitives, 1 = ONE
                                primitive per lane and phase (a lane with a one-primitive group is back in interior work
                                after one test; +12 % traversal time: a group's records are requested together) */
-    uint32_t early_resolve; /* a query that enters no interior slot of the walk tree's root record answered by the kernel
-                               that makes its ray (full waves) instead of the traversal kernel: bit 0 = primary rays,
-                               bit 1 = bounced rays; 0 = never (traversal -35 %, shading +40 %: a wash) */
+    uint32_t hit_blocks_per_cu; /* hit kernel: 0 or 2 = built for two workgroups per CU (256 registers, the next batch
+                               requested while this one is computed), 3 = for three, without the look-ahead */
     uint32_t trav_queries;  /* traversal: BVH queries a lane holds at a time, 1 or 2 (a lane with two takes part in a
                                wave's interior or leaf step with whichever of them stands in that phase; three
                                workgroups per CU instead of five: +26 % traversal time); 3 = two, built for four */

@@ -68,9 +68,7 @@ class RenderStats(C.Structure):
                 ("leaf_wave", C.c_uint64), ("interior_ticks", C.c_uint64), ("leaf_ticks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
-                ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64),
-                ("early_visits", C.c_uint64), ("early_tri_tests", C.c_uint64), ("early_sphere_tests", C.c_uint64),
-                ("early_plane_tests", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
+                ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
                 ("local_pool", C.c_uint32), ("pad", C.c_uint32)]
 
     def as_dict(self):
@@ -84,7 +82,7 @@ class Tuning(C.Structure):
                 ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
                 ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32),
                 ("local_pool", C.c_uint32), ("leaf_group", C.c_uint32),
-                ("early_resolve", C.c_uint32), ("trav_queries", C.c_uint32)]
+                ("hit_blocks_per_cu", C.c_uint32), ("trav_queries", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in

@@ -331,6 +331,13 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     std::unique_ptr<rayrs_scene> s(new rayrs_scene());
     int st = build_flat_scene(objs->list, z_near, z_far, heuristic, splits, hdri_w, hdri_h, hdri_rgb, &s->flat);
     if (st != RAYRS_OK) return st;
+    // Every traversal lane gets a stack of wide_depth entries (12 in LDS, the rest in HBM: 1.3 MB per entry on a
+    // 256-CU device).  The reference recurses as deep as its tree; a tree that needs more than 4096 pending
+    // entries (a chain of thousands of nested objects) is refused instead of allocating gigabytes for it.
+    if (s->flat.wide_depth > 4096u) {
+        g_last_error = "walk tree needs " + std::to_string(s->flat.wide_depth) + " stack entries (limit 4096)";
+        return RAYRS_UNSUPPORTED;
+    }
     s->surfaces = objs->list.surfaces;
     s->n_objects = objs->list.objs.size();
     s->device = device;
@@ -413,8 +420,9 @@ int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device 
 
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     if (!scene || !tuning) return RAYRS_INVALID_ARG;
+    if (tuning->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
     if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u ||
-        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || tuning->early_resolve > 3u)
+        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || (tuning->hit_blocks_per_cu != 0u && tuning->hit_blocks_per_cu != 2u && tuning->hit_blocks_per_cu != 3u))
         return RAYRS_INVALID_ARG;
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
@@ -465,7 +473,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 30);
+    RAYRS_STRUCT(rayrs_render_stats, 26);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -477,8 +485,6 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, total_ms), RAYRS_FIELD(rayrs_render_stats, kernel_launches);
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
-    RAYRS_FIELD(rayrs_render_stats, early_visits), RAYRS_FIELD(rayrs_render_stats, early_tri_tests);
-    RAYRS_FIELD(rayrs_render_stats, early_sphere_tests), RAYRS_FIELD(rayrs_render_stats, early_plane_tests);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, pad);
     RAYRS_STRUCT(rayrs_tuning, 13);
@@ -486,7 +492,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
     RAYRS_FIELD(rayrs_tuning, eager_light), RAYRS_FIELD(rayrs_tuning, local_pool);
-    RAYRS_FIELD(rayrs_tuning, leaf_group), RAYRS_FIELD(rayrs_tuning, early_resolve);
+    RAYRS_FIELD(rayrs_tuning, leaf_group), RAYRS_FIELD(rayrs_tuning, hit_blocks_per_cu);
     RAYRS_FIELD(rayrs_tuning, trav_queries);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
@@ -547,7 +553,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     if (params->spp == 0 || camera->x_pixels == 0 || camera->y_pixels == 0) return RAYRS_INVALID_ARG;
     if (camera->x_pixels > 65535u || camera->y_pixels > 65535u) return RAYRS_UNSUPPORTED;  // TailSlot::pix is 16 + 16 bits
-    if (params->max_bounces > 8000u) return RAYRS_UNSUPPORTED;  // bounce and draw counters are 16-bit in the pool
+    // a path's bounce count and RNG draw index travel as 16 bits each (15 + 16 in the local pool); a bounce draws at
+    // most four numbers (material.rs:579 + :1009-1011 + lib.rs:539), so 8000 bounces stay below 2^15 and 2^16
+    if (params->max_bounces > 8000u) return RAYRS_UNSUPPORTED;
     if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;     // a slot's sample cursor has 30 bits
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
@@ -579,7 +587,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
     rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 32u;
     rp.leaf_single = scene->tuning.leaf_group == 1u ? 1u : 0u;
-    rp.early_resolve = scene->tuning.early_resolve;  // bit 0: primary rays (next_sample), bit 1: bounced rays (hit kernel)
+    rp.hit_wps3 = scene->tuning.hit_blocks_per_cu == 3u ? 1u : 0u;  // bit 0: primary rays (next_sample), bit 1: bounced rays (hit kernel)
     rp.trav_two = scene->tuning.trav_queries >= 2u ? scene->tuning.trav_queries - 1u : 0u;
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
@@ -855,8 +863,6 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         stats->direct_rays = c.direct_rays;
-        stats->early_visits = c.early_visits, stats->early_tri_tests = c.early_tri_tests;
-        stats->early_sphere_tests = c.early_sphere_tests, stats->early_plane_tests = c.early_plane_tests;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;

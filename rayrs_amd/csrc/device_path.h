@@ -529,79 +529,6 @@ RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack
     return tv.best_prim != 0xffffffffu;
 }
 
-// A query answered where its ray is made.  Most queries of the reference's framings never come near the mesh:
-// they pass the root Node's box and, of the root RECORD's four slots, only leaf slots -- on the headline scene the
-// group of the floor rectangle.  For such a ray the walk is: root box, root record, those groups' primitives, done;
-// here it is taken by the lane that has just made the ray, in a kernel whose waves are full, instead of by a
-// traversal lane that fetches the slot, runs one interior step and one leaf phase among deeper walks and writes
-// the slot back.  The record and the primitives are the same for every lane: they arrive through the scalar cache.
-//   returns RESOLVE_WALK  an interior slot of the root record is entered: the traversal kernel's business
-//           RESOLVE_HIT   closest hit (t, prim) among the groups entered, by the reference's rule (bvh.rs:62, :406)
-//           RESOLVE_MISS  nothing hit (or the root box missed, bvh.rs:394)
-// No slot is culled by a closest hit here, as none is in the traversal kernel's visit of the root record (its
-// closest hit is still t1 then), so the work is the walk's own: one record, the entered groups' primitives.
-constexpr int RESOLVE_WALK = 0, RESOLVE_HIT = 1, RESOLVE_MISS = 2;
-
-template <bool COMPACT>
-RR_DEV int resolve_root(const SceneDev& sc, V3 o, V3 d, double& t_hit, uint32_t& prim_hit, WorkCount& wc) {
-    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    if (!root_box_hit(sc, o, inv)) return RESOLVE_MISS;
-    if ((sc.root_ref >> 30) != REF_INTERIOR) return RESOLVE_WALK;  // no record at all (local_pool.hip's scenes)
-    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
-    const uint32_t rec = sc.root_ref & 0x3fffffffu;
-    bool pass[4];
-    uint32_t ref[4];
-    bool walk = false;
-    if (COMPACT) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(sc.nodes) + (size_t)rec * 32;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double e;
-            ref[k] = w[24 + k];
-            pass[k] = slab_f32(w[6 * k], w[6 * k + 1], w[6 * k + 2], w[6 * k + 3], w[6 * k + 4], w[6 * k + 5], nx, ny, nz,
-                               o, inv, sc.t0, sc.t1, e);
-        }
-    } else {
-        const double* w = reinterpret_cast<const double*>(sc.nodes) + (size_t)rec * 32;
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(w + 24);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double e;
-            ref[k] = r[k];
-            const double* b = w + 6 * k;
-            pass[k] = slab(nx ? b[1] : b[0], nx ? b[0] : b[1], ny ? b[3] : b[2], ny ? b[2] : b[3], nz ? b[5] : b[4],
-                           nz ? b[4] : b[5], o, inv, sc.t0, sc.t1, e);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) walk = walk || (pass[k] && (ref[k] >> 30) == REF_INTERIOR);
-    if (walk) return RESOLVE_WALK;
-    wc.interior++;
-    double best_t = sc.t1;
-    uint32_t best_prim = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((ref[k] >> 30) != REF_RANGE) continue;  // wave-uniform
-        const uint32_t first = (ref[k] & 0x3fffffffu) >> 2, count = (ref[k] & 3u) + 1u;
-        for (uint32_t j = 0; j < count; j++) {
-            const uint32_t p = first + j;
-            const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
-            if (pass[k]) {
-                const uint32_t kind = r.tag() & 3u;
-                if (kind == PRIM_TRIANGLE) wc.tri++;
-                else if (kind == PRIM_SPHERE) wc.sphere++;
-                else wc.plane++;
-                double t;
-                if (prim_intersect<COMPACT>(r, o, d, t) && t > sc.t0 && t < sc.t1) {  // bvh.rs:406
-                    if (t < best_t || (t == best_t && p < best_prim)) best_t = t, best_prim = p;  // bvh.rs:62
-                }
-            }
-        }
-    }
-    t_hit = best_t, prim_hit = best_prim;
-    return best_prim != 0xffffffffu ? RESOLVE_HIT : RESOLVE_MISS;
-}
-
 // ---------------------------------------------------------------- materials
 
 struct CtLayer {  // struct CookTorrance, material.rs:194-200

@@ -117,9 +117,7 @@ struct Counters {
     unsigned long long step_wave, step_lane, inner_wave, leaf_wave;
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
-    unsigned long long direct_rays;  // queries answered by the kernel that made the ray (root box missed, or resolve_root)
-    // of the work counters above, the part done by those kernels (count_work only)
-    unsigned long long early_visits, early_tri_tests, early_sphere_tests, early_plane_tests;
+    unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
 };
 
 struct RenderDev {
@@ -137,8 +135,8 @@ struct RenderDev {
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     uint32_t leaf_single;           // traversal: a leaf phase tests one primitive per lane (else the lane's whole group)
     uint32_t trav_two;              // traversal: two queries per lane (wf_trav2_kernel)
-    uint32_t early_resolve;         // queries that need no walk are answered by the kernel that makes the ray (resolve_root)
     uint32_t pad2;
+    uint32_t hit_wps3;              // experiment: the hit kernel built for three workgroups per CU, without look-ahead
     double* partial;       // total_items * 3
     unsigned long long* next_item;  // device-wide item counter (shared by the render's pipelines)
     Counters* counters;

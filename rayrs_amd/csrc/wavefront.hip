@@ -251,10 +251,8 @@ RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r)
 // What the kernels that start samples count per lane.
 struct SampleCount {
     unsigned long long paths;   // samples started
-    unsigned long long direct;  // of them: primary rays whose query was answered here with a Miss (sample finished here, below)
+    unsigned long long direct;  // of them: primary rays that missed the root box (answered here, below)
     uint32_t retired;           // slots that found no further item
-    unsigned long long resolved;  // queries answered here whose slot went on to the hit or miss kernel (resolve_root)
-    WorkCount early;              // the work of all queries answered here: root records entered, primitives tested
 };
 
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
@@ -348,14 +346,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
             sn.paths++;
             s_cur++;
-            // the first query, answered here when it needs no walk (resolve_root); else only its first step, the root
-            // Node's box (bvh.rs:394)
-            int first_query = RESOLVE_WALK;
-            double t_hit = 0.0;
-            uint32_t prim_hit = 0xffffffffu;
-            if (rp.early_resolve & 1u) first_query = resolve_root<COMPACT>(sc, o, d, t_hit, prim_hit, sn.early);
-            else if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) first_query = RESOLVE_MISS;
-            if (first_query == RESOLVE_MISS) {
+            if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) {
                 // radiance() with the first query a Miss: light 0 + throughput 1 * background (lib.rs:522-523, :555)
                 const V3 result = v_add(mk(0.0, 0.0, 0.0), v_mul(mk(1.0, 1.0, 1.0), background(sc, d)));
                 acc0 += result.x;
@@ -376,11 +367,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                     t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
                 if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                if (first_query == RESOLVE_HIT) {
-                    rs->t = t_hit, rs->prim = prim_hit;
-                    sn.resolved++;
-                }
-                wf.state[slot] = first_query == RESOLVE_HIT ? WF_HIT : WF_READY;
+                wf.state[slot] = WF_READY;
                 todo = false;
             }
         }
@@ -397,23 +384,6 @@ RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const Sampl
         atomicAdd(&rp.counters->escaped_paths, direct);
         atomicAdd(&rp.counters->direct_rays, direct);
     }
-    if (rp.early_resolve) {  // wave-uniform
-        const unsigned long long resolved = wave_sum(sn.resolved);
-        if ((threadIdx.x & 63u) == 0 && resolved) {
-            atomicAdd(&rp.counters->rays, resolved);
-            atomicAdd(&rp.counters->direct_rays, resolved);
-        }
-        if (rp.count_work) {
-            wave_atomic_add(&rp.counters->interior_visits, sn.early.interior);
-            wave_atomic_add(&rp.counters->tri_tests, sn.early.tri);
-            wave_atomic_add(&rp.counters->sphere_tests, sn.early.sphere);
-            wave_atomic_add(&rp.counters->plane_tests, sn.early.plane);
-            wave_atomic_add(&rp.counters->early_visits, sn.early.interior);
-            wave_atomic_add(&rp.counters->early_tri_tests, sn.early.tri);
-            wave_atomic_add(&rp.counters->early_sphere_tests, sn.early.sphere);
-            wave_atomic_add(&rp.counters->early_plane_tests, sn.early.plane);
-        }
-    }
     const uint32_t r = (uint32_t)wave_sum(sn.retired);
     if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
 }
@@ -427,7 +397,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
+    SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -855,8 +825,10 @@ RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0:
     h.ir = load_item(wf, h.slot);
 }
 
-template <bool COMPACT, bool EAGER>
-__global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+// WPS = workgroups per CU the kernel is built for.  2: 256 registers, batch b + 1 requested while batch b is computed
+// (below).  3: 168 registers and no look-ahead -- a third wave per SIMD covers the waits instead (experiment).
+template <bool COMPACT, bool EAGER, int WPS>
+__global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
     // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
@@ -869,7 +841,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
+    SampleCount sn{0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -887,8 +859,11 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     }
     while (have) {
         HitIn nxt;
-        const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_hit_in<EAGER>(wf, nxt);
+        bool have_next = false;
+        if (WPS == 2) {
+            have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
+            if (have_next) load_hit_in<EAGER>(wf, nxt);
+        }
         PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
@@ -941,21 +916,12 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
             }
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
-            if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
-            // the next query, answered here when it needs no walk (resolve_root)
-            uint8_t next_state = WF_READY;
-            double t_next = 0.0;
-            uint32_t prim_next = 0xffffffffu;
-            if (rp.early_resolve & 2u) {  // wave-uniform
-                const int q = goes_on ? resolve_root<COMPACT>(sc, position, dir, t_next, prim_next, sn.early) : RESOLVE_WALK;
-                if (q != RESOLVE_WALK) next_state = q == RESOLVE_HIT ? WF_HIT : WF_MISS, sn.resolved++;
-            }
+            if (WPS == 2 && have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
             if (goes_on) {
                 RaySlot* rs = ray_slot(wf, slot);
                 rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
                 rs->d[0] = dir.x, rs->d[1] = dir.y, rs->d[2] = dir.z;
                 rs->bd = bd_next;
-                if (next_state == WF_HIT) rs->t = t_next, rs->prim = prim_next;
                 TailSlot* lt = tail_slot(wf, slot);
                 lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
                 const bool keep_light = !light_is_plus_zero(light);
@@ -964,7 +930,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     l[0] = light.x, l[1] = light.y, l[2] = light.z;
                 }
                 lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
-                wf.state[slot] = next_state;
+                wf.state[slot] = WF_READY;
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
@@ -975,9 +941,17 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             }
             next_sample<COMPACT>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
         }
-        cur = nxt;
-        rec_cur = rec_nxt;
-        have = have_next;
+        if (WPS == 2) {
+            cur = nxt;
+            rec_cur = rec_nxt;
+            have = have_next;
+        } else {
+            have = feed_next(feed, wf, cur.slot, cur.valid);
+            if (have) {
+                load_hit_in<EAGER>(wf, cur);
+                rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
+            }
+        }
     }
     store_item_range(wf, wave, range);
     store_sample_count(rp, wf, sn);
@@ -1013,7 +987,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
-    SampleCount sn{0, 0, 0, 0, {0, 0, 0, 0, 0}};
+    SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
@@ -1140,14 +1114,18 @@ hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_reco
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
                          const WfDev& wf, uint32_t blocks, hipStream_t stream) {
     const bool lean = eager_light;
+    if (rp.hit_wps3 && compact && !lean) {  // (the experiment is built for the headline's variant only)
+        hipLaunchKernelGGL((wf_hit_kernel<true, false, 3>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        return hipGetLastError();
+    }
     if (compact && lean)
-        hipLaunchKernelGGL((wf_hit_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<true, true, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else if (compact)
-        hipLaunchKernelGGL((wf_hit_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<true, false, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else if (lean)
-        hipLaunchKernelGGL((wf_hit_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<false, true, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else
-        hipLaunchKernelGGL((wf_hit_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<false, false, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 

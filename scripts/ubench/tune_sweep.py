@@ -1,6 +1,7 @@
 """Same-box sweep of rayrs_tuning settings on one scene built once (development aid).
 usage: python scripts/ubench/tune_sweep.py <config> <res> <spp> "k=v,k=v" "k=v" ...   ("" = defaults)
-Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render."""
+Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render.
+TILE_RANKS=n in the environment renders rank 0's share of n (what one GPU of n does)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayrs_amd
@@ -19,9 +20,9 @@ ref = None
 for s in settings + settings[::-1]:
     kw = {k: int(v) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
     scene.set_tuning(**kw)
-    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk)
+    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, tile_ranks=int(os.environ.get("TILE_RANKS", "1")))
     if ref is None:
         ref = img.copy()
     same = bool((img.view("u4") == ref.view("u4")).all())
     print(f"[{s or 'defaults':40s}] trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f} ms  rounds {st['kernel_launches']:4d}  "
-          f"Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}  same_bits={same}", flush=True)
+          f"Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}  hit {st['hit_ms']:7.1f} miss {st['miss_ms']:7.1f}  same_bits={same}", flush=True)

@@ -157,6 +157,9 @@ def test_launch_limits_are_reported_not_rendered():
     assert status(big, spp=4096, max_bounces=4, sample_chunk=8) == -5  # 2^26 pixels * 512 chunks = 2^35 items
     small = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, 8, 8))
     assert status(small, spp=1, max_bounces=9000) == -5
+    assert status(small, spp=1, max_bounces=8001) == -5
+    img, st = rayrs_amd.render(scene, small, 1, 8000)    # the limit itself renders
+    assert st["paths"] == 64
     assert status(small, spp=(1 << 30) + 5, max_bounces=4) == -5          # a slot's sample cursor has 30 bits
 
 
