@@ -746,6 +746,12 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             lp.item_base = seg * LOCAL_SEGMENT_ITEMS;
             lp.item_count = rp.total_items - lp.item_base < LOCAL_SEGMENT_ITEMS ? rp.total_items - lp.item_base
                                                                                  : LOCAL_SEGMENT_ITEMS;
+            {
+                const uint64_t share = lp.item_count / ((uint64_t)blocks * 4u * 16u);  // a sixteenth of a wave's share
+                lp.reserve = (uint32_t)(share < 8u ? 8u : share > 256u ? 256u : share);
+                if (scene->tuning.pool_slots >= 8u && scene->tuning.pool_slots <= 4096u) lp.reserve = scene->tuning.pool_slots;  // (experiments)
+                lp.pad = 0;
+            }
             while (pl.ev_trav.size() < 4 * (size_t)(seg + 1)) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));

@@ -35,6 +35,8 @@ struct LocalDev {
     unsigned long long* next_item;  // item counter of this launch's segment, counting from 0
     uint64_t item_base;             // first item of the segment
     uint64_t item_count;            // items in the segment
+    uint32_t reserve;               // items a wave takes from the counter at a time
+    uint32_t pad;
 };
 
 uint32_t lp_lds_bytes(uint32_t n_prims, uint32_t n_surfaces);

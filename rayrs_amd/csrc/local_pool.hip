@@ -64,7 +64,9 @@ constexpr uint32_t LP_NSTATE = 12, LP_DEAD = 12;
 constexpr uint32_t LP_BOUNCE_MASK = 0x7fffu;
 constexpr uint32_t LP_DIRECT_BIT = 0x8000u;  // a primary ray that missed the root box: a query answered without a walk
 
-constexpr uint32_t LP_RESERVE = 32;  // items a wave takes from the counter at a time
+// Items a wave takes from the device-wide counter at a time: LocalDev::reserve, between 8 and 256, about a
+// sixteenth of a wave's share of the segment.  One counter word serves about 90 atomics per microsecond on this
+// chip; at 32 items a grab the config-2 frame asked for 60 (each a round trip the wave waits for).
 
 struct Pool {
     double* f64;
@@ -149,7 +151,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
             uint32_t first = 0xffffffffu;
             if (!range.gone) {
                 unsigned long long f64v = 0;
-                if (lane == 0) f64v = atomicAdd(lp.next_item, (unsigned long long)LP_RESERVE);
+                if (lane == 0) f64v = atomicAdd(lp.next_item, (unsigned long long)lp.reserve);
                 const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)f64v);
                 const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(f64v >> 32));
                 first = (fhi != 0u || (uint64_t)flo >= lp.item_count) ? 0xffffffffu : flo;
@@ -160,7 +162,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
                 break;
             }
             range.next = first;
-            range.end = (uint64_t)first + LP_RESERVE < lp.item_count ? first + LP_RESERVE : (uint32_t)lp.item_count;
+            range.end = (uint64_t)first + lp.reserve < lp.item_count ? first + lp.reserve : (uint32_t)lp.item_count;
         }
         const uint32_t avail = range.end - range.next;
         const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
@@ -336,6 +338,14 @@ RR_DEV uint32_t lp_shade(const Pool& pl, bool valid, uint32_t p, int kind, const
     return LP_GEN;
 }
 
+// the shader clock once everything issued so far has completed (count_work only: clock64() alone is read early,
+// and a phase's time lands in the next phase's bucket)
+RR_DEV unsigned long long lp_clock() {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+
 RR_DEV unsigned long long lp_wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -393,7 +403,8 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
     LpRange range{0u, 0u, false};
     LpCount n{0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long u_wave = 0, u_lane = 0;
-    unsigned long long tk_isect = 0, tk_shade = 0, tk_other = 0, tk_last = COUNT ? clock64() : 0ull;
+    unsigned long long tk_isect = 0, tk_shade = 0, tk_other = 0, tk_last = COUNT ? lp_clock() : 0ull;
+    unsigned long long n_isect = 0, n_shade = 0;
 
     for (;;) {
         // the phase most paths wait for
@@ -435,9 +446,9 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
         }
         if (valid) pl.state[p] = (uint8_t)ns;
         if (COUNT) {  // shader clock per phase kind: ISECT / SHADE_k / GEN and BG (Counters::*_ticks)
-            const unsigned long long now = clock64();
-            if (ph == LP_ISECT) tk_isect += now - tk_last;
-            else if (ph >= LP_SHADE0) tk_shade += now - tk_last;
+            const unsigned long long now = lp_clock();
+            if (ph == LP_ISECT) tk_isect += now - tk_last, n_isect++;
+            else if (ph >= LP_SHADE0) tk_shade += now - tk_last, n_shade++;
             else tk_other += now - tk_last;
             tk_last = now;
         }
@@ -462,6 +473,7 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
             atomicAdd(&c->step_wave, u_wave * 64ull);
             atomicAdd(&c->interior_ticks, tk_isect), atomicAdd(&c->leaf_ticks, tk_shade);
             atomicAdd(&c->refill_ticks, tk_other);
+            atomicAdd(&c->inner_wave, n_isect), atomicAdd(&c->leaf_wave, n_shade);  // phase executions (diagnostics)
         }
         lp_wave_add(&c->step_lane, u_lane);
     }
