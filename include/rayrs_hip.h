@@ -242,8 +242,10 @@ typedef struct {
     uint64_t direct_rays;
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
-    uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
+    uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool), 2 = by the
+                               traversal kernel + the stream-pool kernel (rayrs_tuning.stream_pool; its time is hit_ms) */
     uint32_t pad;
+    uint64_t shade_wave, shade_lane; /* stream-pool kernel, count_work only: phase executions x 64, lanes active in them */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:
@@ -313,6 +315,11 @@ typedef struct {
     uint32_t trav_queries;  /* traversal: BVH queries a lane holds at a time, 1 or 2 (a lane with two takes part in a
                                wave's interior or leaf step with whichever of them stands in that phase; three
                                workgroups per CU instead of five: +26 % traversal time); 3 = two, built for four */
+    uint32_t stream_pool;   /* scenes with a deeper walk tree, an experiment of round 3 (bit-identical, slower: DESIGN.md
+                               section 4): 1 = everything of a path except its deep BVH walks runs in ONE kernel that keeps
+                               the path in LDS between two walks (stream_pool.hip: two launches per round, a path crosses
+                               the pool in HBM once per DEEP query; traversal -35 %, shading x1.9), 0 = the hit and miss
+                               kernels (three launches per round, once per query) */
 } rayrs_tuning;
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
@@ -342,6 +349,9 @@ int rayrs_test_material(int device, const rayrs_material* mat, const double* nor
                         uint32_t* draws);
 /* Scene::background for n directions. */
 int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
+/* Development aid: shader-clock ticks (out[0..4]) and executions (out[5..9]) of the stream-pool kernel's phase kinds
+ * -- import, gen, isect, bg, shade -- in the last count_work render of this scene. */
+int rayrs_debug_counters(rayrs_scene* scene, uint64_t out[10]);
 
 /* ---- file formats either side of the path (host only) ---- */
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout",
     "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
-    "rayrs_test_background",
+    "rayrs_test_background", "rayrs_debug_counters",
     "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
     "rayrs_hdr_load", "rayrs_hdr_save", "rayrs_image_to_bytes", "rayrs_ppm_save", "rayrs_png_save",
 ]
@@ -69,7 +69,7 @@ class RenderStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
-                ("local_pool", C.c_uint32), ("pad", C.c_uint32)]
+                ("local_pool", C.c_uint32), ("pad", C.c_uint32), ("shade_wave", C.c_uint64), ("shade_lane", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -82,7 +82,8 @@ class Tuning(C.Structure):
                 ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
                 ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32),
                 ("local_pool", C.c_uint32), ("leaf_group", C.c_uint32),
-                ("hit_blocks_per_cu", C.c_uint32), ("trav_queries", C.c_uint32)]
+                ("hit_blocks_per_cu", C.c_uint32), ("trav_queries", C.c_uint32),
+                ("stream_pool", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in
@@ -145,6 +146,7 @@ def lib():
     L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rayrs_test_material.argtypes = [C.c_int, mp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     L.rayrs_test_background.argtypes = [vp, vp, C.c_uint64, vp]
+    L.rayrs_debug_counters.argtypes = [vp, vp]
     L.rayrs_io_last_error.restype = C.c_char_p
     L.rayrs_buffer_free.argtypes = [vp]
     L.rayrs_buffer_free.restype = None

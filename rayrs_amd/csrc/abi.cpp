@@ -14,6 +14,7 @@
 #include "../../include/rayrs_hip.h"
 #include "kernels.h"
 #include "local_pool.h"
+#include "stream_pool.h"
 #include "scene_host.hpp"
 #include "scene_internal.hpp"
 #include "wavefront.h"
@@ -283,6 +284,31 @@ static void scene_configure_local(rayrs_scene* s) {
     s->local_ok = true;
 }
 
+// The walk tree's root record as kernel arguments of stream_pool.hip (RootRecord): its interior slots send a ray
+// to the traversal kernel, its leaf groups are tested where the ray is made.
+static void scene_configure_stream(rayrs_scene* s) {
+    const FlatScene& f = s->flat;
+    RootRecord& r = s->root_record;
+    std::memset(&r, 0, sizeof(r));
+    s->stream_ok = false;
+    if (f.n_wide() < 1 || (f.wide_root_ref >> 30) != REF_INTERIOR) return;
+    const uint32_t rec = f.wide_root_ref & 0x3fffffffu;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t ref = f.wide_ref[(size_t)rec * 4 + k];
+        r.kind[k] = ref >> 30;
+        for (int i = 0; i < 6; i++) r.box[k][i] = f.wide_box[((size_t)rec * 4 + k) * 6 + i];
+        if (r.kind[k] == REF_RANGE) {
+            r.first[k] = (ref & 0x3fffffffu) >> 2;
+            r.count[k] = (ref & 3u) + 1u;
+            r.lds_first[k] = r.n_lds_prims;
+            r.n_lds_prims += r.count[k];
+        } else if (r.kind[k] != REF_INTERIOR && r.kind[k] != REF_NONE) {
+            return;  // (the walk tree has no other slot kinds)
+        }
+    }
+    s->stream_ok = r.n_lds_prims <= SP_ROOT_PRIMS;
+}
+
 extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     hipDeviceProp_t prop;
@@ -312,6 +338,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         for (auto& e : pl.ev_batch) HIP_TRY(hipEventCreate(&e));
     }
     HIP_TRY(hipMalloc((void**)&s->d_next_item, sizeof(unsigned long long)));
+    if (s->stream_ok) HIP_TRY(sp_configure());
     if (s->local_ok) {
         HIP_TRY(lp_configure());
         HIP_TRY(hipMalloc((void**)&s->d_local_items, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long)));
@@ -342,6 +369,7 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     s->n_objects = objs->list.objs.size();
     s->device = device;
     scene_configure_local(s.get());
+    scene_configure_stream(s.get());
     if (device >= 0) {
         st = scene_upload(s.get());
         if (st != RAYRS_OK) {
@@ -406,6 +434,8 @@ int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scen
         s->tuning = scene->tuning;
         s->device = device;
         scene_configure_local(s.get());
+        scene_configure_stream(s.get());
+    scene_configure_stream(s.get());
         const int st = scene_upload(s.get());
         if (st != RAYRS_OK) {
             scene_free_device(s.get());
@@ -422,7 +452,7 @@ int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     if (!scene || !tuning) return RAYRS_INVALID_ARG;
     if (tuning->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
     if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u ||
-        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || (tuning->hit_blocks_per_cu != 0u && tuning->hit_blocks_per_cu != 2u && tuning->hit_blocks_per_cu != 3u))
+        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || tuning->stream_pool > 1u || (tuning->hit_blocks_per_cu != 0u && tuning->hit_blocks_per_cu != 2u && tuning->hit_blocks_per_cu != 3u))
         return RAYRS_INVALID_ARG;
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
@@ -473,7 +503,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 26);
+    RAYRS_STRUCT(rayrs_render_stats, 28);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -487,13 +517,14 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, pad);
-    RAYRS_STRUCT(rayrs_tuning, 13);
+    RAYRS_FIELD(rayrs_render_stats, shade_wave), RAYRS_FIELD(rayrs_render_stats, shade_lane);
+    RAYRS_STRUCT(rayrs_tuning, 14);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
     RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
     RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
     RAYRS_FIELD(rayrs_tuning, eager_light), RAYRS_FIELD(rayrs_tuning, local_pool);
     RAYRS_FIELD(rayrs_tuning, leaf_group), RAYRS_FIELD(rayrs_tuning, hit_blocks_per_cu);
-    RAYRS_FIELD(rayrs_tuning, trav_queries);
+    RAYRS_FIELD(rayrs_tuning, trav_queries), RAYRS_FIELD(rayrs_tuning, stream_pool);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -629,12 +660,16 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // the second starts its first traversal when the first pipeline's has finished, and from then on each
     // runs its rounds at its own pace: while one is in its hit and miss kernels (memory bound, the vector
     // ALUs mostly idle) the other is in its traversal kernel (ALU bound, a third of the memory traffic).
+    const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
+    // paths resident in LDS between two deep walks (stream_pool.hip): one pipeline, its own grid
+    const bool use_stream = !use_local && scene->stream_ok && scene->tuning.stream_pool == 1u &&
+                            scene->tuning.pipelines != 2u;  // (two pipelines are a layout of the three streaming kernels)
+    const uint32_t sp_blocks = (uint32_t)scene->cu_count * 3u;
     uint32_t n_pipes = scene->tuning.pipelines == 2u ? 2u : 1u;
-    if (live_total < 2ull * 65536ull) n_pipes = 1;
+    if (live_total < 2ull * 65536ull || use_stream) n_pipes = 1;
     scene->n_pipes = n_pipes;
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
     if (use_local && (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS > LOCAL_MAX_SEGMENTS)
         return RAYRS_UNSUPPORTED;
     uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
@@ -684,6 +719,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         flat_blocks[p] = fb;
         // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three
         wf.n_flat_waves = fb * 4u;
+        if (use_stream && wf.n_flat_waves < sp_blocks * 4u) wf.n_flat_waves = sp_blocks * 4u;  // its waves keep item ranges too
         if (wf.n_flat_waves > pl.wave_items_cap) {
             if (pl.d_wave_items) HIP_TRY(hipFree(pl.d_wave_items));
             pl.d_wave_items = nullptr;
@@ -718,6 +754,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
     scene->rounds = 0;
     scene->last_local = use_local;
+    scene->last_stream_pool = use_stream;
     if (use_local && rp.total_items > 0) {
         // ---- one launch per segment of the frame's items; a launch ends when its last path has (local_pool.hip)
         rayrs_scene::Pipeline& pl = scene->pipe[0];
@@ -770,7 +807,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
         for (uint32_t p = 0; p < n_pipes; p++) {
             HIP_TRY(wf_launch_init(wfs[p], lives[p], streams[p]));
-            HIP_TRY(wf_launch_gen(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));  // initial fill; later samples start in hit/miss
+            // initial fill; later samples start in hit/miss (stream_pool.hip's kernel takes the IDLE slots itself)
+            if (!use_stream) HIP_TRY(wf_launch_gen(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));
             scene->pipe[p].h_live[0] = scene->pipe[p].h_live[1] = lives[p];
         }
         // Rounds are enqueued in batches; the live-slot counts of batch b are read back while batch b+1 is
@@ -796,12 +834,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                         }
                         HIP_TRY(hipEventRecord(pl.ev_trav[4 * it], st));
                     }
-                    HIP_TRY(wf_launch_trav(compact, count, sc, rps[p], wfs[p], trav_blocks, st));
+                    // (with the stream pool the frame's first round has nothing to walk yet: every slot is IDLE)
+                    if (!(use_stream && it == 0)) HIP_TRY(wf_launch_trav(compact, count, sc, rps[p], wfs[p], trav_blocks, st));
                     if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 1], st));
                     if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
-                    HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    if (use_stream) HIP_TRY(sp_launch(compact, count, sc, scene->root_record, cam, rps[p], wfs[p], sp_blocks, st));
+                    else HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
                     if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 2], st));
-                    HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
+                    if (!use_stream) HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
                     if (timed) {
                         HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 3], st));
                         pl.timed_rounds = it + 1;
@@ -896,7 +936,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         }
         stats->kernel_ms = trav;
         stats->hit_ms = hit, stats->miss_ms = miss;
-        stats->local_pool = scene->last_local ? 1u : 0u;
+        stats->local_pool = scene->last_local ? 1u : scene->last_stream_pool ? 2u : 0u;
+        stats->shade_wave = c.shade_wave, stats->shade_lane = c.shade_lane;
         stats->kernel_launches = (uint64_t)scene->rounds * scene->n_pipes;
     }
     return RAYRS_OK;
@@ -922,6 +963,17 @@ int rayrs_render(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_ren
     }
     (void)hipFree(d_out);
     return st;
+}
+
+// development aid (scripts/ubench/sp_probe.py): the stream-pool kernel's per-phase clock and execution counts of the
+// last count_work render -- import, gen, isect, bg, shade
+int rayrs_debug_counters(rayrs_scene* scene, uint64_t out[10]) {
+    if (!scene || !out || scene->device < 0) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    Counters c;
+    HIP_TRY(hipMemcpy(&c, scene->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 5; j++) out[j] = c.sp_ticks[j], out[5 + j] = c.sp_phases[j];
+    return RAYRS_OK;
 }
 
 // ------------------------------------------------------------- self tests

@@ -118,6 +118,9 @@ struct Counters {
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
+    unsigned long long shade_wave, shade_lane;  // stream_pool.hip: phase executions x 64 and the lanes active in them (count_work)
+    unsigned long long sp_ticks[5], sp_phases[5];  // stream_pool.hip diagnostics: shader clock and executions per phase kind
+                                                   // (import, gen, isect, bg, shade); read by rayrs_debug_counters
 };
 
 struct RenderDev {

@@ -233,6 +233,7 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->interior_ticks += s.interior_ticks, stats->leaf_ticks += s.leaf_ticks;
                 stats->refill_ticks += s.refill_ticks;
                 for (int k = 0; k < 8; k++) stats->surface_hits[k] += s.surface_hits[k];
+                stats->shade_wave += s.shade_wave, stats->shade_lane += s.shade_lane;
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
                 if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
                 if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;

@@ -8,6 +8,7 @@
 
 #include "../../include/rayrs_hip.h"
 #include "local_pool.h"
+#include "stream_pool.h"
 #include "scene_host.hpp"
 #include "wavefront.h"
 
@@ -63,6 +64,10 @@ struct rayrs_scene {
     bool local_ok = false;
     bool last_local = false;          // the render in flight took that route
     rayrs::LocalScene local = {};
+    // Scenes with a deeper walk tree: paths resident in LDS between two deep walks (stream_pool.hip)
+    bool stream_ok = false;
+    bool last_stream_pool = false;
+    rayrs::RootRecord root_record = {};
     double* d_local_light = nullptr;  // 4 doubles per resident path
     size_t local_light_paths = 0;
     unsigned long long* d_local_items = nullptr;  // one item counter per launch segment

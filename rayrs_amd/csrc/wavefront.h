@@ -58,7 +58,8 @@ constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)
 struct WfCtl {
     uint32_t next_window;  // window cursor of the traversal kernel
     uint32_t live_slots;   // slots that still have or can get work
-    uint32_t pad[6];
+    uint32_t next_window_shade;  // window cursor of stream_pool.hip's kernel (reset by the traversal kernel)
+    uint32_t pad[5];
 };
 
 struct WfDev {

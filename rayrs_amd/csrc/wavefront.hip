@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     if (i == 0) {
         WfCtl* c = wf.ctl;
         c->next_window = 0;
+        c->next_window_shade = 0;
         c->live_slots = live;
     }
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->next_window_shade = 0;  // stream_pool.hip's window cursor
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records

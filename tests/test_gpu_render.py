@@ -395,3 +395,23 @@ def test_light_side_array_eager_and_on_demand():
     ref, ost = osc.render(ocam, 16, 50, sample_chunk=4, traversal=0)
     assert st["rays"] == ost["rays"]
     assert_same_frame(img, ref)
+
+
+@pytest.mark.parametrize("lit,w,h,spp,chunk", [(True, 200, 120, 8, 0), (False, 96, 64, 12, 4), (True, 61, 19, 5, 2)])
+def test_stream_pool_renders_the_streaming_kernels_frame(lit, w, h, spp, chunk):
+    """rayrs_tuning.stream_pool = 1 (an experiment of round 3, off by default): everything of a path except its deep
+    BVH walks in one kernel that keeps the path in LDS between two walks (stream_pool.hip) -- queries that enter no
+    interior slot of the walk tree's root record are answered there.  Same frame bits, same ray / path / escaped
+    counts and the walk's own work counters as the hit and miss kernels and the oracle; no item is lost when slots
+    change waves' pools (200 x 120 x 8 lost 14 pixels' items in the first version, which dealt windows dynamically)."""
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), w, h, spp)
+    a, sa = rayrs_amd.render(scene, cam, spp, 50, seed=7, sample_chunk=chunk, out_f64=True, count_work=True)
+    scene.set_tuning(stream_pool=1)
+    b, sb = rayrs_amd.render(scene, cam, spp, 50, seed=7, sample_chunk=chunk, out_f64=True, count_work=True)
+    assert sa["local_pool"] == 0 and sb["local_pool"] == 2
+    ref, ost = osc.render(ocam, spp, 50, seed=7, sample_chunk=chunk, traversal=0)
+    assert_same_frame(b, ref)
+    assert_same_frame(a, ref)
+    for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "surface_hits"):
+        assert sa[k] == sb[k], k
+    assert sb["rays"] == ost["rays"] and sb["paths"] == ost["paths"] == w * h * spp
