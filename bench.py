@@ -343,7 +343,10 @@ def main():
             share_miss = paths_end_in_miss / max(cst["paths"], 1)
             # every kernel of the frame: its HIP-event time per step (on the render stream) and the useful lane
             # operations it is charged with; the roofline is the one with the largest share of the step
-            if st["local_pool"]:
+            if st["local_pool"] == 2:   # rayrs_tuning.stream_pool (an experiment; not the default route)
+                kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info)},
+                        "sp_path_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_miss + ops_gen}}
+            elif st["local_pool"]:
                 kern = {"lp_path_kernel": {"ms": sum(kernel_ms) / n_st,
                                            "ops": traversal_ops(cst, info) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
             else:
@@ -373,7 +376,7 @@ def main():
                     fabric_gbs = round(k["fabric_bytes"] / (dom_ms * 1e-3) / 1e9, 1)
                     valu_busy = k.get("valu_busy")
                     valu_per_ray = round(k["valu_wave_instructions"] / max(cst["rays"], 1), 2)
-            if st["local_pool"]:
+            if st["local_pool"] == 1:
                 util = {"all phases": round(cst["step_lane"] / max(cst["step_wave"], 1), 3)}
                 tk = max(cst["interior_ticks"] + cst["leaf_ticks"] + cst["refill_ticks"], 1)
                 util["wave time: intersect / shade / generate+background"] = [

@@ -167,6 +167,31 @@ def test_tuning_is_validated_and_needs_no_gpu():
         sc.set_tuning(static_pct=101)
     with pytest.raises(ValueError):
         sc.set_tuning(no_such_knob=1)
+    for bad in (dict(stack_lds=65), dict(local_pool=2), dict(leaf_group=2), dict(trav_queries=4), dict(stream_pool=2),
+                dict(hit_blocks_per_cu=4), dict(pipelines=3)):
+        with pytest.raises(_ffi.RayrsError):
+            sc.set_tuning(**bad)
+    sc.set_tuning(local_pool=1, leaf_group=1, trav_queries=2, stream_pool=1, hit_blocks_per_cu=3)
+
+
+def test_which_route_a_scene_takes_is_decided_at_scene_new_and_needs_no_gpu():
+    """rayrs_scene_info_t.local_pool: a walk tree of at most one record (the reference's sphere scenes) is rendered by
+    local_pool.hip, everything else by the streaming kernels; rayrs_tuning.local_pool = 1 switches the former off."""
+    from rayrs_amd.api import Emission, Material, Object
+    for fn, want in ((scenes.diffuse_single_sphere, 1), (scenes.cook_torrance_spheres_metallic, 1),
+                     (scenes.material_test, 1), (lambda: scenes.mesh_scene(2), 0)):
+        cam_args, objs, heur = fn()
+        sc = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+        info = sc.info()
+        assert info["local_pool"] == want, fn
+        assert (info["n_wide"] <= 1 and info["n_prims"] <= 16) == bool(want)
+        sc.set_tuning(local_pool=1)
+        assert sc.info()["local_pool"] == 0
+    # seventeen primitives under one record cannot happen (4 slots x 4), but seventeen primitives can: two records
+    mat = Material.LambertianDiffuse((0.5, 0.5, 0.5))
+    objs = [Object.sphere(0.3, (float(i % 5), 0.3, float(i // 5)), mat, Emission.Dark()) for i in range(17)]
+    sc = rayrs_amd.Scene(objs, 1e-6, 1e6, scenes.SAH_1000, HDRI, device=-1)
+    assert sc.info()["n_wide"] > 1 and sc.info()["local_pool"] == 0
 
 
 def test_no_environment_variable_reaches_the_product():
