@@ -664,7 +664,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // paths resident in LDS between two deep walks (stream_pool.hip): one pipeline, its own grid
     const bool use_stream = !use_local && scene->stream_ok && scene->tuning.stream_pool == 1u &&
                             scene->tuning.pipelines != 2u;  // (two pipelines are a layout of the three streaming kernels)
-    const uint32_t sp_blocks = (uint32_t)scene->cu_count * 3u;
+    const uint32_t sp_blocks = (uint32_t)scene->cu_count * (uint32_t)SP_WPS;
     uint32_t n_pipes = scene->tuning.pipelines == 2u ? 2u : 1u;
     if (live_total < 2ull * 65536ull || use_stream) n_pipes = 1;
     scene->n_pipes = n_pipes;

@@ -8,7 +8,13 @@
 
 namespace rayrs {
 
-constexpr uint32_t SP_PATHS_PER_WAVE = 120;
+#ifndef SP_P
+#define SP_P 120  // paths per wave (64 < SP_P <= 128); with SP_WPS an experiment's knob
+#endif
+#ifndef SP_WPS
+#define SP_WPS 3  // workgroups per CU the kernel is built for
+#endif
+constexpr uint32_t SP_PATHS_PER_WAVE = SP_P;
 constexpr uint32_t SP_ROOT_PRIMS = 16;  // 4 leaf slots x 4 primitives of the walk tree's root record
 
 // The walk tree's root record as kernel arguments: slot k is unused (kind REF_NONE), an interior slot (a ray that

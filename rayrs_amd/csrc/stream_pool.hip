@@ -451,7 +451,7 @@ RR_DEV void sp_wave_add(unsigned long long* dst, unsigned long long v) {
 }  // namespace
 
 template <bool COMPACT, bool COUNT>
-__global__ void __launch_bounds__(256, 3) sp_path_kernel(SceneDev sc, RootRecord root_arg, CameraDev cam, RenderDev rp,
+__global__ void __launch_bounds__(256, SP_WPS) sp_path_kernel(SceneDev sc, RootRecord root_arg, CameraDev cam, RenderDev rp,
                                                          WfDev wf) {
     extern __shared__ __align__(16) unsigned char sp_lds[];
     if (wf.ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one
