@@ -625,14 +625,27 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.out = out_device;
     rp.counters = scene->d_counters;
 
-    if (rp.total_items > scene->partial_items) {
+    // Item sums: 24 bytes per (pixel, chunk) item, added per pixel in chunk order by the resolve kernel.  The streaming
+    // kernels finish items in no particular order, so the array covers the frame.  The local-pool route renders the frame
+    // as a sequence of launches over segments of whole tiles and resolves each segment behind its launch: one segment's
+    // worth is all it needs (config 4: 3.2 GB instead of 25.8).
+    const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
+    const uint64_t tile_items = (uint64_t)rp.nchunks * 64u;
+    // (rayrs_tuning.pool_slots >= 65536 on this route: items per segment, for the tests of the segment boundaries)
+    const uint64_t seg_want = use_local && scene->tuning.pool_slots >= 65536u ? scene->tuning.pool_slots : LOCAL_SEGMENT_ITEMS;
+    const uint64_t seg_tiles = seg_want / tile_items > 0 ? seg_want / tile_items : 1;
+    const uint64_t seg_items = seg_tiles * tile_items;
+    const uint64_t partial_need = use_local && seg_items < rp.total_items ? seg_items : rp.total_items;
+    if (use_local && seg_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;  // (one tile's chunks alone: spp beyond 2^27)
+    if (partial_need > scene->partial_items) {
         if (scene->d_partial) HIP_TRY(hipFree(scene->d_partial));
         scene->d_partial = nullptr;
         scene->partial_items = 0;
-        HIP_TRY(hipMalloc((void**)&scene->d_partial, (size_t)rp.total_items * 3 * sizeof(double)));
-        scene->partial_items = (size_t)rp.total_items;
+        HIP_TRY(hipMalloc((void**)&scene->d_partial, (size_t)partial_need * 3 * sizeof(double)));
+        scene->partial_items = (size_t)partial_need;
     }
     rp.partial = scene->d_partial;
+    rp.partial_item0 = 0;
 
     const SceneDev sc = make_scene_dev(scene);
     const CameraDev cam = make_camera_dev(camera);
@@ -660,7 +673,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // the second starts its first traversal when the first pipeline's has finished, and from then on each
     // runs its rounds at its own pace: while one is in its hit and miss kernels (memory bound, the vector
     // ALUs mostly idle) the other is in its traversal kernel (ALU bound, a third of the memory traffic).
-    const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
     // paths resident in LDS between two deep walks (stream_pool.hip): one pipeline, its own grid
     const bool use_stream = !use_local && scene->stream_ok && scene->tuning.stream_pool == 1u &&
                             scene->tuning.pipelines != 2u;  // (two pipelines are a layout of the three streaming kernels)
@@ -670,8 +682,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     scene->n_pipes = n_pipes;
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    if (use_local && (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS > LOCAL_MAX_SEGMENTS)
-        return RAYRS_UNSUPPORTED;
+    if (use_local && (rp.total_items + seg_items - 1) / seg_items > LOCAL_MAX_SEGMENTS) return RAYRS_UNSUPPORTED;
     uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
     if (scene->tuning.trav_blocks_per_cu && scene->tuning.trav_blocks_per_cu < trav_bpc) trav_bpc = scene->tuning.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
@@ -760,12 +771,12 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         rayrs_scene::Pipeline& pl = scene->pipe[0];
         scene->n_pipes = 1;
         pl.timed_rounds = 0;
-        const uint64_t n_seg = (rp.total_items + LOCAL_SEGMENT_ITEMS - 1) / LOCAL_SEGMENT_ITEMS;
+        const uint64_t n_seg = (rp.total_items + seg_items - 1) / seg_items;
         // LP_WPS workgroups of four waves per CU; fewer when the frame has fewer items than resident paths
         uint32_t blocks = (uint32_t)scene->cu_count * (uint32_t)LP_WPS;
         {
-            const uint64_t seg_items = rp.total_items < LOCAL_SEGMENT_ITEMS ? rp.total_items : LOCAL_SEGMENT_ITEMS;
-            const uint64_t want = (seg_items + 4u * LP_PATHS_PER_WAVE - 1) / (4u * LP_PATHS_PER_WAVE);
+            const uint64_t most_items = rp.total_items < seg_items ? rp.total_items : seg_items;
+            const uint64_t want = (most_items + 4u * LP_PATHS_PER_WAVE - 1) / (4u * LP_PATHS_PER_WAVE);
             if (want < blocks) blocks = (uint32_t)(want ? want : 1);
         }
         const size_t paths = (size_t)blocks * 4u * LP_PATHS_PER_WAVE;
@@ -780,9 +791,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             LocalDev lp;
             lp.light = scene->d_local_light;
             lp.next_item = scene->d_local_items + seg;
-            lp.item_base = seg * LOCAL_SEGMENT_ITEMS;
-            lp.item_count = rp.total_items - lp.item_base < LOCAL_SEGMENT_ITEMS ? rp.total_items - lp.item_base
-                                                                                 : LOCAL_SEGMENT_ITEMS;
+            lp.item_base = seg * seg_items;
+            lp.item_count = rp.total_items - lp.item_base < seg_items ? rp.total_items - lp.item_base : seg_items;
+            RenderDev rseg = rp;
+            rseg.partial_item0 = lp.item_base;
             {
                 const uint64_t share = lp.item_count / ((uint64_t)blocks * 4u * 16u);  // a sixteenth of a wave's share
                 lp.reserve = (uint32_t)(share < 8u ? 8u : share > 256u ? 256u : share);
@@ -795,8 +807,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                 pl.ev_trav.push_back(e);
             }
             HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg], stream));
-            HIP_TRY(lp_launch(compact, count, sc, scene->local, cam, rp, lp, blocks, stream));
+            HIP_TRY(lp_launch(compact, count, sc, scene->local, cam, rseg, lp, blocks, stream));
             HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg + 1], stream));
+            // the segment's tiles, resolved behind its launch (the next segment reuses the item-sum array)
+            HIP_TRY(launch_resolve(cam, rseg, (uint32_t)(seg * seg_tiles), (uint32_t)(lp.item_count / tile_items), stream));
             pl.timed_rounds = (uint32_t)seg + 1;
         }
         scene->rounds = (uint32_t)n_seg;
@@ -875,7 +889,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
     }
     HIP_TRY(hipEventRecord(scene->ev[1], stream));
-    HIP_TRY(launch_resolve(cam, rp, stream));
+    if (!use_local) HIP_TRY(launch_resolve(cam, rp, 0u, rp.n_local_tiles, stream));
     HIP_TRY(hipEventRecord(scene->ev[2], stream));
     scene->last_stream = stream;
     scene->pending = true;

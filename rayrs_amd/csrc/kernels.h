@@ -6,7 +6,8 @@
 
 namespace rayrs {
 
-hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream);
+// pixel sums of the rank's tiles lt0 .. lt0 + n_lt - 1 from their items' sums (rp.partial, which starts at item rp.partial_item0)
+hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, uint32_t lt0, uint32_t n_lt, hipStream_t stream);
 hipError_t launch_accumulate(void* dst, const void* src, size_t n, bool f64, hipStream_t stream);
 
 hipError_t launch_test_math(int fn, const double* x, const double* y, uint64_t n, double* out, hipStream_t stream);

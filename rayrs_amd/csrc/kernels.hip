@@ -9,19 +9,19 @@ namespace rayrs {
 
 // Adds the chunk sums of each pixel in chunk order, applies pixel / spp
 // (main.rs:89; Div<f64> = multiply by 1/spp) and writes the framebuffer.
-__global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev rp) {
+__global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev rp, uint32_t lt0, uint32_t n_lt) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n = (uint64_t)rp.n_local_tiles * 64u;
+    const uint64_t n = (uint64_t)n_lt * 64u;  // the rank's tiles lt0 .. lt0 + n_lt - 1
     if (idx >= n) return;
     const uint32_t pit = (uint32_t)(idx & 63u);
-    const uint32_t lt = (uint32_t)(idx >> 6);
+    const uint32_t lt = lt0 + (uint32_t)(idx >> 6);
     const uint32_t tile = lt * rp.tile_ranks + rp.tile_rank;
     const uint32_t row = (tile / rp.tiles_x) * 8u + (pit >> 3);
     const uint32_t col = (tile % rp.tiles_x) * 8u + (pit & 7u);
     if (row >= cam.H || col >= cam.W) return;
     double x = 0.0, y = 0.0, z = 0.0;
     for (uint32_t k = 0; k < rp.nchunks; k++) {
-        const double* src = rp.partial + (((size_t)lt * rp.nchunks + k) * 64u + pit) * 3;
+        const double* src = rp.partial + ((((size_t)lt * rp.nchunks + k) * 64u + pit) - rp.partial_item0) * 3;
         if (k == 0) {
             x = src[0], y = src[1], z = src[2];
         } else {
@@ -64,11 +64,11 @@ hipError_t launch_accumulate(void* dst, const void* src, size_t n, bool f64, hip
 
 static inline uint32_t lds_bytes_for(uint32_t stack_depth) { return 4u * 64u * (stack_depth + 1u) * 4u; }  // + the spare entry
 
-hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, hipStream_t stream) {
-    const uint64_t n = (uint64_t)rp.n_local_tiles * 64u;
+hipError_t launch_resolve(const CameraDev& cam, const RenderDev& rp, uint32_t lt0, uint32_t n_lt, hipStream_t stream) {
+    const uint64_t n = (uint64_t)n_lt * 64u;
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, cam, rp);
+    hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, cam, rp, lt0, n_lt);
     return hipGetLastError();
 }
 

@@ -140,7 +140,8 @@ struct RenderDev {
     uint32_t trav_two;              // traversal: two queries per lane (wf_trav2_kernel)
     uint32_t pad2;
     uint32_t hit_wps3;              // experiment: the hit kernel built for three workgroups per CU, without look-ahead
-    double* partial;       // total_items * 3
+    double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)
+    uint64_t partial_item0;
     unsigned long long* next_item;  // device-wide item counter (shared by the render's pipelines)
     Counters* counters;
     void* out;

@@ -140,7 +140,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
     uint32_t row, col, s_end, s_first;
     lp_item_geometry(rp, item, row, col, s_first, s_end);  // (of no meaning without an item)
     if (has_item && s_cur >= s_end) {  // the item's sum goes to the resolve kernel
-        double* dst = rp.partial + (size_t)item * 3;
+        double* dst = rp.partial + ((size_t)item - rp.partial_item0) * 3;
         dst[0] = pl.f(F_AX, p), dst[1] = pl.f(F_AY, p), dst[2] = pl.f(F_AZ, p);
         has_item = false;
     }
@@ -173,7 +173,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
             s_cur = s_begin;
             if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
                 // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
-                double* dst = rp.partial + (size_t)item * 3;
+                double* dst = rp.partial + ((size_t)item - rp.partial_item0) * 3;
                 dst[0] = dst[1] = dst[2] = 0.0;
                 if (row < cam.H && col < cam.W) n.paths += s_end - s_begin;
             } else {

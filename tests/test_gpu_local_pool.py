@@ -152,3 +152,23 @@ def test_config1_whole_frame_at_its_stated_size():
         img, st = rayrs_amd.render(scene, cam, spp, mb, seed=0x5EED, sample_chunk=chunk, out_f64=True)
         assert st["paths"] == 256 * 256 * 64 == ost["paths"] and st["rays"] == ost["rays"]
         assert same_bits(img, ref)
+
+
+def test_segments_of_whole_tiles_are_resolved_behind_their_launch():
+    """The local-pool route renders a frame as launches over segments of whole tiles (2^27 items by default: config 4's
+    2^30 items are eight) and resolves each segment behind its launch, so the item-sum array holds one segment
+    (3.2 GB instead of 25.8 on config 4).  Here: segments of 65536 items on a ragged frame -- seven of them, the
+    last one short -- against one segment and the oracle."""
+    cam_args, objs, heur = scenes.cook_torrance_spheres_frosted_glass()
+    cam_args = scenes.camera_for_resolution(cam_args, 203, 117)   # 26 x 15 tiles, padding pixels on two edges
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    cam = rayrs_amd.Camera(*cam_args)
+    one, st1 = rayrs_amd.render(scene, cam, 64, 32, seed=9, sample_chunk=4, out_f64=True)
+    scene.set_tuning(pool_slots=65536)
+    many, stn = rayrs_amd.render(scene, cam, 64, 32, seed=9, sample_chunk=4, out_f64=True)
+    assert st1["kernel_launches"] == 1 and stn["kernel_launches"] == 7   # 390 tiles x 16 chunks x 64 = 399360 items
+    assert stn["rays"] == st1["rays"] and stn["paths"] == 203 * 117 * 64
+    assert same_bits(one, many)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+    ref, ost = osc.render(_oracle.OracleCamera(*cam_args), 64, 32, seed=9, sample_chunk=4, traversal=0)
+    assert same_bits(many, ref) and stn["rays"] == ost["rays"]
