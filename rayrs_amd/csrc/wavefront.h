@@ -50,7 +50,7 @@ constexpr uint32_t SLOT_SAMPLE_MASK = (1u << 30) - 1u;  // samples per pixel a s
 
 // slot states
 constexpr uint8_t WF_IDLE = 0;   // no path in flight: gen_kernel's input
-constexpr uint8_t WF_READY = 1;  // ray written, waiting for the traversal kernel
+constexpr uint8_t WF_READY = 1;  // ray written, waiting for the traversal kernel; | octant of its direction << 4 (wavefront.hip ready_state)
 constexpr uint8_t WF_HIT = 2;    // closest hit found: hit_kernel's input
 constexpr uint8_t WF_MISS = 3;   // no hit: miss_kernel's input
 constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)

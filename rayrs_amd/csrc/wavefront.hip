@@ -70,6 +70,22 @@ RR_DEV uint32_t compact_window(const WfDev& wf, uint32_t win, uint8_t want, uint
     return compact_words(load_state_words(wf, win), want, list);
 }
 
+// A READY state carries the octant of its ray's direction in the high nibble, and the traversal kernel builds its list
+// octant by octant: the rays a wave takes together look the same way, so they meet the tree's records in much the same
+// order (same-box A/B: traversal -1.7 % on the headline frame, -2.9 % on config 3; a fourth key bit -- steeper than
+// 45 degrees or not -- doubles the passes and gains less).
+RR_DEV uint8_t ready_state(V3 d) {
+    const uint32_t key = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+    return (uint8_t)(WF_READY | (key << 4));
+}
+RR_DEV uint32_t compact_window_ready(const WfDev& wf, uint32_t win, uint16_t* list) {
+    const StateWords sw = load_state_words(wf, win);
+    uint32_t count = 0;
+#pragma nounroll  // (unrolled, the 64 ballots' masks cost the kernel registers it does not have)
+    for (uint32_t key = 0; key < 8u; key++) count += compact_words(sw, (uint8_t)(WF_READY | (key << 4)), list + count);
+    return count;
+}
+
 // The hit and miss kernels' walk over their slots: wave g of n_waves takes windows g,
 // g + n_waves, ... and within a window the slots of state `want`, 64 at a time.  The state
 // bytes of the following window are loaded while the current one is being worked on, and the
@@ -368,7 +384,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                     t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
                 if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                wf.state[slot] = WF_READY;
+                wf.state[slot] = ready_state(d);
                 todo = false;
             }
         }
@@ -499,7 +515,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                         break;
                     }
                     list_base = w * WINDOW;
-                    list_len = compact_window(wf, w, WF_READY, list);
+                    list_len = compact_window_ready(wf, w, list);
                     list_pos = 0;
                     continue;
                 }
@@ -626,7 +642,7 @@ RR_DEV void trav2_refill(const SceneDev& sc, const WfDev& wf, WfCtl* ctl, Window
                 break;
             }
             f.list_base = w * WINDOW;
-            f.list_len = compact_window(wf, w, WF_READY, f.list);
+            f.list_len = compact_window_ready(wf, w, f.list);
             f.list_pos = 0;
             continue;
         }
@@ -932,7 +948,7 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                     l[0] = light.x, l[1] = light.y, l[2] = light.z;
                 }
                 lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
-                wf.state[slot] = WF_READY;
+                wf.state[slot] = ready_state(dir);
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
