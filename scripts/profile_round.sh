@@ -17,8 +17,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 python -c 'import __graft_entry__ as g; g.build()'
-python bench.py --no-build "$@" > $OUT/bench.json 2> $OUT/bench.err
-tail -c 300 $OUT/bench.json; echo
+python bench.py --no-build --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err  # (for the hash and the workload key)
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --no-build --steps 1 --warmup 0 --no-cpu-baseline --no-roofline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
@@ -61,3 +60,9 @@ for k, v in res.items():
     print(k, v["launches"], "fabric GB", round(v["fabric_bytes"] / 1e9, 2), "valu_busy", v["valu_busy"])
 PY
 rm -rf $OUT/pmc_mem $OUT/pmc_sq $OUT/stats
+# the bench line again, now that this tree's counters exist: bench.py fills roofline.traffic / fabric_GBps /
+# fp64_valu_busy from profiles/*_pmc.json when its source hash and workload key match
+cp $OUT/pmc.json $ROOT/profiles/${TAG}_pmc.json
+cd $ROOT
+python bench.py --no-build "$@" > $OUT/bench.json 2> $OUT/bench.err
+tail -c 200 $OUT/bench.json; echo
