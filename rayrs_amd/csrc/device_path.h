@@ -188,7 +188,11 @@ RR_DEV bool triangle_intersect(V3 p1, V3 p2, V3 p3, V3 o, V3 d, double& t) {
     const double den = v_dot(p, e1);
     double dd, u, v;  // three true divisions (geometry.rs:364-374), sharing what they can
     div3_by(v_dot(q, e2), v_dot(p, tt), v_dot(q, d), den, dd, u, v);
-    if (dd < 0.0 || u < 0.0 || v < 0.0 || u + v > 1.0) return false;
+    // (four compares OR-ed as wave masks: given lane booleans, the compiler folds the three "< 0" into
+    // min(dd, u, v) < 0 -- three canonicalisations, two minima and a compare for three compares)
+    const unsigned long long out = __builtin_amdgcn_ballot_w64(dd < 0.0) | __builtin_amdgcn_ballot_w64(u < 0.0) |
+                                   __builtin_amdgcn_ballot_w64(v < 0.0) | __builtin_amdgcn_ballot_w64(u + v > 1.0);
+    if (__builtin_amdgcn_inverse_ballot_w64(out)) return false;
     t = dd;
     return true;
 }
@@ -420,11 +424,17 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // box around it are rounded independently (and t badly so on grazing rays), so a hit computed in
     // front of its own box must not be lost to a farther one (every primitive that is tested is judged
     // by the reference's rule, so a wider margin only costs visits, never the answer).
+    // Which slots are entered, and the six comparisons of their entry parameters below, are taken as wave masks (a
+    // compare writes its mask to a scalar register pair) and combined there: "b before a" and its complement are
+    // one comparison and one scalar operation, where the compiler, given lane booleans, issues a second f64
+    // compare for every complement.
     const double cull = tv.best_t * TRAV_CULL_MARGIN;
-    h0 = h0 && !(e0 > cull);
-    h1 = h1 && !(e1 > cull);
-    h2 = h2 && !(e2 > cull);
-    h3 = h3 && !(e3 > cull);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
+#define RR_LANE_BIT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+    h0 = RR_LANE_BIT(m0), h1 = RR_LANE_BIT(m1), h2 = RR_LANE_BIT(m2), h3 = RR_LANE_BIT(m3);
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (n == 0) {
         trav_pop(stack, tv);
@@ -432,21 +442,26 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
     // rank of a hit slot = number of hit slots visited before it (nearer entry, then lower slot);
     // for a < b, slot a goes first unless e_b < e_a
-    const bool c01 = e1 < e0, c02 = e2 < e0, c03 = e3 < e0, c12 = e2 < e1, c13 = e3 < e1, c23 = e3 < e2;
-    const int k_0 = (int)(h1 && c01) + (int)(h2 && c02) + (int)(h3 && c03);
-    const int k_1 = (int)(h0 && !c01) + (int)(h2 && c12) + (int)(h3 && c13);
-    const int k_2 = (int)(h0 && !c02) + (int)(h1 && !c12) + (int)(h3 && c23);
-    const int k_3 = (int)(h0 && !c03) + (int)(h1 && !c13) + (int)(h2 && !c23);
+    const unsigned long long c01 = __builtin_amdgcn_ballot_w64(e1 < e0), c02 = __builtin_amdgcn_ballot_w64(e2 < e0);
+    const unsigned long long c03 = __builtin_amdgcn_ballot_w64(e3 < e0), c12 = __builtin_amdgcn_ballot_w64(e2 < e1);
+    const unsigned long long c13 = __builtin_amdgcn_ballot_w64(e3 < e1), c23 = __builtin_amdgcn_ballot_w64(e3 < e2);
+    const int k_0 = (int)RR_LANE_BIT(m1 & c01) + (int)RR_LANE_BIT(m2 & c02) + (int)RR_LANE_BIT(m3 & c03);
+    const int k_1 = (int)RR_LANE_BIT(m0 & ~c01) + (int)RR_LANE_BIT(m2 & c12) + (int)RR_LANE_BIT(m3 & c13);
+    const int k_2 = (int)RR_LANE_BIT(m0 & ~c02) + (int)RR_LANE_BIT(m1 & ~c12) + (int)RR_LANE_BIT(m3 & c23);
+    const int k_3 = (int)RR_LANE_BIT(m0 & ~c03) + (int)RR_LANE_BIT(m1 & ~c13) + (int)RR_LANE_BIT(m2 & ~c23);
+#undef RR_LANE_BIT
     tv.cur = (h0 && k_0 == 0) ? r0 : (h1 && k_1 == 0) ? r1 : (h2 && k_2 == 0) ? r2 : r3;
     // rank k >= 1 goes to stack entry top - k; everything else to the lane's spare entry
     const int top = tv.sp + n - 1;
     tv.sp = top;
     if (__ballot((uint32_t)top > stack.cap) == 0ull) {  // all of the wave's entries are in LDS: no branches
+        // (the rank-0 slot is written too, to entry `top`: the first free one above the new stack top, never read
+        // before it is overwritten, and at most the spare entry -- one comparison per slot less)
         const int spare = (int)stack.cap;
-        stack.lds[((h0 && k_0 > 0) ? top - k_0 : spare) * 64] = r0;
-        stack.lds[((h1 && k_1 > 0) ? top - k_1 : spare) * 64] = r1;
-        stack.lds[((h2 && k_2 > 0) ? top - k_2 : spare) * 64] = r2;
-        stack.lds[((h3 && k_3 > 0) ? top - k_3 : spare) * 64] = r3;
+        stack.lds[(h0 ? top - k_0 : spare) * 64] = r0;
+        stack.lds[(h1 ? top - k_1 : spare) * 64] = r1;
+        stack.lds[(h2 ? top - k_2 : spare) * 64] = r2;
+        stack.lds[(h3 ? top - k_3 : spare) * 64] = r3;
     } else {
         if (h0 && k_0 > 0) stack.put(top - k_0, r0);
         if (h1 && k_1 > 0) stack.put(top - k_1, r1);
