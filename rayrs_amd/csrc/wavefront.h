@@ -12,8 +12,8 @@ namespace rayrs {
 struct RaySlot {
     double o[3];
     double d[3];
-    double t;        // closest hit (valid when prim != 0xffffffff)
-    uint32_t prim;   // DFS slot of the closest primitive, 0xffffffff = miss
+    double t;        // closest hit } written by the traversal kernel for a slot it leaves in state HIT;
+    uint32_t prim;   // DFS slot of the closest primitive } stale in every other state
     uint32_t bd;     // bounce | draw << 16: number of the BVH query in flight, 1-based (loop counter of
                      // lib.rs:525), and the path's next RNG draw index
 };

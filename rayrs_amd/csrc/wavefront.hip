@@ -491,10 +491,13 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
             // ---- retire finished queries: result and new state to the slot
             if (pending) {
-                RaySlot* rs = ray_slot(wf, slot);
-                rs->t = tv.best_t;
-                rs->prim = tv.best_prim;
-                wf.state[slot] = tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
+                const bool hit = tv.best_prim != 0xffffffffu;
+                if (hit) {  // (a MISS says it all: nothing reads t or prim of such a slot, and its line stays clean)
+                    RaySlot* rs = ray_slot(wf, slot);
+                    rs->t = tv.best_t;
+                    rs->prim = tv.best_prim;
+                }
+                wf.state[slot] = hit ? WF_HIT : WF_MISS;
                 pending = false;
             }
             if (no_more) break;  // only reached with no query in flight
@@ -613,10 +616,13 @@ struct WindowFeed {
 
 RR_DEV void trav2_retire(const WfDev& wf, Query& q) {
     if (q.pending) {
-        RaySlot* rs = ray_slot(wf, q.slot);
-        rs->t = q.tv.best_t;
-        rs->prim = q.tv.best_prim;
-        wf.state[q.slot] = q.tv.best_prim != 0xffffffffu ? WF_HIT : WF_MISS;
+        const bool hit = q.tv.best_prim != 0xffffffffu;
+        if (hit) {
+            RaySlot* rs = ray_slot(wf, q.slot);
+            rs->t = q.tv.best_t;
+            rs->prim = q.tv.best_prim;
+        }
+        wf.state[q.slot] = hit ? WF_HIT : WF_MISS;
         q.pending = false;
     }
 }
@@ -947,7 +953,9 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                     double* l = light_slot(wf, slot);
                     l[0] = light.x, l[1] = light.y, l[2] = light.z;
                 }
-                lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
+                // (the cursor word changes only when the path gets or loses its light: mostly it is left alone, and with
+                // it the 32-byte sector it lies in -- stores cost these kernels more than anything they compute)
+                if (keep_light != (ir.has_light != 0u)) lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
                 wf.state[slot] = ready_state(dir);
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
