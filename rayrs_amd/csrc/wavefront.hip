@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
         {
             const uint32_t slot = cur.slot;
             const bool valid = cur.valid;
-            bool ended = false, goes_on = false;
+            bool ended = false, goes_on = false, acc_changed = false;
             uint32_t hit_sid = 8u;
             ItemRegs ir = cur.ir;
             V3 thr = mk(1.0, 1.0, 1.0), light = mk(0.0, 0.0, 0.0), position = mk(0.0, 0.0, 0.0), dir = mk(0.0, 0.0, 1.0);
@@ -937,6 +937,8 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                     ir.acc[0] += light.x;
                     ir.acc[1] += light.y;
                     ir.acc[2] += light.z;
+                    // a sum is never -0 (it starts at +0), so adding +0 leaves its bits alone, and the slot's copy stands
+                    acc_changed = !light_is_plus_zero(light);
                 }
             }
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
@@ -965,7 +967,7 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample<COMPACT>(ended, slot, ir, true, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
         }
         if (WPS == 2) {
             cur = nxt;
