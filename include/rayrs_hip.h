@@ -289,7 +289,7 @@ int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camer
 /* ---- tuning: how the kernels are scheduled, never what they compute.  0 = the built-in default.
  * (Round 1 read these from RAYRS_* environment variables; a library must not.) */
 typedef struct {
-    uint32_t pool_slots;    /* paths in flight (default: min(items, 64 Mi, samples / 16)).  On the local-pool route, which has
+    uint32_t pool_slots;    /* paths in flight (default: min(items, 112 Mi, samples / 12)).  On the local-pool route, which has
                                no pool in HBM: 8..4096 = items a wave takes from the counter at a time, >= 65536 = items
                                per launch segment (default 2^27; each segment is resolved behind its launch) */
     uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */

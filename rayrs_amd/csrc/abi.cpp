@@ -655,14 +655,17 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // items per slot -- up to the point where the hit and miss kernels lose more to the larger
     // footprint.  Swept on the headline frame with one-line slots: 24 M slots 1520 ms, 32 M 1516,
     // 48 M 1497, 64 M 1467, 96 M 1468, 128 M 1481, 192 M 1498 (round 1, 192-byte slots: 32 M).
-    // 64 M slots are 8.3 GB of the 288 GB.  A frame should also last some tens of rounds, or
-    // filling and draining the pool is all it does: at most one slot per 16 samples -- which is
-    // what a one-eighth tile share of the headline frame gets (33.5 M; 64 M would cost it 5 %).
+    // Swept again on round 3's kernels (the traversal kernel faster, its fixed cost per launch the same): 64 M 1369 ms,
+    // 80 M 1372, 96 M 1368, 112 M 1353, 128 M 1356, 160 M 1353, 192 M 1350: 112 M slots (18 GB of the 288 GB), 84 rounds.
+    // A frame should also last some tens of rounds, or filling and draining the pool is all it does: at most one
+    // slot per 12 samples -- which is what a one-eighth tile share of the headline frame gets (44.7 M: 33.5 M 189 ms,
+    // 48 M 184, 64 M 186).
+    constexpr uint64_t POOL_MAX_SLOTS = 7ull << 24;
     uint64_t np64 = rp.total_items;
-    if (np64 > (1ull << 26)) np64 = 1ull << 26;
+    if (np64 > POOL_MAX_SLOTS) np64 = POOL_MAX_SLOTS;
     {
         const uint64_t samples = n_local * 64ull * rp.spp;
-        const uint64_t by_work = samples / 16u > (1ull << 20) ? samples / 16u : (1ull << 20);
+        const uint64_t by_work = samples / 12u > (1ull << 20) ? samples / 12u : (1ull << 20);
         if (np64 > by_work) np64 = by_work;
     }
     if (scene->tuning.pool_slots) np64 = scene->tuning.pool_slots;
