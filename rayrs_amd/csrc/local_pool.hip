@@ -218,6 +218,8 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
 template <bool COMPACT, bool COUNT>
 RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, const SceneDev& sc, const LocalScene& ls,
                          const SurfaceDev* s_surf, const uint4* s_prims, LpCount& n) {
+    // (the ray is read back from the pool: handed over in registers, it costs the phase before it more in spills
+    // than the six LDS reads cost here -- config 2 +1.5 %)
     const V3 o = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
     const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const bool in = valid && root_box_hit(sc, o, inv);
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
     LpCount n{0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long u_wave = 0, u_lane = 0;
     unsigned long long tk_isect = 0, tk_shade = 0, tk_other = 0, tk_last = COUNT ? lp_clock() : 0ull;
-    unsigned long long n_isect = 0, n_shade = 0;
+    unsigned long long n_isect = 0, n_shade = 0, tk_gen = 0, n_gen = 0, n_bg = 0, t_mid = 0;
 
     for (;;) {
         // the phase most paths wait for
@@ -429,8 +431,6 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
         uint32_t ns = LP_DEAD;
         if (ph == LP_GEN) {
             ns = lp_gen(pl, valid, p, sc, cam, rp, lp, range, n);
-        } else if (ph == LP_ISECT) {
-            ns = lp_isect<COMPACT, COUNT>(pl, valid, p, sc, *s_ls, s_surf, s_prims, n);
         } else if (ph == LP_BG) {
             ns = lp_background(pl, valid, p, sc, lp, n);
         } else {
@@ -444,12 +444,28 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
                 }
             }
         }
+        // ISECT is not a phase of its own: a path that has just got a ray (GEN, SHADE_k) asks its query in the same phase
+        // execution, on the lanes it is in.  The query is short and its loops are
+        // wave-uniform, so the lanes whose paths ended idle through little, and a query costs no phase execution (state
+        // bytes, list, field loads, counters): config 2 24.5 -> 22.9 ms, config 4 220 -> 204 ms as a separate phase's
+        // replacement.  LP_ISECT is only what lp_gen / lp_shade answer for "has a ray".
+        if (ph != LP_BG) {
+            if (COUNT) t_mid = lp_clock();
+            const bool q = valid && ns == LP_ISECT;
+            if (__ballot(q) != 0ull) {
+                const uint32_t nq = lp_isect<COMPACT, COUNT>(pl, q, p, sc, *s_ls, s_surf, s_prims, n);
+                if (q) ns = nq;
+            }
+        }
         if (valid) pl.state[p] = (uint8_t)ns;
         if (COUNT) {  // shader clock per phase kind: ISECT / SHADE_k / GEN and BG (Counters::*_ticks)
             const unsigned long long now = lp_clock();
-            if (ph == LP_ISECT) tk_isect += now - tk_last, n_isect++;
-            else if (ph >= LP_SHADE0) tk_shade += now - tk_last, n_shade++;
-            else tk_other += now - tk_last;
+            if (ph != LP_BG) tk_isect += now - t_mid, n_isect++;  // the query behind a GEN or SHADE_k phase
+            else t_mid = now;
+            if (ph >= LP_SHADE0) tk_shade += t_mid - tk_last, n_shade++;
+            else tk_other += t_mid - tk_last;
+            if (ph == LP_GEN) tk_gen += t_mid - tk_last, n_gen++;
+            if (ph == LP_BG) n_bg++;
             tk_last = now;
         }
 #pragma unroll
@@ -474,6 +490,11 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
             atomicAdd(&c->interior_ticks, tk_isect), atomicAdd(&c->leaf_ticks, tk_shade);
             atomicAdd(&c->refill_ticks, tk_other);
             atomicAdd(&c->inner_wave, n_isect), atomicAdd(&c->leaf_wave, n_shade);  // phase executions (diagnostics)
+            // per phase kind for rayrs_debug_counters (the stream-pool kernel's slots: -, gen, isect, bg, shade)
+            atomicAdd(&c->sp_ticks[1], tk_gen), atomicAdd(&c->sp_ticks[2], tk_isect);
+            atomicAdd(&c->sp_ticks[3], tk_other - tk_gen), atomicAdd(&c->sp_ticks[4], tk_shade);
+            atomicAdd(&c->sp_phases[1], n_gen), atomicAdd(&c->sp_phases[2], n_isect);
+            atomicAdd(&c->sp_phases[3], n_bg), atomicAdd(&c->sp_phases[4], n_shade);
         }
         lp_wave_add(&c->step_lane, u_lane);
     }

@@ -20,3 +20,9 @@ print(f"timed {t['kernel_ms']:.2f} ms ({t['rays'] / t['kernel_ms'] / 1e3:.0f} Mr
 print(f"rays {s['rays']/1e6:.1f} M, hits {hits/1e6:.1f} M, escaped {s['escaped_paths']/1e6:.1f} M, paths {s['paths']/1e6:.1f} M; lane utilisation {s['step_lane']/s['step_wave']:.3f}")
 for name, ticks, n in (("ISECT", s["interior_ticks"], s["inner_wave"]), ("SHADE", s["leaf_ticks"], s["leaf_wave"]), ("GEN+BG", s["refill_ticks"], n_other)):
     print(f"  {name:7s} {ticks / tk:6.3f} of the wave time, {n/1e6:8.2f} M phase executions, {ticks / max(n, 1):8.0f} shader-clock ticks each")
+import numpy as np
+out = np.zeros(10, dtype=np.uint64)
+rayrs_amd._ffi.lib().rayrs_debug_counters(scene._h, out.ctypes.data)
+tot = float(out[1:5].sum())
+for k, name in ((1, "GEN"), (2, "ISECT"), (3, "BG"), (4, "SHADE")):
+    print(f"  {name:6s} {out[k] / tot:6.3f} of the wave time, {out[5 + k] / 1e6:8.2f} M executions, {out[k] / max(int(out[5 + k]), 1):8.0f} ticks each")
