@@ -15,10 +15,10 @@
 //     lanes (__ballot + popcount rank, the list in LDS), loads their state, runs the phase on all lanes
 //     and stores the state back:
 //        GEN     finished item -> HBM, next sample or next item, primary ray      main.rs:67-79, lib.rs:202-210
-//        ISECT   Bvh::intersect: root box, gating boxes, primitives               bvh.rs:391-415
-//        BG      Scene::background, sample added to the item's sum                lib.rs:254-285, :555
+//        BG      Scene::background, sample added to the item's sum, then GEN       lib.rs:254-285, :555
 //        SHADE_k Material::evaluate of material kind k, emission, roulette        lib.rs:528-551
-//     a wave in SHADE_k runs one arm of Material::evaluate (the kind is wave-uniform);
+//     a wave in SHADE_k runs one arm of Material::evaluate (the kind is wave-uniform); GEN and SHADE_k end with the
+//     new ray's query (ISECT: Bvh::intersect -- root box, gating boxes, primitives, bvh.rs:391-415) on the same lanes;
 //   * an item (pixel, sample chunk) belongs to one path slot, which runs its samples one after the other,
 //     so they are summed in order (main.rs:67-69); items come from a device-wide counter, a few dozen at
 //     a time per wave.
@@ -131,7 +131,8 @@ RR_DEV void lp_item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, 
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
 // (bvh.rs:394): such a path goes straight to BG.
 RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& sc, const CameraDev& cam,
-                       const RenderDev& rp, const LocalDev& lp, LpRange& range, LpCount& n) {
+                       const RenderDev& rp, const LocalDev& lp, LpRange& range, LpCount& n, V3& ray_o, V3& ray_d,
+                       V3& ray_inv) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     const uint32_t w = pl.u(U_SCUR, p);
@@ -195,7 +196,9 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
         primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
         n.paths++;
         s_cur++;
-        const bool enters = root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z));
+        const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        const bool enters = root_box_hit(sc, o, inv);
+        ray_o = o, ray_d = d, ray_inv = inv;  // for the query that follows at once (GEN is not short of registers)
         pl.set_v3(F_OX, p, o);
         pl.set_v3(F_DX, p, d);
         pl.set_v3(F_TX, p, mk(1.0, 1.0, 1.0));  // throughput 1, light 0 (lib.rs:522-523)
@@ -215,14 +218,15 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
 // Node's; the closest hit is the smallest accepted t, the first primitive in depth-first order on exact ties
 // (bvh.rs:62).  Gates and primitives are the same for every lane: the loops are wave-uniform and the records
 // arrive through the scalar cache.
-template <bool COMPACT, bool COUNT>
-RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, const SceneDev& sc, const LocalScene& ls,
-                         const SurfaceDev* s_surf, const uint4* s_prims, LpCount& n) {
-    // (the ray is read back from the pool: handed over in registers, it costs the phase before it more in spills
-    // than the six LDS reads cost here -- config 2 +1.5 %)
-    const V3 o = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
-    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    const bool in = valid && root_box_hit(sc, o, inv);
+// FROM_GEN: the ray, 1 / d and the root box's verdict come from lp_gen in registers (a lane is only `valid` here if its
+// ray enters the root box).  Behind SHADE_k the ray is read back from the pool: handed over in registers, it costs
+// that phase more in spills than the six LDS reads cost here (config 2 +1.5 %).
+template <bool COMPACT, bool COUNT, bool FROM_GEN>
+RR_DEV uint32_t lp_isect(const Pool& pl, bool valid, uint32_t p, V3 gen_o, V3 gen_d, V3 gen_inv, const SceneDev& sc,
+                         const LocalScene& ls, const SurfaceDev* s_surf, const uint4* s_prims, LpCount& n) {
+    const V3 o = FROM_GEN ? gen_o : pl.v3(F_OX, p), d = FROM_GEN ? gen_d : pl.v3(F_DX, p);
+    const V3 inv = FROM_GEN ? gen_inv : mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const bool in = FROM_GEN ? valid : (valid && root_box_hit(sc, o, inv));
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
     if (valid) n.rays++;
     if (COUNT && in) n.interior += ls.n_records;
@@ -429,10 +433,23 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
         if (COUNT) u_wave += 1, u_lane += valid ? 1 : 0;
 
         uint32_t ns = LP_DEAD;
-        if (ph == LP_GEN) {
-            ns = lp_gen(pl, valid, p, sc, cam, rp, lp, range, n);
-        } else if (ph == LP_BG) {
-            ns = lp_background(pl, valid, p, sc, lp, n);
+        // Phase executions chain where every lane goes the same way: a path that escapes (BG) has ended, so its slot
+        // takes its next sample (GEN) at once; a path that has just got a ray (GEN, SHADE_k) asks its BVH query in the
+        // same execution, on the lanes it is in -- the query is short and its loops are wave-uniform, so the lanes of
+        // ended paths idle through little.  What is saved is a phase execution's overhead (state bytes, list, field
+        // loads, counters): 2.64 -> 1.22 executions per query on config 2, 24.5 -> 22.0 ms.  LP_ISECT is only what
+        // lp_gen / lp_shade answer for "has a ray"; no path waits in it.
+        if (ph == LP_BG) (void)lp_background(pl, valid, p, sc, lp, n);
+        if (ph == LP_GEN || ph == LP_BG) {
+            V3 ro, rd, rinv;
+            ro = rd = rinv = mk(0.0, 0.0, 1.0);
+            ns = lp_gen(pl, valid, p, sc, cam, rp, lp, range, n, ro, rd, rinv);
+            if (COUNT) t_mid = lp_clock();
+            const bool q = valid && ns == LP_ISECT;
+            if (__ballot(q) != 0ull) {
+                const uint32_t nq = lp_isect<COMPACT, COUNT, true>(pl, q, p, ro, rd, rinv, sc, *s_ls, s_surf, s_prims, n);
+                if (q) ns = nq;
+            }
         } else {
             uint32_t hit_sid = 8u;
             ns = lp_shade<COMPACT>(pl, valid, p, (int)(ph - LP_SHADE0), cam, rp, lp, s_surf, s_prims, hit_sid);
@@ -444,24 +461,19 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
                 }
             }
         }
-        // ISECT is not a phase of its own: a path that has just got a ray (GEN, SHADE_k) asks its query in the same phase
-        // execution, on the lanes it is in.  The query is short and its loops are
-        // wave-uniform, so the lanes whose paths ended idle through little, and a query costs no phase execution (state
-        // bytes, list, field loads, counters): config 2 24.5 -> 22.9 ms, config 4 220 -> 204 ms as a separate phase's
-        // replacement.  LP_ISECT is only what lp_gen / lp_shade answer for "has a ray".
-        if (ph != LP_BG) {
+        if (ph >= LP_SHADE0) {
             if (COUNT) t_mid = lp_clock();
             const bool q = valid && ns == LP_ISECT;
             if (__ballot(q) != 0ull) {
-                const uint32_t nq = lp_isect<COMPACT, COUNT>(pl, q, p, sc, *s_ls, s_surf, s_prims, n);
+                const V3 none = mk(0.0, 0.0, 1.0);
+                const uint32_t nq = lp_isect<COMPACT, COUNT, false>(pl, q, p, none, none, none, sc, *s_ls, s_surf, s_prims, n);
                 if (q) ns = nq;
             }
         }
         if (valid) pl.state[p] = (uint8_t)ns;
         if (COUNT) {  // shader clock per phase kind: ISECT / SHADE_k / GEN and BG (Counters::*_ticks)
             const unsigned long long now = lp_clock();
-            if (ph != LP_BG) tk_isect += now - t_mid, n_isect++;  // the query behind a GEN or SHADE_k phase
-            else t_mid = now;
+            tk_isect += now - t_mid, n_isect++;  // the query at the end of every execution (t_mid: where it began)
             if (ph >= LP_SHADE0) tk_shade += t_mid - tk_last, n_shade++;
             else tk_other += t_mid - tk_last;
             if (ph == LP_GEN) tk_gen += t_mid - tk_last, n_gen++;
