@@ -1,0 +1,55 @@
+"""The register budget of the hot kernels, from the ISA hipcc emits for gfx950 (no GPU needed).
+
+Occupancy is decided by these numbers and nothing at run time says so when they move: 52 bytes of scratch in the
+traversal kernel's loop cost it 45 % (lists by octant), a 97th VGPR its fifth wave per SIMD."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rayrs_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# the flags of rayrs_amd/csrc/Makefile
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-S",
+         "--cuda-device-only"]
+
+
+def kernel_resources(source, tmp_path):
+    out = tmp_path / (source + ".s")
+    subprocess.run([HIPCC, *FLAGS, "-o", str(out), source], cwd=CSRC, check=True, capture_output=True)
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), re.S):
+        body = m.group(2)
+        res[m.group(1)] = (int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)),
+                           int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)))
+    return res
+
+
+def pick(res, *parts):
+    names = [n for n in res if all(p in n for p in parts)]
+    assert names, parts
+    return {n: res[n] for n in names}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_streaming_kernels_keep_their_occupancy(tmp_path):
+    res = kernel_resources("wavefront.hip", tmp_path)
+    # the timed traversal kernels (COUNT = false, one query per lane): five waves per SIMD, nothing in scratch
+    for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb").items():
+        assert vgpr <= 96 and scratch == 0, (name, vgpr, scratch)
+    # hit: two waves per SIMD (its look-ahead batch fills the file), miss: three; no scratch in either
+    for name, (vgpr, scratch) in pick(res, "wf_hit_kernel", "ELi2E").items():
+        assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
+    for name, (vgpr, scratch) in pick(res, "wf_miss_kernel").items():
+        assert vgpr <= 168 and scratch == 0, (name, vgpr, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_local_pool_kernel_fits_three_workgroups_per_cu(tmp_path):
+    res = kernel_resources("local_pool.hip", tmp_path)
+    for name, (vgpr, scratch) in pick(res, "lp_path_kernel").items():
+        assert vgpr <= 168, (name, vgpr)
+        if "ELb0EEE" in name.split("lp_path_kernelILb")[1][:8]:  # the timed build (COUNT = false): spills stay small
+            assert scratch <= 96, (name, scratch)
