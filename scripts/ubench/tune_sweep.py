@@ -1,7 +1,7 @@
 """Same-box sweep of rayrs_tuning settings on one scene built once (development aid).
 usage: python scripts/ubench/tune_sweep.py <config> <res> <spp> "k=v,k=v" "k=v" ...   ("" = defaults)
 Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render.
-TILE_RANKS=n in the environment renders rank 0's share of n (what one GPU of n does)."""
+TILE_RANKS=n in the environment renders rank 0's share of n (what one GPU of n does); CHUNK=n another sample chunk."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayrs_amd
@@ -14,7 +14,7 @@ cam_args = scenes.camera_for_resolution(cam_args, res, res)
 scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, procedural.make_hdri(1024, 512), device=0)
 cam = rayrs_amd.Camera(*cam_args)
 print("compact", scene.info()["compact"], "n_wide", scene.info()["n_wide"], flush=True)
-chunk = rayrs_amd.frame_sample_chunk(res, res, spp)
+chunk = int(os.environ.get("CHUNK", "0")) or rayrs_amd.frame_sample_chunk(res, res, spp)  # CHUNK=n: another sample chunk
 rayrs_amd.render(scene, cam, 4, mb, sample_chunk=0)  # warm
 ref = None
 for s in settings + settings[::-1]:
