@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            const ItemRegs ir = load_item(wf, slot);
+            // an IDLE slot has no item (wf_init_kernel: cursor word 0): nothing of its line needs reading
+            ItemRegs ir;
+            ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
+            ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;
             next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
