@@ -88,6 +88,15 @@ def useful_f64_ops(stats, info):
     return traversal_ops(stats, info) + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY
 
 
+def layout_conversion_ops(stats, info):
+    """The f32 -> f64 conversions of the compact layout among traversal_ops(): they exist because of the layout, not
+    because of the reference's arithmetic (24 per record, 9 per triangle)."""
+    if not info["compact"]:
+        return 0
+    return (stats["interior_visits"] * (OPS_RECORD_COMPACT - OPS_RECORD_F64)
+            + stats["tri_tests"] * (OPS_TRIANGLE_COMPACT - OPS_TRIANGLE_F64))
+
+
 def surface_units(objs):
     """Material unit of every (Material, Emission) row, in insertion order (what surface_hits is indexed by)."""
     from rayrs_amd.api import flatten_objects
@@ -203,6 +212,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
                     "rehearsing the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device of every rank (rehearsal only)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the framebuffer reduce also with one rank (under "
+                         "torch.distributed.run --nproc-per-node=1): the RCCL code path of an N-GPU run on a one-GPU box")
     ap.add_argument("--no-build", action="store_true",
                     help="do not run make: required under rocprofv3 (a profiled process must not spawn the compiler); "
                          "fails if the library is older than its sources")
@@ -224,7 +236,7 @@ def main():
     elif rank == 0:
         graft.build()
 
-    use_dist = world > 1
+    use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -343,10 +355,7 @@ def main():
             share_miss = paths_end_in_miss / max(cst["paths"], 1)
             # every kernel of the frame: its HIP-event time per step (on the render stream) and the useful lane
             # operations it is charged with; the roofline is the one with the largest share of the step
-            if st["local_pool"] == 2:   # rayrs_tuning.stream_pool (an experiment; not the default route)
-                kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info)},
-                        "sp_path_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_miss + ops_gen}}
-            elif st["local_pool"]:
+            if st["local_pool"]:
                 kern = {"lp_path_kernel": {"ms": sum(kernel_ms) / n_st,
                                            "ops": traversal_ops(cst, info) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
             else:
@@ -364,10 +373,14 @@ def main():
             avg_ms = dom_ms / launches
             ops = kern[dom]["ops"]
             achieved = ops / (dom_ms * 1e-3) / 1e12
+            # the same without the f32 -> f64 conversions of the compact layout (they are in every traversal figure)
+            conv = layout_conversion_ops(cst, info)
+            frac_no_conv = (ops - conv) / (dom_ms * 1e-3) / 1e12 / F64_PEAK_TOPS
             abytes = algorithmic_bytes(cst, info)
             prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
             pmc = find_pmc_profile(workload_key(W, H, chunk))
             traffic = fabric_gbs = valu_busy = valu_per_ray = pmc_src = None
+            step_fabric = None
             if pmc is not None:
                 pmc_src, pj = pmc
                 k = pj["kernels"].get(dom)
@@ -376,6 +389,19 @@ def main():
                     fabric_gbs = round(k["fabric_bytes"] / (dom_ms * 1e-3) / 1e9, 1)
                     valu_busy = k.get("valu_busy")
                     valu_per_ray = round(k["valu_wave_instructions"] / max(cst["rays"], 1), 2)
+                    step_fabric = sum(kk["fabric_bytes"] for kk in pj["kernels"].values())  # every kernel of ONE frame
+            # the whole step: every kernel's useful operations, and (from the PMC passes) all fabric traffic, over the
+            # step's wall time -- what the one-kernel-after-the-other schedule makes of the chip as a whole
+            step_ops = sum(k["ops"] for k in kern.values())
+            whole_step = {
+                "ms": round(step_ms, 2), "useful_ops": int(step_ops),
+                "achieved_Tlaneops": round(step_ops / (step_ms * 1e-3) / 1e12, 3),
+                "frac_of_fp64_issue_peak": round(step_ops / (step_ms * 1e-3) / 1e12 / F64_PEAK_TOPS, 4),
+                "fabric_bytes": None if step_fabric is None else int(step_fabric),
+                "fabric_GBps": None if step_fabric is None else round(step_fabric / (step_ms * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": None if step_fabric is None else round(step_fabric / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel_ms_sum": round(sum(k["ms"] for k in kern.values()), 2),
+            }
             if st["local_pool"] == 1:
                 util = {"all phases": round(cst["step_lane"] / max(cst["step_wave"], 1), 3)}
                 tk = max(cst["interior_ticks"] + cst["leaf_ticks"] + cst["refill_ticks"], 1)
@@ -386,14 +412,20 @@ def main():
                         "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)}
             roofline = {
                 "bound": "fp64_valu", "achieved": round(achieved, 3), "peak": round(F64_PEAK_TOPS, 2),
-                "unit": "TFLOP/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
+                "unit": "Tlane-op/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
+                "frac_without_layout_conversions": round(frac_no_conv, 4),
+                "step": whole_step,
                 "kernel": dom, "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
                 "kernel_share_of_step": round(dom_ms / step_ms, 3),
-                "definition": "the kernel with the largest share of the step: useful lane operations it is charged with "
-                              "(traversal: record / primitive / ray counters x the f64 operations per unit counted in "
-                              "device_path.h; shading: closest hits per material, escaped paths and samples x the vector "
-                              "instructions of that unit compiled alone, profiles/r03_op_model.json) / its HIP-event time / "
-                              "(256 CU x 4 SIMD x 16 lanes x 2.4 GHz); no FMA credit: the reference's arithmetic is unfused",
+                "definition": "the kernel with the largest share of the step: useful lane operations it is charged with / its "
+                              "HIP-event time / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz = vector issue rate of f64-width "
+                              "instructions; no FMA credit: the reference's arithmetic is unfused).  Traversal units (record, "
+                              "primitive, ray) are f64 operations counted in device_path.h (plus the compact layout's f32 -> "
+                              "f64 conversions: frac_without_layout_conversions leaves them out).  Shading units (material "
+                              "arms, background, new sample) are VALU lane-INSTRUCTIONS of the unit compiled alone "
+                              "(profiles/r03_op_model.json): they include integer RNG hashing, moves and selects and both "
+                              "sides of divergent branches, so a shading kernel's frac is an instruction-issue share, not an "
+                              "FP64 FLOP fraction, and is not comparable with the traversal kernel's",
                 "kernels": kern,
                 "useful_ops_per_launch": int(ops / launches), "useful_ops_per_ray": round(ops / max(cst["rays"], 1), 1),
                 "records_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
@@ -423,8 +455,9 @@ def main():
     if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_secondary
             and not args.no_roofline):
         close = scenes.camera_for_resolution(scenes.MESH_CLOSE_CAM, W0, H0)
-        sec = measure(close, 1, 1, True)
+        sec = measure(close, 3, 1, True)
         secondary = {"workload": "the same scene and settings from a camera the mesh fills (scenes.MESH_CLOSE_CAM)",
+                     "steps": 3, "warmup": 1,
                      "value": round(sec["value"], 2), "unit": "Mray/s", "ms_per_step": round(sec["ms_per_step"], 2),
                      "rays_per_step": sec["rays_per_step"], "ray_shares": sec["shares"],
                      "records_per_ray": sec["roofline"]["records_per_ray"],
@@ -459,6 +492,11 @@ def main():
                                   f"{mid - rows // 2}..{mid + rows // 2} of {H} at {cspp} spp: {cst2['rays']} rays in "
                                   f"{cst2['seconds']:.2f} s (oracle BVH build {obuild:.1f} s not timed)"}
 
+    collective = None
+    if use_dist:
+        rccl = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+        collective = {"backend": args.backend, "world": world, "forced_single_rank": bool(args.force_dist and world == 1),
+                      "librccl_mapped": rccl[0] if rccl else None}
     if rank == 0:
         n_prims = info["n_prims"]
         what = {1: "floor + 1 diffuse sphere", 2: "floor + 7 Cook-Torrance metallic spheres",
@@ -491,7 +529,7 @@ def main():
                 "layout": "compact f32 records" if info["compact"] else "f64 records",
                 "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"], "scene_bytes": info["device_bytes"],
                 "scene_build_s": round(build_s, 2), "source_hash": source_hash(),
-                "workload_key": workload_key(W, H, chunk),
+                "workload_key": workload_key(W, H, chunk), "collective": collective,
             },
             "rays_per_step": main_run["rays_per_step"],
             "framebuffer_checksum": main_run["checksum"],

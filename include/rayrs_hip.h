@@ -208,6 +208,15 @@ typedef struct {
     uint32_t tile_rank, tile_ranks;
     uint32_t out_format;   /* RAYRS_OUT_F32: f32x3 (image.rs:224-229), RAYRS_OUT_F64: f64x3 */
     uint32_t count_work;   /* 1 = also count traversal work (slower; for the roofline figure) */
+    /* Closest-hit culling.  BvhTree::intersect visits every Node whose box the ray enters and never compares a box
+     * with the closest hit so far (bvh.rs:391-415).  0 (default): the walk skips a box entered beyond
+     * best_t * (1 + 2^-10) -- the reference's answer unless a primitive's COMPUTED t lies more than that in front
+     * of a box around it, which Moeller-Trumbore's t does for rays within about 10^-7 rad of a triangle's plane
+     * (measured: one ray in 10^7 of that family returns another primitive; none on any rendered frame;
+     * tests/test_walk_tree.py pins a failing ray).  1: nothing is culled -- the reference's visit set by
+     * construction, bit-identical closest hits for every ray, at several times the traversal cost.  The
+     * local-pool route never culls. */
+    uint32_t exact_traversal;
 } rayrs_render_params;
 
 typedef struct {
@@ -242,10 +251,8 @@ typedef struct {
     uint64_t direct_rays;
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
-    uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool), 2 = by the
-                               traversal kernel + the stream-pool kernel (rayrs_tuning.stream_pool; its time is hit_ms) */
+    uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
     uint32_t pad;
-    uint64_t shade_wave, shade_lane; /* stream-pool kernel, count_work only: phase executions x 64, lanes active in them */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:
@@ -286,42 +293,16 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats);
 int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camera* camera,
                        const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats);
 
-/* ---- tuning: how the kernels are scheduled, never what they compute.  0 = the built-in default.
- * (Round 1 read these from RAYRS_* environment variables; a library must not.) */
+/* ---- tuning: the two scheduling choices a caller may legitimately make.  0 = the built-in default.  Neither changes
+ * what is computed.  (Round 1 read such settings from RAYRS_* environment variables; a library must not.  The kernels'
+ * development knobs -- thresholds, LDS budgets, test switches -- are not part of this boundary: rayrs_amd/csrc/rayrs_lab.h.) */
 typedef struct {
-    uint32_t pool_slots;    /* paths in flight (default: min(items, 112 Mi, samples / 12)).  On the local-pool route, which has
-                               no pool in HBM: 8..4096 = items a wave takes from the counter at a time, >= 65536 = items
-                               per launch segment (default 2^27; each segment is resolved behind its launch) */
-    uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
-    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (32) */
-    uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
-    uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
-    uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
-                               0xffffffff = none */
-    uint32_t pipelines;     /* 1 or 2: halves of the pool on two streams, one's hit/miss kernels beside the
-                               other's traversal kernel (default: see rayrs_render_launch in abi.cpp) */
-    uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
-    uint32_t eager_light;   /* 1 = the hit and miss kernels request a path's entry of the light side array together
-                               with its slot also where no surface emits (they do anyway where one does) */
+    uint32_t pool_slots;    /* streaming route: paths in flight = slots of the pool in HBM, 128 + 33 bytes each
+                               (default: min(items, 112 Mi, samples / 12)); ignored on the local-pool route */
     uint32_t local_pool;    /* a scene whose walk tree is at most one record (n_wide <= 1: the reference's sphere
                                scenes) is rendered by ONE launch that keeps every path in LDS from its first ray
                                to its last (local_pool.hip) instead of three launches per bounce over a pool in
                                HBM; same arithmetic, same bits.  0 = do so, 1 = never (the streaming kernels) */
-    /* The next three are experiments of round 3, measured slower on the headline frame (DESIGN.md
-     * section 4) and kept selectable because they are tested bit-identical: */
-    uint32_t leaf_group;    /* traversal: 0 = a leaf phase tests the lane's whole group of 1..4 primitives, 1 = ONE
-                               primitive per lane and phase (a lane with a one-primitive group is back in interior work
-                               after one test; +12 % traversal time: a group's records are requested together) */
-    uint32_t hit_blocks_per_cu; /* hit kernel: 0 or 2 = built for two workgroups per CU (256 registers, the next batch
-                               requested while this one is computed), 3 = for three, without the look-ahead */
-    uint32_t trav_queries;  /* traversal: BVH queries a lane holds at a time, 1 or 2 (a lane with two takes part in a
-                               wave's interior or leaf step with whichever of them stands in that phase; three
-                               workgroups per CU instead of five: +26 % traversal time); 3 = two, built for four */
-    uint32_t stream_pool;   /* scenes with a deeper walk tree, an experiment of round 3 (bit-identical, slower: DESIGN.md
-                               section 4): 1 = everything of a path except its deep BVH walks runs in ONE kernel that keeps
-                               the path in LDS between two walks (stream_pool.hip: two launches per round, a path crosses
-                               the pool in HBM once per DEEP query; traversal -35 %, shading x1.9), 0 = the hit and miss
-                               kernels (three launches per round, once per query) */
 } rayrs_tuning;
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
@@ -342,8 +323,9 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);
 int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out);
 int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
                    uint64_t n, uint64_t* out_bits);
-/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss). */
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, double* t, int64_t* object);
+/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  exact: rayrs_render_params.exact_traversal */
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
+                         int64_t* object);
 /* Material::evaluate for n (normal, view, key) tuples with one material:
  * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */
 int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
@@ -351,9 +333,6 @@ int rayrs_test_material(int device, const rayrs_material* mat, const double* nor
                         uint32_t* draws);
 /* Scene::background for n directions. */
 int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
-/* Development aid: shader-clock ticks (out[0..4]) and executions (out[5..9]) of the stream-pool kernel's phase kinds
- * -- import, gen, isect, bg, shade -- in the last count_work render of this scene. */
-int rayrs_debug_counters(rayrs_scene* scene, uint64_t out[10]);
 
 /* ---- file formats either side of the path (host only) ---- */
 

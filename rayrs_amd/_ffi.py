@@ -22,7 +22,7 @@ SYMBOLS = [
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout",
     "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
-    "rayrs_test_background", "rayrs_debug_counters",
+    "rayrs_test_background",
     "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
     "rayrs_hdr_load", "rayrs_hdr_save", "rayrs_image_to_bytes", "rayrs_ppm_save", "rayrs_png_save",
 ]
@@ -57,7 +57,7 @@ class SceneInfo(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("max_bounces", C.c_uint32), ("seed", C.c_uint64),
                 ("sample_chunk", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_ranks", C.c_uint32),
-                ("out_format", C.c_uint32), ("count_work", C.c_uint32)]
+                ("out_format", C.c_uint32), ("count_work", C.c_uint32), ("exact_traversal", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -69,7 +69,7 @@ class RenderStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
-                ("local_pool", C.c_uint32), ("pad", C.c_uint32), ("shade_wave", C.c_uint64), ("shade_lane", C.c_uint64)]
+                ("local_pool", C.c_uint32), ("pad", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -78,12 +78,16 @@ class RenderStats(C.Structure):
 
 
 class Tuning(C.Structure):
-    _fields_ = [("pool_slots", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("static_pct", C.c_uint32), ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32),
-                ("pipelines", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32), ("eager_light", C.c_uint32),
-                ("local_pool", C.c_uint32), ("leaf_group", C.c_uint32),
-                ("hit_blocks_per_cu", C.c_uint32), ("trav_queries", C.c_uint32),
-                ("stream_pool", C.c_uint32)]
+    _fields_ = [("pool_slots", C.c_uint32), ("local_pool", C.c_uint32)]
+
+
+class LabTuning(C.Structure):
+    """rayrs_amd/csrc/rayrs_lab.h: the kernels' development knobs -- tests/ and scripts/ubench/ only, not part of the
+    boundary (include/rayrs_hip.h)."""
+    _fields_ = [("refill_min", C.c_uint32), ("leaf_min", C.c_uint32), ("static_pct", C.c_uint32),
+                ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32),
+                ("eager_light", C.c_uint32), ("local_reserve", C.c_uint32), ("local_segment_items", C.c_uint32),
+                ("force_rccl", C.c_uint32), ("streams", C.c_uint32), ("band_rows", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in
@@ -130,6 +134,8 @@ def lib():
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    L.rayrs_lab_set.argtypes = [vp, C.POINTER(LabTuning)]  # private: rayrs_amd/csrc/rayrs_lab.h
+    L.rayrs_lab_set.restype = C.c_int
     L.rayrs_frame_sample_chunk.argtypes = [C.c_uint32] * 4
     L.rayrs_frame_sample_chunk.restype = C.c_uint32
     L.rayrs_abi_layout.argtypes = [vp, C.c_uint32]
@@ -143,10 +149,9 @@ def lib():
     L.rayrs_render_finish.argtypes = [vp, C.POINTER(RenderStats)]
     L.rayrs_test_math.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp]
     L.rayrs_test_rng.argtypes = [C.c_int, C.c_uint64, vp, vp, vp, C.c_uint64, vp]
-    L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, vp, vp]
     L.rayrs_test_material.argtypes = [C.c_int, mp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     L.rayrs_test_background.argtypes = [vp, vp, C.c_uint64, vp]
-    L.rayrs_debug_counters.argtypes = [vp, vp]
     L.rayrs_io_last_error.restype = C.c_char_p
     L.rayrs_buffer_free.argtypes = [vp]
     L.rayrs_buffer_free.restype = None

@@ -304,14 +304,23 @@ class Scene:
         return Scene._from_handle(self._L, h, device)
 
     def set_tuning(self, **kw):
-        """Scheduling knobs of the kernels (include/rayrs_hip.h rayrs_tuning); 0 = default.  They
-        never change what is computed."""
+        """The two scheduling choices of include/rayrs_hip.h rayrs_tuning (pool_slots, local_pool); 0 = default.
+        They never change what is computed."""
         t = _ffi.Tuning()
         for k, v in kw.items():
             if k not in dict(_ffi.Tuning._fields_):
                 raise ValueError(f"unknown tuning field {k}")
             setattr(t, k, int(v))
         _ffi.check(self._L.rayrs_scene_set_tuning(self._h, C.byref(t)), "rayrs_scene_set_tuning")
+
+    def lab_set(self, **kw):
+        """The kernels' development knobs (rayrs_amd/csrc/rayrs_lab.h): for tests and scripts/ubench only."""
+        t = _ffi.LabTuning()
+        for k, v in kw.items():
+            if k not in dict(_ffi.LabTuning._fields_):
+                raise ValueError(f"unknown lab field {k}")
+            setattr(t, k, int(v))
+        _ffi.check(self._L.rayrs_lab_set(self._h, C.byref(t)), "rayrs_lab_set")
 
     def info(self) -> dict:
         i = _ffi.SceneInfo()
@@ -358,17 +367,19 @@ def frame_sample_chunk(width: int, height: int, spp: int, requested: int = 4) ->
 
 
 def make_params(spp, max_bounces=50, seed=0x5EED, sample_chunk=0, tile_rank=0, tile_ranks=1, out_f64=False,
-                count_work=False) -> _ffi.RenderParams:
+                count_work=False, exact_traversal=False) -> _ffi.RenderParams:
     p = _ffi.RenderParams()
     p.spp, p.max_bounces, p.seed = int(spp), int(max_bounces), int(seed)
     p.sample_chunk, p.tile_rank, p.tile_ranks = int(sample_chunk), int(tile_rank), int(tile_ranks)
     p.out_format = 1 if out_f64 else 0
     p.count_work = 1 if count_work else 0
+    p.exact_traversal = 1 if exact_traversal else 0
     return p
 
 
 def render(scene: Scene, camera: Camera, spp: int, max_bounces: int = 50, seed: int = 0x5EED, sample_chunk: int = 0,
-           tile_rank: int = 0, tile_ranks: int = 1, out_f64: bool = False, count_work: bool = False, out=None):
+           tile_rank: int = 0, tile_ranks: int = 1, out_f64: bool = False, count_work: bool = False, out=None,
+           exact_traversal: bool = False):
     """The block loop of rayrs/src/main.rs:57-101 on the GPU.
 
     Returns (image, stats): image is (y_pixels, x_pixels, 3), f32 (what
@@ -382,7 +393,7 @@ def render(scene: Scene, camera: Camera, spp: int, max_bounces: int = 50, seed: 
     if out is None:
         out = np.zeros((H, W, 3), dtype=dt)
     assert out.shape == (H, W, 3) and out.dtype == dt and out.flags.c_contiguous
-    p = make_params(spp, max_bounces, seed, sample_chunk, tile_rank, tile_ranks, out_f64, count_work)
+    p = make_params(spp, max_bounces, seed, sample_chunk, tile_rank, tile_ranks, out_f64, count_work, exact_traversal)
     st = _ffi.RenderStats()
     _ffi.check(L.rayrs_render(scene._h, C.byref(camera.desc), C.byref(p), out.ctypes.data, C.byref(st)),
                "rayrs_render")

@@ -14,7 +14,7 @@
 #include "../../include/rayrs_hip.h"
 #include "kernels.h"
 #include "local_pool.h"
-#include "stream_pool.h"
+#include "rayrs_lab.h"
 #include "scene_host.hpp"
 #include "scene_internal.hpp"
 #include "wavefront.h"
@@ -23,6 +23,7 @@ using namespace rayrs;
 
 namespace {
 thread_local std::string g_last_error;
+constexpr double TRAV_CULL_MARGIN_HOST = 1.0 + 0x1p-10;  // device_path.h TRAV_CULL_MARGIN (a device-only header)
 constexpr uint32_t TRAV_STACK_LDS = 12;
 constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 }  // namespace
@@ -199,7 +200,8 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_partial) (void)hipFree(s->d_partial);
-    for (auto& pl : s->pipe) {
+    {
+        rayrs_scene::Pool& pl = s->pool;
         if (pl.block) (void)hipFree(pl.block);
         if (pl.d_wave_items) (void)hipFree(pl.d_wave_items);
         if (pl.d_stack_spill) (void)hipFree(pl.d_stack_spill);
@@ -207,7 +209,7 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
         if (pl.h_live) (void)hipHostFree(pl.h_live);
         for (auto& e : pl.ev_batch)
             if (e) (void)hipEventDestroy(e);
-        for (auto& e : pl.ev_trav)
+        for (auto& e : pl.ev_round)
             if (e) (void)hipEventDestroy(e);
     }
     if (s->d_next_item) (void)hipFree(s->d_next_item);
@@ -215,9 +217,6 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
     if (s->d_local_light) (void)hipFree(s->d_local_light);
     if (s->d_local_items) (void)hipFree(s->d_local_items);
-    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
-    for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_stagger})
-        if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
 }
@@ -236,14 +235,14 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;
     const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
-    uint32_t want = s->tuning.stack_lds ? s->tuning.stack_lds : TRAV_STACK_LDS;
+    uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
     s->stack_lds = want < depth ? want : depth;
     const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
     uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
-    if (s->tuning.hot_records == 0xffffffffu) hot = 0;
-    else if (s->tuning.hot_records) hot = s->tuning.hot_records < WIDE_FRONT ? s->tuning.hot_records : WIDE_FRONT;
+    if (s->lab.hot_records == 0xffffffffu) hot = 0;
+    else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
     s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
-    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, s->tuning.trav_queries >= 2u ? s->tuning.trav_queries - 1u : 0u, &s->blocks_per_cu));
+    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
     return RAYRS_OK;
 }
@@ -284,31 +283,6 @@ static void scene_configure_local(rayrs_scene* s) {
     s->local_ok = true;
 }
 
-// The walk tree's root record as kernel arguments of stream_pool.hip (RootRecord): its interior slots send a ray
-// to the traversal kernel, its leaf groups are tested where the ray is made.
-static void scene_configure_stream(rayrs_scene* s) {
-    const FlatScene& f = s->flat;
-    RootRecord& r = s->root_record;
-    std::memset(&r, 0, sizeof(r));
-    s->stream_ok = false;
-    if (f.n_wide() < 1 || (f.wide_root_ref >> 30) != REF_INTERIOR) return;
-    const uint32_t rec = f.wide_root_ref & 0x3fffffffu;
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t ref = f.wide_ref[(size_t)rec * 4 + k];
-        r.kind[k] = ref >> 30;
-        for (int i = 0; i < 6; i++) r.box[k][i] = f.wide_box[((size_t)rec * 4 + k) * 6 + i];
-        if (r.kind[k] == REF_RANGE) {
-            r.first[k] = (ref & 0x3fffffffu) >> 2;
-            r.count[k] = (ref & 3u) + 1u;
-            r.lds_first[k] = r.n_lds_prims;
-            r.n_lds_prims += r.count[k];
-        } else if (r.kind[k] != REF_INTERIOR && r.kind[k] != REF_NONE) {
-            return;  // (the walk tree has no other slot kinds)
-        }
-    }
-    s->stream_ok = r.n_lds_prims <= SP_ROOT_PRIMS;
-}
-
 extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     hipDeviceProp_t prop;
@@ -332,21 +306,21 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         const int st = scene_configure_traversal(s);
         if (st != RAYRS_OK) return st;
     }
-    for (auto& pl : s->pipe) {
+    {
+        rayrs_scene::Pool& pl = s->pool;
         HIP_TRY(hipMalloc((void**)&pl.wf.ctl, sizeof(WfCtl)));
         HIP_TRY(hipHostMalloc((void**)&pl.h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
         for (auto& e : pl.ev_batch) HIP_TRY(hipEventCreate(&e));
     }
-    HIP_TRY(hipMalloc((void**)&s->d_next_item, sizeof(unsigned long long)));
-    if (s->stream_ok) HIP_TRY(sp_configure());
+    HIP_TRY(hipMalloc((void**)&s->d_next_item, MAX_STREAMS * sizeof(unsigned long long)));
     if (s->local_ok) {
         HIP_TRY(lp_configure());
+        // (from about 13 primitives and surface rows up three workgroups' LDS no longer fit a CU: ask, do not assume)
+        HIP_TRY(lp_occupancy(s->flat.compact, s->local.n_prims, (uint32_t)s->surfaces.size(), &s->local_blocks_per_cu));
+        if (s->local_blocks_per_cu < 1) s->local_blocks_per_cu = 1;
+        if (s->local_blocks_per_cu > (int)LP_WPS) s->local_blocks_per_cu = (int)LP_WPS;
         HIP_TRY(hipMalloc((void**)&s->d_local_items, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long)));
     }
-    HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_stagger, hipEventDisableTiming));
     return RAYRS_OK;
 }
 
@@ -369,7 +343,6 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     s->n_objects = objs->list.objs.size();
     s->device = device;
     scene_configure_local(s.get());
-    scene_configure_stream(s.get());
     if (device >= 0) {
         st = scene_upload(s.get());
         if (st != RAYRS_OK) {
@@ -432,10 +405,9 @@ int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scen
         s->surfaces = scene->surfaces;
         s->n_objects = scene->n_objects;
         s->tuning = scene->tuning;
+        s->lab = scene->lab;
         s->device = device;
         scene_configure_local(s.get());
-        scene_configure_stream(s.get());
-    scene_configure_stream(s.get());
         const int st = scene_upload(s.get());
         if (st != RAYRS_OK) {
             scene_free_device(s.get());
@@ -448,12 +420,7 @@ int rayrs_scene_clone_to_device(const rayrs_scene* scene, int device, rayrs_scen
 
 int rayrs_scene_device(const rayrs_scene* scene) { return scene ? scene->device : -1; }
 
-int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
-    if (!scene || !tuning) return RAYRS_INVALID_ARG;
-    if (tuning->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
-    if (tuning->static_pct > 100u || tuning->refill_min > 64u || tuning->leaf_min > 64u || tuning->pipelines > 2u ||
-        tuning->local_pool > 1u || tuning->leaf_group > 1u || tuning->trav_queries > 3u || tuning->stream_pool > 1u || (tuning->hit_blocks_per_cu != 0u && tuning->hit_blocks_per_cu != 2u && tuning->hit_blocks_per_cu != 3u))
-        return RAYRS_INVALID_ARG;
+static int scene_quiesce(rayrs_scene* scene) {  // settings change between renders, never under one
     if (scene->device >= 0) {
         HIP_TRY(hipSetDevice(scene->device));
         if (scene->pending && scene->last_stream) {
@@ -461,7 +428,31 @@ int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
             scene->pending = false;
         }
     }
+    return RAYRS_OK;
+}
+
+int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
+    if (!scene || !tuning) return RAYRS_INVALID_ARG;
+    if (tuning->local_pool > 1u) return RAYRS_INVALID_ARG;
+    const int st = scene_quiesce(scene);
+    if (st != RAYRS_OK) return st;
     scene->tuning = *tuning;
+    return RAYRS_OK;
+}
+
+// rayrs_lab.h: the kernels' development knobs (tests/ and scripts/ubench/ only)
+int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
+    if (!scene || !lab) return RAYRS_INVALID_ARG;
+    if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u)
+        return RAYRS_INVALID_ARG;
+    if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
+    if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
+    if (lab->streams != 0u && lab->streams != 1u && lab->streams != 2u && lab->streams != 4u && lab->streams != 8u)
+        return RAYRS_INVALID_ARG;
+    const int st = scene_quiesce(scene);
+    if (st != RAYRS_OK) return st;
+    scene->lab = *lab;
     if (scene->device >= 0) return scene_configure_traversal(scene);
     return RAYRS_OK;
 }
@@ -498,12 +489,13 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, root_box), RAYRS_FIELD(rayrs_scene_info_t, build_seconds);
     RAYRS_FIELD(rayrs_scene_info_t, n_wide), RAYRS_FIELD(rayrs_scene_info_t, wide_root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, local_pool);
-    RAYRS_STRUCT(rayrs_render_params, 8);
+    RAYRS_STRUCT(rayrs_render_params, 9);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_STRUCT(rayrs_render_stats, 28);
+    RAYRS_FIELD(rayrs_render_params, exact_traversal);
+    RAYRS_STRUCT(rayrs_render_stats, 26);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -517,14 +509,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, pad);
-    RAYRS_FIELD(rayrs_render_stats, shade_wave), RAYRS_FIELD(rayrs_render_stats, shade_lane);
-    RAYRS_STRUCT(rayrs_tuning, 14);
-    RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, refill_min), RAYRS_FIELD(rayrs_tuning, leaf_min);
-    RAYRS_FIELD(rayrs_tuning, static_pct), RAYRS_FIELD(rayrs_tuning, stack_lds), RAYRS_FIELD(rayrs_tuning, hot_records);
-    RAYRS_FIELD(rayrs_tuning, pipelines), RAYRS_FIELD(rayrs_tuning, trav_blocks_per_cu);
-    RAYRS_FIELD(rayrs_tuning, eager_light), RAYRS_FIELD(rayrs_tuning, local_pool);
-    RAYRS_FIELD(rayrs_tuning, leaf_group), RAYRS_FIELD(rayrs_tuning, hit_blocks_per_cu);
-    RAYRS_FIELD(rayrs_tuning, trav_queries), RAYRS_FIELD(rayrs_tuning, stream_pool);
+    RAYRS_STRUCT(rayrs_tuning, 2);
+    RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
 #undef RAYRS_STRUCT
 #undef RAYRS_FIELD
     for (uint32_t i = 0; i < cap && i < t.size(); i++) out[i] = t[i];
@@ -540,7 +526,7 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 
 // ------------------------------------------------------------------ render
 
-static SceneDev make_scene_dev(const rayrs_scene* s) {
+static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
     sc.nodes = s->d_nodes;
@@ -557,6 +543,7 @@ static SceneDev make_scene_dev(const rayrs_scene* s) {
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
+    sc.cull_margin = exact ? (double)INFINITY : TRAV_CULL_MARGIN_HOST;
     return sc;
 }
 
@@ -577,6 +564,30 @@ static CameraDev make_camera_dev(const rayrs_camera* c) {
     return cam;
 }
 
+// The order in which a rank's tiles become items (layout.h TileOrder): bands of `rows` grid rows, column by column.
+static TileOrder make_tile_order(uint32_t n_local, uint32_t tiles_x, uint32_t tile_ranks, uint32_t rows_wanted) {
+    TileOrder to;
+    std::memset(&to, 0, sizeof(to));
+    if (rows_wanted == 0u || n_local == 0u) return to;  // row-major
+    // the local tiles as a grid: when the ranks divide a row of tiles a grid row IS an image row of this rank's tiles;
+    // otherwise a grid row is tiles_x consecutive local tiles (tile_ranks image rows' worth)
+    to.width = tiles_x % tile_ranks == 0u ? tiles_x / tile_ranks : tiles_x;
+    const uint32_t grid_rows = (n_local + to.width - 1u) / to.width;
+    to.ragged = n_local % to.width;
+    to.rows = rows_wanted < grid_rows ? rows_wanted : grid_rows;
+    const uint32_t n_bands = (grid_rows + to.rows - 1u) / to.rows;
+    to.band_cells = to.rows * to.width;
+    to.last_base = (n_bands - 1u) * to.rows;
+    to.last_first = to.last_base * to.width;
+    to.last_rows = grid_rows - to.last_base;
+    to.last_cut = to.ragged ? to.ragged * to.last_rows : to.last_rows * to.width;
+    to.inv_band_cells = 1.0 / (double)to.band_cells;
+    to.inv_rows = 1.0 / (double)to.rows;
+    to.inv_last_rows = 1.0 / (double)to.last_rows;
+    to.inv_last_rows_m1 = to.last_rows > 1u ? 1.0 / (double)(to.last_rows - 1u) : 1.0;
+    return to;
+}
+
 int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
                         void* out_device, void* hip_stream) {
     RAYRS_GUARDED({
@@ -590,12 +601,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;     // a slot's sample cursor has 30 bits
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
+    if (params->exact_traversal > 1u) return RAYRS_INVALID_ARG;
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (scene->pending) {  // one render in flight per scene: its counters and partial sums are shared
         HIP_TRY(hipStreamSynchronize(scene->last_stream));
         scene->pending = false;
     }
+    const rayrs_lab_tuning& lab = scene->lab;
 
     RenderDev rp;
     std::memset(&rp, 0, sizeof(rp));
@@ -615,15 +628,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_nchunks = 1.0 / (double)rp.nchunks;
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
-    rp.refill_min = scene->tuning.refill_min ? scene->tuning.refill_min : 52u;
-    rp.leaf_min = scene->tuning.leaf_min ? scene->tuning.leaf_min : 32u;
-    rp.leaf_single = scene->tuning.leaf_group == 1u ? 1u : 0u;
-    rp.hit_wps3 = scene->tuning.hit_blocks_per_cu == 3u ? 1u : 0u;  // bit 0: primary rays (next_sample), bit 1: bounced rays (hit kernel)
-    rp.trav_two = scene->tuning.trav_queries >= 2u ? scene->tuning.trav_queries - 1u : 0u;
+    rp.refill_min = lab.refill_min ? lab.refill_min : 52u;
+    rp.leaf_min = lab.leaf_min ? lab.leaf_min : 32u;
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;
     rp.counters = scene->d_counters;
+    rp.n_streams = 1;
+    rp.stream_end[0] = rp.total_items;
 
     // Item sums: 24 bytes per (pixel, chunk) item, added per pixel in chunk order by the resolve kernel.  The streaming
     // kernels finish items in no particular order, so the array covers the frame.  The local-pool route renders the frame
@@ -631,9 +643,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // worth is all it needs (config 4: 3.2 GB instead of 25.8).
     const bool use_local = scene->local_ok && scene->tuning.local_pool != 1u;
     const uint64_t tile_items = (uint64_t)rp.nchunks * 64u;
-    // (rayrs_tuning.pool_slots >= 65536 on this route: items per segment, for the tests of the segment boundaries)
-    const uint64_t seg_want = use_local && scene->tuning.pool_slots >= 65536u ? scene->tuning.pool_slots : LOCAL_SEGMENT_ITEMS;
-    const uint64_t seg_tiles = seg_want / tile_items > 0 ? seg_want / tile_items : 1;
+    uint64_t seg_want = lab.local_segment_items ? lab.local_segment_items : LOCAL_SEGMENT_ITEMS;
+    // (a frame stays within LOCAL_MAX_SEGMENTS launches: larger segments rather than a refused frame)
+    if ((rp.total_items + seg_want - 1) / seg_want > LOCAL_MAX_SEGMENTS) seg_want = (rp.total_items + LOCAL_MAX_SEGMENTS - 1) / LOCAL_MAX_SEGMENTS;
+    const uint64_t seg_tiles = (seg_want + tile_items - 1) / tile_items > 0 ? (seg_want + tile_items - 1) / tile_items : 1;
     const uint64_t seg_items = seg_tiles * tile_items;
     const uint64_t partial_need = use_local && seg_items < rp.total_items ? seg_items : rp.total_items;
     if (use_local && seg_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;  // (one tile's chunks alone: spp beyond 2^27)
@@ -647,7 +660,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.partial = scene->d_partial;
     rp.partial_item0 = 0;
 
-    const SceneDev sc = make_scene_dev(scene);
+    const SceneDev sc = make_scene_dev(scene, params->exact_traversal != 0u);
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
@@ -672,42 +685,26 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (np64 > rp.total_items) np64 = rp.total_items;
     const uint64_t live_total = np64;
 
-    // ---- one pipeline, or two halves of the pool on two streams (scene_internal.hpp Pipeline).  With two,
-    // the second starts its first traversal when the first pipeline's has finished, and from then on each
-    // runs its rounds at its own pace: while one is in its hit and miss kernels (memory bound, the vector
-    // ALUs mostly idle) the other is in its traversal kernel (ALU bound, a third of the memory traffic).
-    // paths resident in LDS between two deep walks (stream_pool.hip): one pipeline, its own grid
-    const bool use_stream = !use_local && scene->stream_ok && scene->tuning.stream_pool == 1u &&
-                            scene->tuning.pipelines != 2u;  // (two pipelines are a layout of the three streaming kernels)
-    const uint32_t sp_blocks = (uint32_t)scene->cu_count * (uint32_t)SP_WPS;
-    uint32_t n_pipes = scene->tuning.pipelines == 2u ? 2u : 1u;
-    if (live_total < 2ull * 65536ull || use_stream) n_pipes = 1;
-    scene->n_pipes = n_pipes;
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    if (use_local && (rp.total_items + seg_items - 1) / seg_items > LOCAL_MAX_SEGMENTS) return RAYRS_UNSUPPORTED;
     uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
-    if (scene->tuning.trav_blocks_per_cu && scene->tuning.trav_blocks_per_cu < trav_bpc) trav_bpc = scene->tuning.trav_blocks_per_cu;
+    if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
-    uint32_t static_pct = scene->tuning.static_pct ? scene->tuning.static_pct : 50u;
+    uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;
     if (static_pct > 100) static_pct = 100;
 
     // A path's light lives in a side array and only while it is not +0 (wavefront.h PathSlot).  Where a surface
     // emits, paths do get light, and the hit and miss kernels request the side array's entry together with the
     // slot instead of after it.
-    bool eager_light = scene->tuning.eager_light != 0u;
+    bool eager_light = lab.eager_light != 0u;
     for (const SurfaceDev& sf : scene->surfaces)
         if (sf.emit[0] != 0.0 || sf.emit[1] != 0.0 || sf.emit[2] != 0.0) eager_light = true;
     constexpr size_t slot_bytes = sizeof(PathSlot) + 4 * sizeof(double);  // slot + its entry of the light array
-    hipStream_t streams[2] = {stream, scene->aux_stream};
-    WfDev wfs[2];
-    RenderDev rps[2];
-    uint32_t lives[2], flat_blocks[2];
-    for (uint32_t p = 0; p < n_pipes && !use_local; p++) {  // (the local-pool route keeps its paths in LDS)
-        rayrs_scene::Pipeline& pl = scene->pipe[p];
-        const uint64_t live64 = live_total / n_pipes + (p < live_total % n_pipes ? 1u : 0u);
-        const uint32_t np = (uint32_t)((live64 + 1023ull) & ~1023ull);  // whole windows
-        lives[p] = (uint32_t)live64;
+    rayrs_scene::Pool& pl = scene->pool;
+    WfDev wf = pl.wf;
+    uint32_t flat_blocks = 0;
+    if (!use_local && rp.total_items > 0) {  // (the local-pool route keeps its paths in LDS)
+        const uint32_t np = (uint32_t)((live_total + 1023ull) & ~1023ull);  // whole windows
         const size_t block_bytes = (size_t)np * (slot_bytes + 1u);
         if (block_bytes > pl.block_bytes || !pl.block) {
             if (pl.block) HIP_TRY(hipFree(pl.block));
@@ -719,21 +716,50 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         pl.wf.slots = static_cast<PathSlot*>(pl.block);
         pl.wf.light = reinterpret_cast<double*>(pl.wf.slots + np);
         pl.wf.state = reinterpret_cast<uint8_t*>(pl.wf.light + (size_t)np * 4u);
-        WfDev wf = pl.wf;
+        wf = pl.wf;
         wf.np = np;
-        RenderDev r = rp;
-        {
-            // whole round-robin rounds covering about static_pct % of the pool's windows
-            const uint64_t n_windows = np / wf_window_slots(), n_waves = (uint64_t)trav_blocks * 4u;
-            r.static_windows = (uint32_t)(n_windows * static_pct / 100u / n_waves * n_waves);
+        const uint32_t n_windows = np / wf_window_slots();
+
+        // ---- item streams and pool regions (wavefront.h WfDev): one per XCD when the pool is large enough for that
+        // to mean anything -- at least 64 windows (32 k slots) and 16 tiles per stream; rayrs_lab.h streams overrides
+        uint32_t ns = lab.streams ? lab.streams : MAX_STREAMS;
+        if (lab.streams) {
+            while (ns > 1u && (n_windows < ns || n_local < ns)) ns /= 2u;  // (a test may ask for tiny regions; not for empty ones)
+        } else {
+            while (ns > 1u && (n_windows < 64u * ns || n_local < 16u * ns)) ns /= 2u;
         }
-        uint32_t fb = (np / wf_window_slots() + 3u) / 4u;  // one wave per window
+        rp.n_streams = wf.n_streams = ns;
+        wf.stream_shift = ns == 8u ? 3u : ns == 4u ? 2u : ns == 2u ? 1u : 0u;
+        for (uint32_t s = 0; s < ns; s++) {
+            rp.stream_end[s] = (n_local * (s + 1u) / ns) * tile_items;  // whole tiles
+            wf.win_lo[s] = (uint32_t)((uint64_t)n_windows * s / ns);
+        }
+        wf.win_lo[ns] = n_windows;
+        for (uint32_t s = 0; s < ns; s++) {
+            // whole round-robin rounds covering about static_pct % of the region's windows
+            const uint64_t n = wf.win_lo[s + 1] - wf.win_lo[s], n_waves = (uint64_t)((trav_blocks - s + ns - 1u) / ns) * 4u;
+            wf.win_static[s] = n_waves ? (uint32_t)(n * static_pct / 100u / n_waves * n_waves) : 0u;
+        }
+        // tiles become items band by band, each band column by column: by default a band is what one stream holds
+        // of the grid's rows (the streams' tiles are then blocks of the image), at most 32 rows
+        {
+            const uint32_t width = rp.tiles_x % rp.tile_ranks == 0u ? rp.tiles_x / rp.tile_ranks : rp.tiles_x;
+            const uint32_t grid_rows = (uint32_t)((n_local + width - 1u) / width);
+            uint32_t rows = (grid_rows + ns - 1u) / ns;
+            if (rows > 32u) rows = 32u;
+            if (lab.band_rows == 0xffffffffu) rows = 0;
+            else if (lab.band_rows) rows = lab.band_rows;
+            rp.order = make_tile_order((uint32_t)n_local, rp.tiles_x, rp.tile_ranks, rows);
+        }
+
+        // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three: one
+        // wave per window, at most eight workgroups per CU, and as many workgroups for every region
+        uint32_t fb = (n_windows + 3u) / 4u;
         const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
         if (fb > flat_cap) fb = flat_cap;
-        flat_blocks[p] = fb;
-        // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three
+        fb = (fb + ns - 1u) / ns * ns;
+        flat_blocks = fb;
         wf.n_flat_waves = fb * 4u;
-        if (use_stream && wf.n_flat_waves < sp_blocks * 4u) wf.n_flat_waves = sp_blocks * 4u;  // its waves keep item ranges too
         if (wf.n_flat_waves > pl.wave_items_cap) {
             if (pl.d_wave_items) HIP_TRY(hipFree(pl.d_wave_items));
             pl.d_wave_items = nullptr;
@@ -745,7 +771,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         wf.trav_threads = trav_blocks * 256u;
         {
             const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
-            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads * (rp.trav_two ? 2u : 1u);
+            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
             if (words > pl.stack_spill_words) {
                 if (pl.d_stack_spill) HIP_TRY(hipFree(pl.d_stack_spill));
                 pl.d_stack_spill = nullptr;
@@ -755,28 +781,28 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             }
             wf.stack_spill = pl.d_stack_spill;
         }
-        r.next_item = scene->d_next_item;
-        wfs[p] = wf;
-        rps[p] = r;
-        pl.timed_rounds = 0;
     }
     rp.next_item = scene->d_next_item;
+    pl.timed_rounds = 0;
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
-    HIP_TRY(hipMemsetAsync(scene->d_next_item, 0, sizeof(unsigned long long), stream));
     if (use_local) HIP_TRY(hipMemsetAsync(scene->d_local_items, 0, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
     scene->rounds = 0;
     scene->last_local = use_local;
-    scene->last_stream_pool = use_stream;
+    auto round_events = [&](size_t n) -> int {
+        while (pl.ev_round.size() < n) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            pl.ev_round.push_back(e);
+        }
+        return RAYRS_OK;
+    };
     if (use_local && rp.total_items > 0) {
         // ---- one launch per segment of the frame's items; a launch ends when its last path has (local_pool.hip)
-        rayrs_scene::Pipeline& pl = scene->pipe[0];
-        scene->n_pipes = 1;
-        pl.timed_rounds = 0;
         const uint64_t n_seg = (rp.total_items + seg_items - 1) / seg_items;
         // LP_WPS workgroups of four waves per CU; fewer when the frame has fewer items than resident paths
-        uint32_t blocks = (uint32_t)scene->cu_count * (uint32_t)LP_WPS;
+        uint32_t blocks = (uint32_t)scene->cu_count * (uint32_t)scene->local_blocks_per_cu;
         {
             const uint64_t most_items = rp.total_items < seg_items ? rp.total_items : seg_items;
             const uint64_t want = (most_items + 4u * LP_PATHS_PER_WAVE - 1) / (4u * LP_PATHS_PER_WAVE);
@@ -801,35 +827,27 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             {
                 const uint64_t share = lp.item_count / ((uint64_t)blocks * 4u * 16u);  // a sixteenth of a wave's share
                 lp.reserve = (uint32_t)(share < 8u ? 8u : share > 256u ? 256u : share);
-                if (scene->tuning.pool_slots >= 8u && scene->tuning.pool_slots <= 4096u) lp.reserve = scene->tuning.pool_slots;  // (experiments)
+                if (lab.local_reserve) lp.reserve = lab.local_reserve;
                 lp.pad = 0;
             }
-            while (pl.ev_trav.size() < 4 * (size_t)(seg + 1)) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreate(&e));
-                pl.ev_trav.push_back(e);
+            {
+                const int st = round_events(4 * (size_t)(seg + 1));
+                if (st != RAYRS_OK) return st;
             }
-            HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg], stream));
+            HIP_TRY(hipEventRecord(pl.ev_round[4 * seg], stream));
             HIP_TRY(lp_launch(compact, count, sc, scene->local, cam, rseg, lp, blocks, stream));
-            HIP_TRY(hipEventRecord(pl.ev_trav[4 * seg + 1], stream));
+            HIP_TRY(hipEventRecord(pl.ev_round[4 * seg + 1], stream));
             // the segment's tiles, resolved behind its launch (the next segment reuses the item-sum array)
             HIP_TRY(launch_resolve(cam, rseg, (uint32_t)(seg * seg_tiles), (uint32_t)(lp.item_count / tile_items), stream));
             pl.timed_rounds = (uint32_t)seg + 1;
         }
         scene->rounds = (uint32_t)n_seg;
     } else if (rp.total_items > 0) {
-        if (n_pipes > 1) {  // fork: the second stream starts behind everything queued on the caller's so far
-            HIP_TRY(hipEventRecord(scene->ev_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(scene->aux_stream, scene->ev_fork, 0));
-        }
-        for (uint32_t p = 0; p < n_pipes; p++) {
-            HIP_TRY(wf_launch_init(wfs[p], lives[p], streams[p]));
-            // initial fill; later samples start in hit/miss (stream_pool.hip's kernel takes the IDLE slots itself)
-            if (!use_stream) HIP_TRY(wf_launch_gen(compact, sc, cam, rps[p], wfs[p], flat_blocks[p], streams[p]));
-            scene->pipe[p].h_live[0] = scene->pipe[p].h_live[1] = lives[p];
-        }
-        // Rounds are enqueued in batches; the live-slot counts of batch b are read back while batch b+1 is
-        // already queued, so the GPU never waits for the host.  Rounds behind a pipeline's last one find
+        HIP_TRY(wf_launch_init(rp, wf, (uint32_t)live_total, stream));
+        HIP_TRY(wf_launch_gen(compact, sc, cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
+        pl.h_live[0] = pl.h_live[1] = (uint32_t)live_total;
+        // Rounds are enqueued in batches; the live-slot count of batch b is read back while batch b+1 is
+        // already queued, so the GPU never waits for the host.  Rounds behind the frame's last one find
         // live_slots == 0 and return at once; batches shrink from 16 rounds to 4 once fewer than an eighth of
         // the slots have work, so that at most 7 such rounds are queued after the end.
         constexpr uint32_t MAX_TIMED = 8192;
@@ -837,46 +855,28 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         uint32_t batch = 16;
         for (uint32_t b = 0;; b++) {
             for (uint32_t k = 0; k < batch; k++, it++) {
-                for (uint32_t p = 0; p < n_pipes; p++) {
-                    rayrs_scene::Pipeline& pl = scene->pipe[p];
-                    hipStream_t st = streams[p];
-                    if (p == 1 && it == 0) HIP_TRY(hipStreamWaitEvent(st, scene->ev_stagger, 0));  // half a round behind
-                    const bool timed = it < MAX_TIMED;
-                    // four events per round: before the traversal kernel, after it, after the hit kernel, after the miss kernel
-                    if (timed) {
-                        while (pl.ev_trav.size() < 4 * (size_t)(it + 1)) {
-                            hipEvent_t e;
-                            HIP_TRY(hipEventCreate(&e));
-                            pl.ev_trav.push_back(e);
-                        }
-                        HIP_TRY(hipEventRecord(pl.ev_trav[4 * it], st));
-                    }
-                    // (with the stream pool the frame's first round has nothing to walk yet: every slot is IDLE)
-                    if (!(use_stream && it == 0)) HIP_TRY(wf_launch_trav(compact, count, sc, rps[p], wfs[p], trav_blocks, st));
-                    if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 1], st));
-                    if (p == 0 && it == 0 && n_pipes > 1) HIP_TRY(hipEventRecord(scene->ev_stagger, st));
-                    if (use_stream) HIP_TRY(sp_launch(compact, count, sc, scene->root_record, cam, rps[p], wfs[p], sp_blocks, st));
-                    else HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
-                    if (timed) HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 2], st));
-                    if (!use_stream) HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rps[p], wfs[p], flat_blocks[p], st));
-                    if (timed) {
-                        HIP_TRY(hipEventRecord(pl.ev_trav[4 * it + 3], st));
-                        pl.timed_rounds = it + 1;
-                    }
+                const bool timed = it < MAX_TIMED;
+                // four events per round: before the traversal kernel, after it, after the hit kernel, after the miss kernel
+                if (timed) {
+                    const int st = round_events(4 * (size_t)(it + 1));
+                    if (st != RAYRS_OK) return st;
+                    HIP_TRY(hipEventRecord(pl.ev_round[4 * it], stream));
+                }
+                HIP_TRY(wf_launch_trav(compact, count, sc, rp, wf, trav_blocks, stream));
+                if (timed) HIP_TRY(hipEventRecord(pl.ev_round[4 * it + 1], stream));
+                HIP_TRY(wf_launch_hit(compact, eager_light, sc, cam, rp, wf, flat_blocks, stream));
+                if (timed) HIP_TRY(hipEventRecord(pl.ev_round[4 * it + 2], stream));
+                HIP_TRY(wf_launch_miss(compact, eager_light, sc, cam, rp, wf, flat_blocks, stream));
+                if (timed) {
+                    HIP_TRY(hipEventRecord(pl.ev_round[4 * it + 3], stream));
+                    pl.timed_rounds = it + 1;
                 }
             }
-            for (uint32_t p = 0; p < n_pipes; p++) {
-                rayrs_scene::Pipeline& pl = scene->pipe[p];
-                HIP_TRY(hipMemcpyAsync(&pl.h_live[b & 1u], &wfs[p].ctl->live_slots, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                       streams[p]));
-                HIP_TRY(hipEventRecord(pl.ev_batch[b & 1u], streams[p]));
-            }
+            HIP_TRY(hipMemcpyAsync(&pl.h_live[b & 1u], &wf.ctl->live_slots, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(pl.ev_batch[b & 1u], stream));
             if (b > 0) {
-                uint64_t seen = 0;
-                for (uint32_t p = 0; p < n_pipes; p++) {
-                    HIP_TRY(hipEventSynchronize(scene->pipe[p].ev_batch[(b - 1u) & 1u]));
-                    seen += scene->pipe[p].h_live[(b - 1u) & 1u];
-                }
+                HIP_TRY(hipEventSynchronize(pl.ev_batch[(b - 1u) & 1u]));
+                const uint64_t seen = pl.h_live[(b - 1u) & 1u];
                 if (seen == 0u) break;
                 batch = seen * 8u < live_total ? 4u : 16u;
             }
@@ -886,10 +886,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
             }
         }
         scene->rounds = it;
-        if (n_pipes > 1) {  // join: the resolve pass waits for the second stream
-            HIP_TRY(hipEventRecord(scene->ev_join, scene->aux_stream));
-            HIP_TRY(hipStreamWaitEvent(stream, scene->ev_join, 0));
-        }
     }
     HIP_TRY(hipEventRecord(scene->ev[1], stream));
     if (!use_local) HIP_TRY(launch_resolve(cam, rp, 0u, rp.n_local_tiles, stream));
@@ -931,31 +927,26 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->trace_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[2]));
         stats->total_ms = ms;
-        double trav = 0.0, hit = 0.0, miss = 0.0;
-        for (uint32_t p = 0; p < scene->n_pipes; p++) {
-            const rayrs_scene::Pipeline& pl = scene->pipe[p];
-            double t = 0.0, h = 0.0, m = 0.0;
-            for (uint32_t r = 0; r < pl.timed_rounds; r++) {
-                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r], pl.ev_trav[4 * r + 1]));
-                t += ms;
-                if (scene->last_local) continue;  // one kernel per segment
-                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r + 1], pl.ev_trav[4 * r + 2]));
-                h += ms;
-                HIP_TRY(hipEventElapsedTime(&ms, pl.ev_trav[4 * r + 2], pl.ev_trav[4 * r + 3]));
-                m += ms;
-            }
-            // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
-            if (pl.timed_rounds && scene->rounds > pl.timed_rounds) {
-                const double f = (double)scene->rounds / (double)pl.timed_rounds;
-                t *= f, h *= f, m *= f;
-            }
-            trav += t, hit += h, miss += m;
+        const rayrs_scene::Pool& pl = scene->pool;
+        double t = 0.0, h = 0.0, m = 0.0;
+        for (uint32_t r = 0; r < pl.timed_rounds; r++) {
+            HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r], pl.ev_round[4 * r + 1]));
+            t += ms;
+            if (scene->last_local) continue;  // one kernel per segment
+            HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r + 1], pl.ev_round[4 * r + 2]));
+            h += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r + 2], pl.ev_round[4 * r + 3]));
+            m += ms;
         }
-        stats->kernel_ms = trav;
-        stats->hit_ms = hit, stats->miss_ms = miss;
-        stats->local_pool = scene->last_local ? 1u : scene->last_stream_pool ? 2u : 0u;
-        stats->shade_wave = c.shade_wave, stats->shade_lane = c.shade_lane;
-        stats->kernel_launches = (uint64_t)scene->rounds * scene->n_pipes;
+        // rounds beyond the event pool (very long renders) are extrapolated from the timed ones
+        if (pl.timed_rounds && scene->rounds > pl.timed_rounds) {
+            const double f = (double)scene->rounds / (double)pl.timed_rounds;
+            t *= f, h *= f, m *= f;
+        }
+        stats->kernel_ms = t;
+        stats->hit_ms = h, stats->miss_ms = m;
+        stats->local_pool = scene->last_local ? 1u : 0u;
+        stats->kernel_launches = (uint64_t)scene->rounds;
     }
     return RAYRS_OK;
 }
@@ -980,17 +971,6 @@ int rayrs_render(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_ren
     }
     (void)hipFree(d_out);
     return st;
-}
-
-// development aid (scripts/ubench/sp_probe.py): the stream-pool kernel's per-phase clock and execution counts of the
-// last count_work render -- import, gen, isect, bg, shade
-int rayrs_debug_counters(rayrs_scene* scene, uint64_t out[10]) {
-    if (!scene || !out || scene->device < 0) return RAYRS_INVALID_ARG;
-    HIP_TRY(hipSetDevice(scene->device));
-    Counters c;
-    HIP_TRY(hipMemcpy(&c, scene->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    for (int j = 0; j < 5; j++) out[j] = c.sp_ticks[j], out[5 + j] = c.sp_phases[j];
-    return RAYRS_OK;
 }
 
 // ------------------------------------------------------------- self tests
@@ -1053,7 +1033,8 @@ int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint6
     return dout.download(out_bits, n * 8);
 }
 
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, double* t, int64_t* object) {
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
+                         int64_t* object) {
     if (!scene || !o || !d || !t || !object) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     HIP_TRY(hipSetDevice(scene->device));
@@ -1062,7 +1043,7 @@ int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, u
     ST_TRY(ddir.upload(d, n * 24));
     ST_TRY(dt.alloc(n * 8));
     ST_TRY(dprim.alloc(n * 8));
-    const SceneDev sc = make_scene_dev(scene);
+    const SceneDev sc = make_scene_dev(scene, exact != 0);
     DevBuf dspill;  // stack entries beyond the LDS part, one strip per thread of the launch
     const uint64_t threads = (n + 255) / 256 * 256;
     if (sc.stack_depth > sc.stack_lds) ST_TRY(dspill.alloc((size_t)(sc.stack_depth - sc.stack_lds) * threads * 4));
@@ -1114,7 +1095,7 @@ int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, dou
     DevBuf dd, dout;
     ST_TRY(dd.upload(dir, n * 24));
     ST_TRY(dout.alloc(n * 24));
-    const SceneDev sc = make_scene_dev(scene);
+    const SceneDev sc = make_scene_dev(scene, false);
     if (n) HIP_TRY(launch_test_background(sc, (const double*)dd.p, n, (double*)dout.p, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     return dout.download(rgb, n * 24);

@@ -273,16 +273,19 @@ RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 // fetched whole, with loads that do not depend on its contents, before anything
 // is decided from it.
 constexpr uint32_t TRAV_DONE = 0xffffffffu;
-// Closest-hit culling is the one place where the walk is exact in practice, not by construction (the reference
-// never culls): a slot is skipped when its box is entered beyond best_t * TRAV_CULL_MARGIN, which loses a hit
-// only if a primitive's computed t lies in front of the entry parameter of a box around it by more than the
-// margin AND another accepted hit falls in between.  Moeller-Trumbore's t has a relative error of about
-// eps * (distance / size) / (grazing angle), so no fixed margin covers every ray.  Measured with
-// scripts/fuzz_traversal.py (60 M rays on sliver meshes and nearly flat sheets, origins up to 10^6 scene sizes
-// away): rays at 10^-7 rad and more off a triangle's plane put t at most 2^-44.8 in front of a box; rays aimed
-// along the plane itself broke a margin of 2^-40 in 59 of 1.6 M cases at 10^-5..10^-3 rad, 2^-24 in 7, 2^-16 and
-// 2^-10 in none; 2^-10 failed once in 1.6 M at less than 10^-11 rad.  2^-10 costs 0.4 % more record visits and
-// 0.7 % more primitive tests on the headline scene (2^-40: round 2's value).  t > t0 >= 0 (lib.rs:234).
+// Closest-hit culling is the one place where the walk departs from the reference's: BvhTree::intersect never culls
+// (bvh.rs:391-415), the walk skips a slot whose box is entered beyond best_t * SceneDev::cull_margin.  That loses a
+// hit only if a primitive's COMPUTED t lies in front of the entry parameter of a box around it by more than the margin
+// AND another accepted hit falls in between.  Moeller-Trumbore's t has a relative error of about eps * (distance / size)
+// / (grazing angle) -- unbounded as the ray approaches the triangle's plane -- and which triangles lie behind a box is
+// not known without reading them, so NO margin computed from the ray and the box alone is sound: culling is either off
+// (cull_margin = +infinity, rayrs_render_params.exact_traversal: the reference's visit set by construction, at the
+// reference's cost) or a bet.  The default margin is the bet measured with scripts/fuzz_traversal.py
+// (profiles/r03_fuzz_traversal.txt: 10^8 rays on sliver meshes and nearly flat sheets, origins up to 10^6 scene sizes
+// away): rays at 10^-7 rad and more off a triangle's plane put t at most 2^-11.1 in front of a box; between 10^-9 and
+// 10^-7 rad one ray in 10^7 loses its hit, closer to the plane one in 10^7 again (tests/test_walk_tree.py pins one: 2 % in
+// front).  2^-10 costs 0.4 % more record visits and 0.7 % more primitive tests on the headline scene than 2^-40.
+// best_t > t0 >= 0 (lib.rs:234), so best_t * inf = inf: nothing is beyond it, NaN entries included (!(NaN > x)).
 constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-10;
 
 // A lane's traversal stack.  Entry k lives in LDS at lds[k * 64] while k < cap; deeper
@@ -291,15 +294,19 @@ constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-10;
 // instead of the bound is what lets five workgroups share a CU on the 1M-triangle scene.
 struct LaneStack {
     uint32_t* lds;  // cap entries and one spare (never read) that branch-free pushes may scribble on
-    uint32_t* spill;
+    uint32_t* spill_base;  // wave-uniform: the strips of all threads of the launch; this lane's is found from its thread
+                           // index when an entry does go there (a per-lane pointer would live in two registers for good)
     uint32_t cap, stride;
+    RR_DEV size_t spill_at(int k) const {
+        uint32_t tid = blockIdx.x * 256u + threadIdx.x;  // workgroups of 256 threads
+        asm volatile("" : "+v"(tid));  // (worked out where it is used: hoisted out of the walk it costs the loop two registers)
+        return (size_t)((uint32_t)k - cap) * stride + tid;
+    }
     RR_DEV void put(int k, uint32_t v) const {
         if ((uint32_t)k < cap) lds[k * 64] = v;
-        else spill[(size_t)((uint32_t)k - cap) * stride] = v;
+        else spill_base[spill_at(k)] = v;
     }
-    RR_DEV uint32_t get(int k) const {
-        return (uint32_t)k < cap ? lds[k * 64] : spill[(size_t)((uint32_t)k - cap) * stride];
-    }
+    RR_DEV uint32_t get(int k) const { return (uint32_t)k < cap ? lds[k * 64] : spill_base[spill_at(k)]; }
 };
 
 struct Trav {
@@ -420,7 +427,7 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     // Unused slots need no special case here: they carry the inverted box (scene_host.cpp), for
     // which the slab test above says "missed".  Boxes entered beyond the closest hit so far are
-    // skipped -- beyond it by TRAV_CULL_MARGIN: a primitive's computed t and the entry parameter of the
+    // skipped -- beyond it by SceneDev::cull_margin (see TRAV_CULL_MARGIN): a primitive's computed t and the entry parameter of the
     // box around it are rounded independently (and t badly so on grazing rays), so a hit computed in
     // front of its own box must not be lost to a farther one (every primitive that is tested is judged
     // by the reference's rule, so a wider margin only costs visits, never the answer).
@@ -428,7 +435,7 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // compare writes its mask to a scalar register pair) and combined there: "b before a" and its complement are
     // one comparison and one scalar operation, where the compiler, given lane booleans, issues a second f64
     // compare for every complement.
-    const double cull = tv.best_t * TRAV_CULL_MARGIN;
+    const double cull = tv.best_t * sc.cull_margin;
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
     const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
     const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
@@ -495,34 +502,6 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
         }
     }
     trav_pop(stack, tv);
-}
-
-// One PRIMITIVE of a leaf reference: the first of its 1..4, in DFS order; the reference then stands for the
-// rest of the group, or is popped.  The traversal kernel's leaf phases take this step, so that a lane with
-// a one-primitive group (the floor rectangle: more than half of the headline frame's queries end there) is
-// back in interior work after one test instead of idling through its neighbours' four.
-template <bool COMPACT, bool COUNT>
-RR_DEV void trav_leaf_step_one(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
-    const double tmin = sc.t0, tmax = sc.t1;
-    const uint32_t payload = tv.cur & 0x3fffffffu;
-    const uint32_t p = payload >> 2, left = payload & 3u;
-    if (COUNT) wc.leaf_prims = 1u;
-    const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
-    if (COUNT) {
-        const uint32_t kind = r.tag() & 3u;
-        if (kind == PRIM_TRIANGLE) wc.tri++;
-        else if (kind == PRIM_SPHERE) wc.sphere++;
-        else wc.plane++;
-    }
-    double t;
-    if (prim_intersect<COMPACT>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
-        if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {    // bvh.rs:62
-            tv.best_t = t;
-            tv.best_prim = p;
-        }
-    }
-    if (left != 0u) tv.cur = (REF_RANGE << 30) | ((p + 1u) << 2) | (left - 1u);
-    else trav_pop(stack, tv);
 }
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }

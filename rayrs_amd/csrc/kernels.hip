@@ -14,8 +14,8 @@ __global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev r
     const uint64_t n = (uint64_t)n_lt * 64u;  // the rank's tiles lt0 .. lt0 + n_lt - 1
     if (idx >= n) return;
     const uint32_t pit = (uint32_t)(idx & 63u);
-    const uint32_t lt = lt0 + (uint32_t)(idx >> 6);
-    const uint32_t tile = lt * rp.tile_ranks + rp.tile_rank;
+    const uint32_t lt = lt0 + (uint32_t)(idx >> 6);  // in item order (layout.h TileOrder)
+    const uint32_t tile = local_tile_of(rp.order, lt) * rp.tile_ranks + rp.tile_rank;
     const uint32_t row = (tile / rp.tiles_x) * 8u + (pit >> 3);
     const uint32_t col = (tile % rp.tiles_x) * 8u + (pit & 7u);
     if (row >= cam.H || col >= cam.W) return;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // sc.stack_lds entries of the stack in LDS, the rest in the strip `spill` (as in the traversal kernel)
-    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill + i, sc.stack_lds,
+    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill, sc.stack_lds,
                           gridDim.x * blockDim.x};
     if (i >= n) return;
     double t = 0.0;

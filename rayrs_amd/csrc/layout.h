@@ -101,6 +101,10 @@ struct SceneDev {
     uint32_t pad0;
     double root_box[6];
     double t0, t1;  // Scene::t_range, lib.rs:218
+    // closest-hit culling of the walk (device_path.h trav_interior_step): a slot entered beyond best_t * cull_margin is
+    // skipped.  1 + 2^-10 by default; +infinity with rayrs_render_params.exact_traversal: nothing is culled, as in
+    // BvhTree::intersect (bvh.rs:391-415)
+    double cull_margin;
 };
 
 struct CameraDev {
@@ -118,9 +122,28 @@ struct Counters {
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
-    unsigned long long shade_wave, shade_lane;  // stream_pool.hip: phase executions x 64 and the lanes active in them (count_work)
-    unsigned long long sp_ticks[5], sp_phases[5];  // stream_pool.hip diagnostics: shader clock and executions per phase kind
-                                                   // (import, gen, isect, bg, shade); read by rayrs_debug_counters
+};
+
+// Item streams (wavefront.hip): the rank's tiles, in item order, are cut into n_streams contiguous ranges, each with an
+// item counter of its own; the pool's windows are cut into as many regions, region s served by the workgroups of one
+// XCD and fed from stream s first (from the others once it has run out).
+constexpr uint32_t MAX_STREAMS = 8;
+
+// The order in which a rank's tiles become items.  Row-major until round 3; now bands of `rows` tile rows, each band
+// column by column, so that the tiles whose items are in flight together form a block of the image rather than a strip
+// across it (what the rays in flight meet of the scene is then a part of it, and an XCD's L2 holds more of that part).
+// Defined on the rank's LOCAL tiles l = 0 .. n_local - 1 (global tile t = l * tile_ranks + tile_rank, row-major in
+// the image) laid out as a grid `width` wide whose last row may be ragged.
+struct TileOrder {
+    uint32_t rows;        // tile rows per band; 0 = row-major (no permutation)
+    uint32_t width;       // local tiles per grid row
+    uint32_t band_cells;  // rows * width
+    uint32_t last_first;  // first item-order tile of the last band
+    uint32_t last_rows;   // grid rows of the last band (1 .. rows)
+    uint32_t last_cut;    // cells of the last band in its full-height columns (ragged last row: the columns below `ragged`)
+    uint32_t ragged;      // cells of the grid's last row if it is not full, else 0
+    uint32_t last_base;   // grid row the last band starts at
+    double inv_band_cells, inv_rows, inv_last_rows, inv_last_rows_m1;  // reciprocals for udiv_by()
 };
 
 struct RenderDev {
@@ -134,17 +157,68 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
-    uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
-    uint32_t leaf_single;           // traversal: a leaf phase tests one primitive per lane (else the lane's whole group)
-    uint32_t trav_two;              // traversal: two queries per lane (wf_trav2_kernel)
-    uint32_t pad2;
-    uint32_t hit_wps3;              // experiment: the hit kernel built for three workgroups per CU, without look-ahead
+    uint32_t n_streams;             // item streams = pool regions, 1 .. MAX_STREAMS
+    uint64_t stream_end[MAX_STREAMS];  // stream s holds the items stream_end[s - 1] (0 for s = 0) .. stream_end[s] - 1
+    TileOrder order;
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)
     uint64_t partial_item0;
-    unsigned long long* next_item;  // device-wide item counter (shared by the render's pipelines)
+    unsigned long long* next_item;  // n_streams item counters; counter s starts at stream s's first item
     Counters* counters;
     void* out;
 };
+
+// n / d and n % d for a launch-constant d with 1/d at hand: the quotient of the f64 product is
+// within one of the true one (n < 2^32, relative error 2^-52), and the remainder says which.
+// A dozen instructions against the ~35 of a 32-bit integer division.
+#if defined(__HIPCC__)
+#define RR_LAYOUT_FN __host__ __device__ static inline
+#else
+#define RR_LAYOUT_FN static inline
+#endif
+RR_LAYOUT_FN uint32_t udiv_by(uint32_t n, uint32_t d, double inv_d, uint32_t& rem) {
+    uint32_t q = (uint32_t)((double)n * inv_d);
+    int32_t r = (int32_t)(n - q * d);
+    if (r < 0) q--, r += (int32_t)d;
+    else if ((uint32_t)r >= d) q++, r -= (int32_t)d;
+    rem = (uint32_t)r;
+    return q;
+}
+
+// Item-order tile j of the rank -> its local tile l (TileOrder above).
+RR_LAYOUT_FN uint32_t local_tile_of(const TileOrder& to, uint32_t j) {
+    if (to.rows == 0u) return j;
+    uint32_t vrow, vcol;
+    if (j < to.last_first) {
+        uint32_t rem;
+        const uint32_t band = udiv_by(j, to.band_cells, to.inv_band_cells, rem);
+        uint32_t r;
+        vcol = udiv_by(rem, to.rows, to.inv_rows, r);
+        vrow = band * to.rows + r;
+    } else {
+        const uint32_t rem = j - to.last_first;
+        uint32_t r;
+        if (rem < to.last_cut) {
+            vcol = udiv_by(rem, to.last_rows, to.inv_last_rows, r);
+        } else {
+            vcol = to.ragged + udiv_by(rem - to.last_cut, to.last_rows - 1u, to.inv_last_rows_m1, r);
+        }
+        vrow = to.last_base + r;
+    }
+    return vrow * to.width + vcol;
+}
+
+// The pixel, and the sample range, of item `item`: 64 pixels of a tile x the tile's chunks (main.rs:65-68).
+RR_LAYOUT_FN void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
+                                uint32_t& s_end) {
+    const uint32_t pit = item & 63u;
+    uint32_t chunk, tile_col;
+    const uint32_t j = udiv_by(item >> 6, rp.nchunks, rp.inv_nchunks, chunk);
+    const uint32_t tile = local_tile_of(rp.order, j) * rp.tile_ranks + rp.tile_rank;
+    row = udiv_by(tile, rp.tiles_x, rp.inv_tiles_x, tile_col) * 8u + (pit >> 3);
+    col = tile_col * 8u + (pit & 7u);
+    s_begin = chunk * rp.chunk;
+    s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
+}
 
 }  // namespace rayrs

@@ -41,6 +41,7 @@ struct LocalDev {
 
 uint32_t lp_lds_bytes(uint32_t n_prims, uint32_t n_surfaces);
 hipError_t lp_configure();  // raises the kernels' dynamic LDS limit; once per device
+hipError_t lp_occupancy(bool compact, uint32_t n_prims, uint32_t n_surfaces, int* blocks_per_cu);
 hipError_t lp_launch(bool compact, bool count, const SceneDev& sc, const LocalScene& ls, const CameraDev& cam,
                      const RenderDev& rp, const LocalDev& lp, uint32_t blocks, hipStream_t stream);
 

@@ -103,29 +103,6 @@ RR_DEV double* lp_light(const LocalDev& lp, uint32_t p) {
     return lp.light + ((size_t)wave_global * P + p) * 4u;
 }
 
-// n / d and n % d for a launch-constant d with 1/d at hand (wavefront.hip udiv_by): the quotient of the f64
-// product is within one of the true one (n < 2^32), and the remainder says which
-RR_DEV uint32_t lp_udiv_by(uint32_t n, uint32_t d, double inv_d, uint32_t& rem) {
-    uint32_t q = (uint32_t)((double)n * inv_d);
-    int32_t r = (int32_t)(n - q * d);
-    if (r < 0) q--, r += (int32_t)d;
-    else if ((uint32_t)r >= d) q++, r -= (int32_t)d;
-    rem = (uint32_t)r;
-    return q;
-}
-
-// the item numbering of wavefront.hip item_geometry: 64 pixels of a tile x the tile's chunks
-RR_DEV void lp_item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
-                             uint32_t& s_end) {
-    const uint32_t pit = item & 63u;
-    uint32_t chunk, tx;
-    const uint32_t tile = lp_udiv_by(item >> 6, rp.nchunks, rp.inv_nchunks, chunk) * rp.tile_ranks + rp.tile_rank;
-    row = lp_udiv_by(tile, rp.tiles_x, rp.inv_tiles_x, tx) * 8u + (pit >> 3);
-    col = tx * 8u + (pit & 7u);
-    s_begin = chunk * rp.chunk;
-    s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
-}
-
 // ---- GEN: the path in this slot has ended (or the slot never had one).  Write the item out if its samples are
 // all done, take the next sample -- or the next item -- and make its primary ray (main.rs:67-79, lib.rs:202-210).
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
@@ -139,7 +116,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
     bool has_item = valid && (w >> 31) != 0u;
     uint32_t s_cur = w & SLOT_SAMPLE_MASK, item = pl.u(U_ITEM, p);
     uint32_t row, col, s_end, s_first;
-    lp_item_geometry(rp, item, row, col, s_first, s_end);  // (of no meaning without an item)
+    item_geometry(rp, item, row, col, s_first, s_end);  // (of no meaning without an item)
     if (has_item && s_cur >= s_end) {  // the item's sum goes to the resolve kernel
         double* dst = rp.partial + ((size_t)item - rp.partial_item0) * 3;
         dst[0] = pl.f(F_AX, p), dst[1] = pl.f(F_AY, p), dst[2] = pl.f(F_AZ, p);
@@ -170,7 +147,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
         if (need && rank < avail) {
             item = (uint32_t)(lp.item_base + range.next + rank);
             uint32_t s_begin;
-            lp_item_geometry(rp, item, row, col, s_begin, s_end);
+            item_geometry(rp, item, row, col, s_begin, s_end);
             s_cur = s_begin;
             if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
                 // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
@@ -301,7 +278,7 @@ RR_DEV uint32_t lp_shade(const Pool& pl, bool valid, uint32_t p, int kind, const
     const uint32_t bounce = bd & LP_BOUNCE_MASK;
     // the RNG key of the sample in flight: the item's pixel and the sample before the cursor
     uint32_t row, col, s_first, s_end;
-    lp_item_geometry(rp, pl.u(U_ITEM, p), row, col, s_first, s_end);
+    item_geometry(rp, pl.u(U_ITEM, p), row, col, s_first, s_end);
     Rng rng{rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)((w & SLOT_SAMPLE_MASK) - 1u)), bd >> 16};
     V3 light = mk(0.0, 0.0, 0.0);
     if (valid && ((w >> 30) & 1u)) {
@@ -410,7 +387,7 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
     LpCount n{0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long u_wave = 0, u_lane = 0;
     unsigned long long tk_isect = 0, tk_shade = 0, tk_other = 0, tk_last = COUNT ? lp_clock() : 0ull;
-    unsigned long long n_isect = 0, n_shade = 0, tk_gen = 0, n_gen = 0, n_bg = 0, t_mid = 0;
+    unsigned long long n_isect = 0, n_shade = 0, t_mid = 0;
 
     for (;;) {
         // the phase most paths wait for
@@ -476,8 +453,6 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
             tk_isect += now - t_mid, n_isect++;  // the query at the end of every execution (t_mid: where it began)
             if (ph >= LP_SHADE0) tk_shade += t_mid - tk_last, n_shade++;
             else tk_other += t_mid - tk_last;
-            if (ph == LP_GEN) tk_gen += t_mid - tk_last, n_gen++;
-            if (ph == LP_BG) n_bg++;
             tk_last = now;
         }
 #pragma unroll
@@ -502,11 +477,6 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
             atomicAdd(&c->interior_ticks, tk_isect), atomicAdd(&c->leaf_ticks, tk_shade);
             atomicAdd(&c->refill_ticks, tk_other);
             atomicAdd(&c->inner_wave, n_isect), atomicAdd(&c->leaf_wave, n_shade);  // phase executions (diagnostics)
-            // per phase kind for rayrs_debug_counters (the stream-pool kernel's slots: -, gen, isect, bg, shade)
-            atomicAdd(&c->sp_ticks[1], tk_gen), atomicAdd(&c->sp_ticks[2], tk_isect);
-            atomicAdd(&c->sp_ticks[3], tk_other - tk_gen), atomicAdd(&c->sp_ticks[4], tk_shade);
-            atomicAdd(&c->sp_phases[1], n_gen), atomicAdd(&c->sp_phases[2], n_isect);
-            atomicAdd(&c->sp_phases[3], n_bg), atomicAdd(&c->sp_phases[4], n_shade);
         }
         lp_wave_add(&c->step_lane, u_lane);
     }
@@ -527,6 +497,13 @@ hipError_t lp_configure() {
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_path_kernel<false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, most);
+}
+
+// workgroups of the kernel a CU holds with this scene's LDS footprint (at most LP_WPS, its launch bound)
+hipError_t lp_occupancy(bool compact, uint32_t n_prims, uint32_t n_surfaces, int* blocks_per_cu) {
+    const uint32_t lds = lp_block_bytes(n_prims < LP_MAX_PRIMS ? n_prims : LP_MAX_PRIMS, n_surfaces < LP_MAX_PRIMS ? n_surfaces : LP_MAX_PRIMS);
+    if (compact) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lp_path_kernel<true, false>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lp_path_kernel<false, false>, 256, lds);
 }
 
 hipError_t lp_launch(bool compact, bool count, const SceneDev& sc, const LocalScene& ls, const CameraDev& cam,

@@ -212,8 +212,11 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 }
             }
         }
-        // one device (a rehearsal with several handles on it): everything is summed already, no collective, no RCCL
-        if (st == RAYRS_OK && devs.size() > 1) st = rccl_reduce_to_first(devs, bufs, streams, count, f64);
+        // one device (a rehearsal with several handles on it): everything is summed already, no collective, no RCCL --
+        // unless rayrs_lab.h force_rccl asks for the call path of a multi-GPU node anyway: a communicator of one
+        // device, and the same grouped in-place ncclReduce to rank 0 (which then copies nothing and changes nothing)
+        const bool force_rccl = scenes[0]->lab.force_rccl != 0u;
+        if (st == RAYRS_OK && (devs.size() > 1 || force_rccl)) st = rccl_reduce_to_first(devs, bufs, streams, count, f64);
         if (st == RAYRS_OK) {
             hipError_t e = hipSetDevice(devs[0]);
             if (e == hipSuccess) e = hipMemcpy(out_host, bufs[0], bytes, hipMemcpyDeviceToHost);
@@ -233,7 +236,6 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->interior_ticks += s.interior_ticks, stats->leaf_ticks += s.leaf_ticks;
                 stats->refill_ticks += s.refill_ticks;
                 for (int k = 0; k < 8; k++) stats->surface_hits[k] += s.surface_hits[k];
-                stats->shade_wave += s.shade_wave, stats->shade_lane += s.shade_lane;
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
                 if (s.trace_ms > stats->trace_ms) stats->trace_ms = s.trace_ms;
                 if (s.kernel_ms > stats->kernel_ms) stats->kernel_ms = s.kernel_ms;

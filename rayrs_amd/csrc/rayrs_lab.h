@@ -1,0 +1,46 @@
+/*
+ * rayrs_lab.h -- PRIVATE scheduling knobs of librayrs_hip.so, for tests/ and scripts/ubench/ only.
+ *
+ * Not part of the boundary a rayrs-lib maintainer binds (include/rayrs_hip.h): nothing here has a
+ * reference counterpart, none of it changes what is computed, and any of it may go away.  The public
+ * header keeps the two settings a caller may legitimately choose (rayrs_tuning: pool size, route).
+ * 0 = the built-in default everywhere.
+ */
+#ifndef RAYRS_LAB_H
+#define RAYRS_LAB_H
+
+#include <stdint.h>
+
+#include "../../include/rayrs_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
+    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (32) */
+    uint32_t static_pct;    /* traversal: share of a stream's windows dealt round robin, 1..100 (50) */
+    uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
+    uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
+                               0xffffffff = none */
+    uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
+    uint32_t eager_light;   /* 1 = the hit and miss kernels request a path's entry of the light side array together
+                               with its slot also where no surface emits (they do anyway where one does) */
+    uint32_t local_reserve; /* local-pool route: items a wave takes from the counter at a time, 8..4096 */
+    uint32_t local_segment_items; /* local-pool route: items per launch segment, >= 65536 (default 2^27); raised
+                               as far as needed to keep a frame within 64 segments */
+    uint32_t force_rccl;    /* rayrs_render_multi: run the RCCL reduce even when every handle sits on one device
+                               (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
+    uint32_t streams;       /* streaming route: item streams / pool regions (one per XCD), 1..8 (8) */
+    uint32_t band_rows;     /* streaming route: tile rows per band of the column-major tile order, 0 = default,
+                               0xffffffff = row-major tiles (the order until round 3) */
+} rayrs_lab_tuning;
+
+/* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
+int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,7 +8,7 @@
 
 #include "../../include/rayrs_hip.h"
 #include "local_pool.h"
-#include "stream_pool.h"
+#include "rayrs_lab.h"
 #include "scene_host.hpp"
 #include "wavefront.h"
 
@@ -37,11 +37,9 @@ struct rayrs_scene {
     uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
     uint32_t hot_records = 0;    // leading wide records kept in LDS
     uint64_t device_bytes = 0;
-    // The path pool, as one or two pipelines (abi.cpp rayrs_render_launch): each owns its slots, state
-    // bytes, control words, per-wave item ranges and traversal-stack overflow strips, and runs its rounds on
-    // a stream of its own, so that one pipeline's memory-bound hit/miss kernels can run beside the other's
-    // ALU-bound traversal kernel.
-    struct Pipeline {
+    // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,
+    // per-wave item ranges and traversal-stack overflow strips, kept between renders.
+    struct Pool {
         rayrs::WfDev wf = {};
         void* block = nullptr;       // one allocation holding the slot records and the state bytes
         size_t block_bytes = 0;
@@ -51,23 +49,17 @@ struct rayrs_scene {
         size_t stack_spill_words = 0;
         uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
         hipEvent_t ev_batch[2] = {nullptr, nullptr};
-        std::vector<hipEvent_t> ev_trav;  // start/stop pairs around the traversal launches
+        std::vector<hipEvent_t> ev_round;  // four per round: around the traversal, hit and miss launches
         uint32_t timed_rounds = 0;
     };
-    Pipeline pipe[2];
-    uint32_t n_pipes = 1;            // pipelines of the render in flight
-    hipStream_t aux_stream = nullptr;  // the second pipeline's stream (the first uses the caller's)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
-    unsigned long long* d_next_item = nullptr;  // the device-wide item counter both pipelines draw from
+    Pool pool;
+    unsigned long long* d_next_item = nullptr;  // the item counters, one per stream (layout.h MAX_STREAMS)
     uint32_t rounds = 0;
     // Scenes whose walk tree is at most one record are rendered by local_pool.hip: every path resident in LDS.
     bool local_ok = false;
     bool last_local = false;          // the render in flight took that route
     rayrs::LocalScene local = {};
-    // Scenes with a deeper walk tree: paths resident in LDS between two deep walks (stream_pool.hip)
-    bool stream_ok = false;
-    bool last_stream_pool = false;
-    rayrs::RootRecord root_record = {};
+    int local_blocks_per_cu = 1;      // local-pool kernel, from the occupancy query with the scene's LDS size
     double* d_local_light = nullptr;  // 4 doubles per resident path
     size_t local_light_paths = 0;
     unsigned long long* d_local_items = nullptr;  // one item counter per launch segment
@@ -76,6 +68,7 @@ struct rayrs_scene {
     void* multi_out = nullptr;
     size_t multi_out_bytes = 0;
     rayrs_tuning tuning = {};  // zeros = defaults (rayrs_scene_set_tuning)
+    rayrs_lab_tuning lab = {};  // development knobs (rayrs_lab.h), zeros = defaults
 };
 
 

@@ -56,10 +56,9 @@ constexpr uint8_t WF_MISS = 3;   // no hit: miss_kernel's input
 constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)
 
 struct WfCtl {
-    uint32_t next_window;  // window cursor of the traversal kernel
-    uint32_t live_slots;   // slots that still have or can get work
-    uint32_t next_window_shade;  // window cursor of stream_pool.hip's kernel (reset by the traversal kernel)
-    uint32_t pad[5];
+    uint32_t next_window[MAX_STREAMS];  // per pool region: cursor over the windows the traversal kernel hands out on demand
+    uint32_t live_slots;                // slots that still have or can get work
+    uint32_t pad[7];
 };
 
 struct WfDev {
@@ -68,6 +67,13 @@ struct WfDev {
     uint8_t* state;
     WfCtl* ctl;
     uint32_t np;  // slots in the pool, a multiple of 1024
+    // Pool regions: region s = the windows win_lo[s] .. win_lo[s + 1] - 1, worked on by the workgroups b with
+    // b % n_streams == s -- workgroups are dealt round robin over the 8 XCDs, so a region stays with one XCD (two or
+    // four for fewer regions) and its slots take their items from stream s (RenderDev::stream_end): the rays an XCD's
+    // L2 sees come from one part of the image.  Placement is for speed only; nothing depends on it.
+    uint32_t n_streams, stream_shift;  // n_streams = 1 << stream_shift: 1, 2, 4 or 8
+    uint32_t win_lo[MAX_STREAMS + 1];
+    uint32_t win_static[MAX_STREAMS];  // leading windows of a region dealt round robin to its traversal waves (whole rounds)
     // per-wave reserved item ranges [next, end) of the gen/hit/miss kernels, which all run with
     // the same grid (n_flat_waves waves) and give wave w the same windows
     unsigned long long* wave_items;
@@ -79,12 +85,12 @@ struct WfDev {
 };
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
-hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
+hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, uint32_t live, hipStream_t stream);
 hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, uint32_t two_queries, int* blocks_per_cu);
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
 // eager_light: request the side array's entry together with the slot (scenes in which a surface emits)
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);

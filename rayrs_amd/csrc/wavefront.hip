@@ -96,9 +96,25 @@ RR_DEV uint32_t compact_window_ready(const WfDev& wf, uint32_t win, uint16_t* li
 // frame's 58 % / 34 % of a window that is 4.6 instead of 5 and 2.7 instead of 3 batches per window.
 constexpr uint32_t FEED_LIST = WINDOW + 64;  // entries per wave
 
+// A wave's place in its stream (WfDev: pool regions): workgroup b serves region b % n_streams, as wave
+// (b / n_streams) * 4 + wave-in-workgroup of the region's waves.  Wave-uniform.
+struct StreamSeat {
+    uint32_t stream, wave, n_waves;  // region, index among its waves, number of its waves
+    uint32_t win_lo, win_hi;         // the region's windows
+};
+RR_DEV StreamSeat stream_seat(const WfDev& wf) {
+    StreamSeat st;
+    const uint32_t ns = wf.n_streams, sh = wf.stream_shift;  // ns = 1 << sh
+    st.stream = blockIdx.x & (ns - 1u);
+    st.wave = (blockIdx.x >> sh) * 4u + (threadIdx.x >> 6);
+    st.n_waves = ((gridDim.x - st.stream + ns - 1u) >> sh) * 4u;
+    st.win_lo = wf.win_lo[st.stream], st.win_hi = wf.win_lo[st.stream + 1u];
+    return st;
+}
+
 struct BatchFeed {
-    uint32_t next_win, n_waves, n_windows, count, k, total;  // wave-uniform
-    StateWords ahead;                                        // state bytes of window next_win
+    uint32_t next_win, n_waves, win_hi, count, k, total;  // wave-uniform
+    StateWords ahead;                                     // state bytes of window next_win
     uint8_t want;
     uint32_t* list;
 };
@@ -119,17 +135,18 @@ RR_DEV uint32_t compact_words_abs(const StateWords& sw, uint8_t want, uint32_t b
     return count;
 }
 
-RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_waves, uint8_t want, uint32_t* list) {
-    f.next_win = wave, f.n_waves = n_waves, f.n_windows = wf.np / WINDOW;
+// the seat's windows win_lo + wave, + n_waves, ... of its region
+RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, const StreamSeat& seat, uint8_t want, uint32_t* list) {
+    f.next_win = seat.win_lo + seat.wave, f.n_waves = seat.n_waves, f.win_hi = seat.win_hi;
     f.count = 0, f.k = 0, f.total = 0, f.want = want, f.list = list;
     f.ahead.w[0] = f.ahead.w[1] = 0;
-    if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
+    if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, f.next_win);
 }
 
 // Next batch: false when the wave's windows are exhausted.
 RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid) {
     const uint32_t lane = threadIdx.x & 63u;
-    while (f.count - f.k < 64u && f.next_win < f.n_windows) {
+    while (f.count - f.k < 64u && f.next_win < f.win_hi) {
         const uint32_t left = f.count - f.k;  // < 64: one entry per lane, moved to the front
         const uint32_t carry = lane < left ? f.list[f.k + lane] : 0u;
         if (lane < left) f.list[lane] = carry;
@@ -138,7 +155,7 @@ RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid
         f.count = left + fresh;
         f.k = 0;
         f.next_win += f.n_waves;
-        if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
+        if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, f.next_win);
     }
     if (f.k >= f.count) return false;
     valid = f.k + lane < f.count;
@@ -164,45 +181,20 @@ RR_DEV void wave_atomic_add(unsigned long long* dst, unsigned long long v) {
     if ((threadIdx.x & 63u) == 0 && s) atomicAdd(dst, s);
 }
 
-// n / d and n % d for a launch-constant d with 1/d at hand: the quotient of the f64 product is
-// within one of the true one (n < 2^32, relative error 2^-52), and the remainder says which.
-// A dozen instructions against the ~35 of a 32-bit integer division, four of which every
-// new sample used to pay.
-RR_DEV uint32_t udiv_by(uint32_t n, uint32_t d, double inv_d, uint32_t& rem) {
-    uint32_t q = (uint32_t)((double)n * inv_d);
-    int32_t r = (int32_t)(n - q * d);
-    if (r < 0) q--, r += (int32_t)d;
-    else if ((uint32_t)r >= d) q++, r -= (int32_t)d;
-    rem = (uint32_t)r;
-    return q;
-}
-
-RR_DEV void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
-                          uint32_t& s_end) {
-    const uint32_t pit = item & 63u;
-    const uint32_t tc = item >> 6;
-    uint32_t chunk, tile_col;
-    const uint32_t tile = udiv_by(tc, rp.nchunks, rp.inv_nchunks, chunk) * rp.tile_ranks + rp.tile_rank;
-    row = udiv_by(tile, rp.tiles_x, rp.inv_tiles_x, tile_col) * 8u + (pit >> 3);
-    col = tile_col * 8u + (pit & 7u);
-    s_begin = chunk * rp.chunk;
-    s_end = s_begin + rp.chunk < rp.spp ? s_begin + rp.chunk : rp.spp;
-}
-
 RR_DEV RaySlot* ray_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].ray; }
 RR_DEV TailSlot* tail_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].tail; }
 RR_DEV double* light_slot(const WfDev& wf, uint32_t slot) { return wf.light + (size_t)slot * 4u; }
 
 // ------------------------------------------------------------------- init
 
-__global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
+__global__ void __launch_bounds__(256) wf_init_kernel(RenderDev rp, WfDev wf, uint32_t live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         WfCtl* c = wf.ctl;
-        c->next_window = 0;
-        c->next_window_shade = 0;
+        for (uint32_t s = 0; s < MAX_STREAMS; s++) c->next_window[s] = 0;
         c->live_slots = live;
     }
+    if (i < rp.n_streams) rp.next_item[i] = i ? rp.stream_end[i - 1u] : 0ull;  // every stream's counter at its first item
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
@@ -240,29 +232,58 @@ RR_DEV uint64_t sample_key(const RenderDev& rp, const CameraDev& cam, const Item
     return rr_path_key(rp.seed, (uint64_t)(ir.pix >> 16) * cam.W + (ir.pix & 0xffffu), (uint64_t)(ir.s_cur - 1u));
 }
 
-// A wave's private range of reserved item ids [next, end).  Items are taken from the
-// device-wide counter ITEM_RESERVE at a time (one atomic), not one batch at a time: with
-// ~10^5 batches per round finishing items, per-batch atomics on the single counter word
-// (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
-// The range lives in registers during a launch and in WfDev::wave_items between launches.
+// A wave's private range of reserved item ids [next, end).  Items are taken from a stream's counter ITEM_RESERVE
+// at a time (one atomic), not one batch at a time: with ~10^5 batches per round finishing items, per-batch atomics
+// on one counter word (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
+// A wave asks its own stream first (StreamSeat) and, once that has run out, the others in turn; `gone` has a bit
+// for every stream the wave has seen exhausted, so that at the end of a frame nobody keeps asking.  The range
+// lives in registers during a launch and in WfDev::wave_items between launches.
 constexpr uint32_t ITEM_RESERVE = 256;
-constexpr unsigned long long ITEMS_GONE = ~0ull;  // ItemRange::end of a wave that found the counter exhausted
 
 struct ItemRange {
     unsigned long long next, end;
+    uint32_t gone;  // bit s: stream s's counter has run out
 };
 
 RR_DEV ItemRange load_item_range(const WfDev& wf, uint32_t wave) {
     ItemRange r;
     r.next = wf.wave_items[2 * (size_t)wave];
-    r.end = wf.wave_items[2 * (size_t)wave + 1];
+    const unsigned long long w = wf.wave_items[2 * (size_t)wave + 1];
+    r.end = w & 0xffffffffffffull;
+    r.gone = (uint32_t)(w >> 48);
     return r;
 }
 RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r) {
     if ((threadIdx.x & 63u) == 0) {
         wf.wave_items[2 * (size_t)wave] = r.next;
-        wf.wave_items[2 * (size_t)wave + 1] = r.end;
+        wf.wave_items[2 * (size_t)wave + 1] = r.end | ((unsigned long long)r.gone << 48);
     }
+}
+
+// Refills an empty range from the streams' counters, the wave's own stream first.  False when every stream has run
+// out.  Wave-uniform (one lane asks, all lanes get the answer).
+RR_DEV bool refill_item_range(const RenderDev& rp, uint32_t own_stream, ItemRange& range) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t all = (1u << rp.n_streams) - 1u;
+    while (range.gone != all) {
+        uint32_t s = own_stream;
+        while ((range.gone >> s) & 1u) s = s + 1u == rp.n_streams ? 0u : s + 1u;
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(&rp.next_item[s], (unsigned long long)ITEM_RESERVE);
+        const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
+        const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
+        first = ((unsigned long long)fhi << 32) | flo;
+        const unsigned long long end = rp.stream_end[s];
+        if (first >= end) {
+            range.gone |= 1u << s;
+            continue;
+        }
+        range.next = first;
+        range.end = first + ITEM_RESERVE < end ? first + ITEM_RESERVE : end;
+        return true;
+    }
+    range.next = range.end = 0ull;
+    return false;
 }
 
 // What the kernels that start samples count per lane.
@@ -279,8 +300,8 @@ struct SampleCount {
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
 template <bool COMPACT>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
-                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
-                        SampleCount& sn) {
+                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t own_stream,
+                        ItemRange& range, SampleCount& sn) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     bool todo = want;  // lanes still without a ray for their slot
@@ -305,24 +326,9 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         bool dead = false;
         unsigned long long need_mask = __ballot(need);
         while (need_mask != 0ull) {
-            if (range.next >= range.end) {  // wave-uniform
-                // a wave that has seen the counter run out remembers it (range.end = ITEMS_GONE, kept in
-                // WfDev::wave_items between launches): at the end of a frame every batch of every wave would
-                // otherwise ask the one counter word again, which serves ~90 atomics per microsecond
-                unsigned long long first = ITEMS_GONE;
-                if (range.end != ITEMS_GONE) {
-                    if (lane == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
-                    const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
-                    const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
-                    first = ((unsigned long long)fhi << 32) | flo;
-                }
-                if (first >= rp.total_items) {  // the counter has run out: these slots are done
-                    range.next = range.end = ITEMS_GONE;
-                    if (need) dead = true;
-                    break;
-                }
-                range.next = first;
-                range.end = first + ITEM_RESERVE < rp.total_items ? first + ITEM_RESERVE : rp.total_items;
+            if (range.next >= range.end && !refill_item_range(rp, own_stream, range)) {  // wave-uniform
+                if (need) dead = true;  // every stream has run out: these slots are done
+                break;
             }
             const uint32_t avail = (uint32_t)(range.end - range.next);
             const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
@@ -412,11 +418,10 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n_windows = wf.np / WINDOW;
+    const StreamSeat seat = stream_seat(wf);
     SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
-    for (uint32_t win = wave; win < n_windows; win += n_waves) {
+    for (uint32_t win = seat.win_lo + seat.wave; win < seat.win_hi; win += seat.n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
@@ -425,7 +430,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
             ItemRegs ir;
             ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
             ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;
-            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, seat.stream, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -439,17 +444,15 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-template <bool COMPACT, bool COUNT, bool LEAF_ONE>
+template <bool COMPACT, bool COUNT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->next_window_shade = 0;  // stream_pool.hip's window cursor
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
-    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane,
-                          wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
+    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, wf.stack_spill, sc.stack_lds, wf.trav_threads};
     uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u) + wave * WINDOW;
     uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u + 4u * WINDOW / 2u);
     {
@@ -462,17 +465,19 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     const HotNodes hot{hot_lds, sc.hot_records};
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
 
-    const uint32_t n_windows = wf.np / WINDOW;
-    // Windows of the pool are handed out in two ways.  The first rp.static_windows windows are
-    // dealt round robin: wave g takes g, g + n_waves, ... and asks nobody.  The rest go to whoever
-    // runs dry first, through one atomic cursor (WfCtl::next_window), which evens out the
-    // waves' finishing times.  All of the pool through the cursor costs a fifth of the waves'
-    // time waiting for it: a single word takes about 90 atomics per microsecond on this chip.
-    // Once most slots have run out of work (the tail of a frame, long on a small tile share) the
-    // cursor's atomics are all a launch would wait for, and balance no longer matters: deal everything.
-    const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t static_windows = ctl->live_slots < wf.np / 4u ? n_windows : rp.static_windows;
-    uint32_t static_next = blockIdx.x * 4u + wave;       // wave-uniform
+    // A workgroup works on the windows of its pool region (StreamSeat: one region per XCD).  They are handed out in
+    // two ways.  The first static_pct % of the region are dealt round robin: the region's wave g takes its windows g,
+    // g + n_waves, ... and asks nobody.  The rest go to whoever runs dry first, through the region's atomic cursor
+    // (WfCtl::next_window), which evens out the waves' finishing times -- and a wave that finds its own region's
+    // cursor at the end goes on with the other regions' (`steal`), so that the XCDs finish together too.  All of
+    // the pool through one cursor costs a fifth of the waves' time waiting for it: a single word takes about 90
+    // atomics per microsecond on this chip.  Once most slots have run out of work (the tail of a frame, long on a
+    // small tile share) the cursors' atomics are all a launch would wait for, and balance no longer matters: deal
+    // everything.
+    // (what says which windows are the wave's is worked out again each time a window is fetched, once per 512 slots:
+    // kept across the traversal loop, those scalars crowd the register file the loop needs)
+    uint32_t static_next = (blockIdx.x >> wf.stream_shift) * 4u + wave;  // wave-uniform: next of the wave's dealt windows (region-relative)
+    uint32_t steal = 0;                                                  // wave-uniform: regions whose cursor the wave has seen run out
     uint32_t list_pos = 0, list_len = 0, list_base = 0;  // wave-uniform
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
@@ -509,14 +514,31 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
-                    uint32_t w = static_next;
-                    if (w < static_windows) {
-                        static_next += n_waves;
+                    uint32_t w = 0xffffffffu;
+                    const StreamSeat seat = stream_seat(wf);
+                    const bool deal_all = ctl->live_slots < wf.np / 4u;
+                    const uint32_t static_windows = deal_all ? seat.win_hi - seat.win_lo : wf.win_static[seat.stream];
+                    if (static_next < static_windows) {
+                        w = seat.win_lo + static_next;
+                        static_next += seat.n_waves;
                     } else {
-                        if (lane == 0) w = static_windows + atomicAdd(&ctl->next_window, 1u);
-                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+                        // the region's cursor, then the others' in turn
+                        while (steal < wf.n_streams) {
+                            const uint32_t r = (seat.stream + steal) & (wf.n_streams - 1u);
+                            const uint32_t lo = wf.win_lo[r], n = wf.win_lo[r + 1u] - lo;
+                            // (a region's dealt share is its own waves': its cursor starts behind it)
+                            const uint32_t r_static = deal_all ? n : wf.win_static[r];
+                            uint32_t k = 0;
+                            if (lane == 0) k = atomicAdd(&ctl->next_window[r], 1u);
+                            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                            if (r_static + k < n) {
+                                w = lo + r_static + k;
+                                break;
+                            }
+                            steal++;
+                        }
                     }
-                    if (w >= n_windows) {
+                    if (w == 0xffffffffu) {
                         no_more = true;
                         break;
                     }
@@ -555,8 +577,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                if (LEAF_ONE) trav_leaf_step_one<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-                else trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -569,230 +590,6 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             if (at_int) {
                 trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
-            }
-            if (COUNT) {
-                const unsigned long long now = clock64();
-                tk_int += now - tk_last, tk_last = now;
-            }
-        }
-    }
-
-    Counters* c = rp.counters;
-    wave_atomic_add(&c->rays, n_rays);
-    if (COUNT) {
-        wave_atomic_add(&c->interior_visits, wc.interior);
-        wave_atomic_add(&c->tri_tests, wc.tri);
-        wave_atomic_add(&c->sphere_tests, wc.sphere);
-        wave_atomic_add(&c->plane_tests, wc.plane);
-        wave_atomic_add(&c->step_wave, u_int_wave), wave_atomic_add(&c->step_lane, u_int_lane);
-        wave_atomic_add(&c->inner_wave, u_leaf_lane), wave_atomic_add(&c->leaf_wave, u_leaf_wave);
-        if (lane == 0) {
-            atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
-            atomicAdd(&c->refill_ticks, tk_refill);
-        }
-    }
-}
-
-// ------------------------------------------------------------- trav, two queries per lane
-//
-// The same traversal with TWO queries per lane (A and B), each with its own stack.  A wave decides per
-// iteration, as above, whether to run an interior or a leaf step; a lane takes part with whichever of its two
-// queries stands in that phase (A first).  A lane is idle in a phase only if neither of its queries is in it:
-// with one query per lane 34 % of the lanes are idle in an interior step and 43 % in a leaf step on the headline
-// frame (lanes waiting for the other phase, or for the next refill).  The price: the step's operands are selected
-// from two register sets (v_cndmask) and written back, and a wave needs 24 more registers.
-
-struct Query {
-    V3 o, d;
-    Trav tv;
-    uint32_t slot;
-    bool active, pending;
-};
-
-// the wave's window list and how windows are dealt (wave-uniform)
-struct WindowFeed {
-    uint32_t static_next, static_windows, n_waves, n_windows;
-    uint32_t list_pos, list_len, list_base;
-    bool no_more;
-    uint16_t* list;
-};
-
-RR_DEV void trav2_retire(const WfDev& wf, Query& q) {
-    if (q.pending) {
-        const bool hit = q.tv.best_prim != 0xffffffffu;
-        if (hit) {
-            RaySlot* rs = ray_slot(wf, q.slot);
-            rs->t = q.tv.best_t;
-            rs->prim = q.tv.best_prim;
-        }
-        wf.state[q.slot] = hit ? WF_HIT : WF_MISS;
-        q.pending = false;
-    }
-}
-
-// idle queries of this kind (A or B) take rays from the wave's window list
-RR_DEV void trav2_refill(const SceneDev& sc, const WfDev& wf, WfCtl* ctl, WindowFeed& f, Query& q,
-                         unsigned long long& n_rays) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    bool need = !q.active;
-    unsigned long long need_mask = __ballot(need);
-    while (need_mask != 0ull) {
-        if (f.list_pos >= f.list_len) {
-            uint32_t w = f.static_next;
-            if (w < f.static_windows) {
-                f.static_next += f.n_waves;
-            } else {
-                if (lane == 0) w = f.static_windows + atomicAdd(&ctl->next_window, 1u);
-                w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-            }
-            if (w >= f.n_windows) {
-                f.no_more = true;
-                break;
-            }
-            f.list_base = w * WINDOW;
-            f.list_len = compact_window_ready(wf, w, f.list);
-            f.list_pos = 0;
-            continue;
-        }
-        const uint32_t avail = f.list_len - f.list_pos;
-        const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
-        if (need && rank < avail) {
-            q.slot = f.list_base + (uint32_t)f.list[f.list_pos + rank];
-            const RaySlot* rs = ray_slot(wf, q.slot);
-            q.o = mk(rs->o[0], rs->o[1], rs->o[2]);
-            q.d = mk(rs->d[0], rs->d[1], rs->d[2]);
-            n_rays++;
-            trav_init(sc, q.o, q.d, q.tv);
-            if (q.tv.cur == TRAV_DONE)
-                q.pending = true;  // missed the root box: retired at the next refill
-            else
-                q.active = true;
-            need = false;
-        }
-        const uint32_t wanted = (uint32_t)__popcll(need_mask);
-        f.list_pos += wanted < avail ? wanted : avail;
-        need_mask = __ballot(need);
-    }
-}
-
-RR_DEV V3 sel3(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
-
-template <bool COMPACT, bool COUNT, int WPS>
-__global__ void __launch_bounds__(256, WPS) wf_trav2_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
-    extern __shared__ uint32_t lds_dyn[];
-    WfCtl* ctl = wf.ctl;
-    if (ctl->live_slots == 0u) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    // dynamic LDS: per wave two stacks of (stack_lds + 1 spare) x 64 words (A then B), 4 window lists, hot records
-    const uint32_t stack_words = (sc.stack_lds + 1u) * 64u;
-    uint32_t* stack_a = lds_dyn + (size_t)wave * 2u * stack_words + lane;
-    const size_t spill_words = (size_t)(sc.stack_depth > sc.stack_lds ? sc.stack_depth - sc.stack_lds : 0u) * wf.trav_threads;
-    uint32_t* spill_a = wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x);
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 8u * (size_t)stack_words) + wave * WINDOW;
-    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 8u * (size_t)stack_words + 4u * WINDOW / 2u);
-    {
-        constexpr uint32_t G = COMPACT ? 8u : 16u;
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
-        for (uint32_t i = threadIdx.x; i < sc.hot_records * G; i += 256u)
-            hot_lds[(i / G) * HotNodes::stride<COMPACT>() + i % G] = src[i];
-        __syncthreads();
-    }
-    const HotNodes hot{hot_lds, sc.hot_records};
-
-    WindowFeed feed;
-    feed.n_windows = wf.np / WINDOW;
-    feed.n_waves = gridDim.x * 4u;
-    feed.static_windows = ctl->live_slots < wf.np / 4u ? feed.n_windows : rp.static_windows;
-    feed.static_next = blockIdx.x * 4u + wave;
-    feed.list_pos = feed.list_len = feed.list_base = 0;
-    feed.no_more = false;
-    feed.list = list;
-
-    Query qa, qb;
-    qa.o = qb.o = mk(0, 0, 0), qa.d = qb.d = mk(0, 0, 1);
-    qa.tv.inv = qb.tv.inv = mk(0, 0, 0);
-    qa.tv.best_t = qb.tv.best_t = 0, qa.tv.best_prim = qb.tv.best_prim = 0xffffffffu;
-    qa.tv.cur = qb.tv.cur = TRAV_DONE, qa.tv.sp = qb.tv.sp = 0;
-    qa.slot = qb.slot = 0, qa.active = qb.active = false, qa.pending = qb.pending = false;
-    WorkCount wc{0, 0, 0, 0, 0};
-    unsigned long long n_rays = 0;
-    unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
-    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
-    const uint32_t refill_min2 = 2u * rp.refill_min;
-
-    for (;;) {
-        const bool a_int = qa.active && trav_at_interior(qa.tv), a_leaf = qa.active && !trav_at_interior(qa.tv);
-        const bool b_int = qb.active && trav_at_interior(qb.tv), b_leaf = qb.active && !trav_at_interior(qb.tv);
-        const bool l_int = a_int || b_int, l_leaf = a_leaf || b_leaf;
-        const int n_int = __popcll(__ballot(l_int));
-        const int n_leaf = __popcll(__ballot(l_leaf));
-        const uint32_t n_act = (uint32_t)__popcll(__ballot(qa.active)) + (uint32_t)__popcll(__ballot(qb.active));
-        if ((n_act < refill_min2 && !feed.no_more) || n_int + n_leaf == 0) {
-            trav2_retire(wf, qa);
-            trav2_retire(wf, qb);
-            if (feed.no_more) break;  // only reached with no query in flight
-            trav2_refill(sc, wf, ctl, feed, qa, n_rays);
-            if (!feed.no_more) trav2_refill(sc, wf, ctl, feed, qb, n_rays);
-            if (COUNT) {
-                const unsigned long long now = clock64();
-                tk_refill += now - tk_last, tk_last = now;
-            }
-            if (__ballot(qa.active || qa.pending || qb.active || qb.pending) == 0ull && feed.no_more) break;
-            continue;
-        }
-        if (n_leaf >= (int)rp.leaf_min || n_int == 0) {
-            // ---- leaf phase: a lane with a query on a leaf tests that leaf's primitives
-            if (COUNT) u_leaf_wave += 1, u_leaf_lane += l_leaf ? 1 : 0;
-            if (l_leaf) {
-                const bool ua = a_leaf;
-                const V3 o = sel3(ua, qa.o, qb.o), d = sel3(ua, qa.d, qb.d);
-                Trav tv;
-                tv.inv = mk(0, 0, 0);
-                tv.best_t = ua ? qa.tv.best_t : qb.tv.best_t;
-                tv.best_prim = ua ? qa.tv.best_prim : qb.tv.best_prim;
-                tv.cur = ua ? qa.tv.cur : qb.tv.cur;
-                tv.sp = ua ? qa.tv.sp : qb.tv.sp;
-                const LaneStack stack{stack_a + (ua ? 0u : stack_words), spill_a + (ua ? (size_t)0 : spill_words),
-                                      sc.stack_lds, wf.trav_threads};
-                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-                const bool done = tv.cur == TRAV_DONE;
-                if (ua) {
-                    qa.tv.best_t = tv.best_t, qa.tv.best_prim = tv.best_prim, qa.tv.cur = tv.cur, qa.tv.sp = tv.sp;
-                    if (done) qa.active = false, qa.pending = true;
-                } else {
-                    qb.tv.best_t = tv.best_t, qb.tv.best_prim = tv.best_prim, qb.tv.cur = tv.cur, qb.tv.sp = tv.sp;
-                    if (done) qb.active = false, qb.pending = true;
-                }
-            }
-            if (COUNT) {
-                const unsigned long long now = clock64();
-                tk_leaf += now - tk_last, tk_last = now;
-            }
-        } else {
-            // ---- interior phase: one record for every lane with a query standing on one
-            if (COUNT) u_int_wave += 1, u_int_lane += l_int ? 1 : 0;
-            if (l_int) {
-                const bool ua = a_int;
-                const V3 o = sel3(ua, qa.o, qb.o);
-                Trav tv;
-                tv.inv = sel3(ua, qa.tv.inv, qb.tv.inv);
-                tv.best_t = ua ? qa.tv.best_t : qb.tv.best_t;
-                tv.best_prim = 0u;
-                tv.cur = ua ? qa.tv.cur : qb.tv.cur;
-                tv.sp = ua ? qa.tv.sp : qb.tv.sp;
-                const LaneStack stack{stack_a + (ua ? 0u : stack_words), spill_a + (ua ? (size_t)0 : spill_words),
-                                      sc.stack_lds, wf.trav_threads};
-                trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
-                const bool done = tv.cur == TRAV_DONE;
-                if (ua) {
-                    qa.tv.cur = tv.cur, qa.tv.sp = tv.sp;
-                    if (done) qa.active = false, qa.pending = true;
-                } else {
-                    qb.tv.cur = tv.cur, qb.tv.sp = tv.sp;
-                    if (done) qb.active = false, qb.pending = true;
-                }
             }
             if (COUNT) {
                 const unsigned long long now = clock64();
@@ -852,10 +649,9 @@ RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0:
     h.ir = load_item(wf, h.slot);
 }
 
-// WPS = workgroups per CU the kernel is built for.  2: 256 registers, batch b + 1 requested while batch b is computed
-// (below).  3: 168 registers and no look-ahead -- a third wave per SIMD covers the waits instead (experiment).
-template <bool COMPACT, bool EAGER, int WPS>
-__global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+// Built for two workgroups per CU: 256 registers, batch b + 1 requested while batch b is computed (below).
+template <bool COMPACT, bool EAGER>
+__global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
     // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
@@ -867,12 +663,12 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
     __syncthreads();
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const StreamSeat seat = stream_seat(wf);
     SampleCount sn{0, 0, 0};
-    if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
+    if (blockIdx.x == 0 && threadIdx.x < MAX_STREAMS) wf.ctl->next_window[threadIdx.x] = 0;  // the traversal kernel's window cursors
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
-    feed_init(feed, wf, wave, n_waves, WF_HIT, list);
+    feed_init(feed, wf, seat, WF_HIT, list);
     // Three fetches per hit depend on each other: slot -> primitive record -> surface row.  The slot records of
     // batch b + 1 are requested before batch b is computed; the primitive records of batch b + 1 as soon as batch
     // b's arithmetic is done -- before batch b's stores, so that the wait for them is not behind the stores
@@ -887,10 +683,8 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
     while (have) {
         HitIn nxt;
         bool have_next = false;
-        if (WPS == 2) {
-            have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-            if (have_next) load_hit_in<EAGER>(wf, nxt);
-        }
+        have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
+        if (have_next) load_hit_in<EAGER>(wf, nxt);
         PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
@@ -945,7 +739,7 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                 }
             }
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
-            if (WPS == 2 && have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
+            if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
             if (goes_on) {
                 RaySlot* rs = ray_slot(wf, slot);
                 rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
@@ -970,19 +764,11 @@ __global__ void __launch_bounds__(256, WPS) wf_hit_kernel(SceneDev sc, CameraDev
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, seat.stream, range, sn);
         }
-        if (WPS == 2) {
-            cur = nxt;
-            rec_cur = rec_nxt;
-            have = have_next;
-        } else {
-            have = feed_next(feed, wf, cur.slot, cur.valid);
-            if (have) {
-                load_hit_in<EAGER>(wf, cur);
-                rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
-            }
-        }
+        cur = nxt;
+        rec_cur = rec_nxt;
+        have = have_next;
     }
     store_item_range(wf, wave, range);
     store_sample_count(rp, wf, sn);
@@ -1016,12 +802,12 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const StreamSeat seat = stream_seat(wf);
     unsigned long long n_escaped = 0;
     SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
-    feed_init(feed, wf, wave, n_waves, WF_MISS, list);
+    feed_init(feed, wf, seat, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
     if (have) load_miss_in<EAGER>(wf, cur);
@@ -1041,7 +827,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, seat.stream, range, sn);
         cur = nxt;
         have = have_next;
     }
@@ -1053,14 +839,14 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
 
 // ----------------------------------------------------------- launch glue
 
-static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records, bool two = false) {
-    return (two ? 2u : 1u) * 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
+static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
+    return 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
 }
 
 uint32_t wf_window_slots() { return WINDOW; }
 
-hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, wf, live);
+hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, uint32_t live, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, rp, wf, live);
     return hipGetLastError();
 }
 
@@ -1074,19 +860,8 @@ hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam,
 template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
-    if (rp.trav_two) {
-        const uint32_t lds2 = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records, true);
-        if (rp.trav_two == 2u)
-            hipLaunchKernelGGL((wf_trav2_kernel<COMPACT, COUNT, 4>), dim3(blocks), dim3(256), lds2, stream, sc, rp, wf);
-        else
-            hipLaunchKernelGGL((wf_trav2_kernel<COMPACT, COUNT, 3>), dim3(blocks), dim3(256), lds2, stream, sc, rp, wf);
-        return hipGetLastError();
-    }
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (rp.leaf_single)
-        hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    else
-        hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -1099,64 +874,35 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
                  : launch_trav_t<false, false>(sc, rp, wf, blocks, stream);
 }
 
-template <bool COMPACT, bool COUNT, bool LEAF_ONE>
+template <bool COMPACT, bool COUNT>
 static hipError_t trav_set_lds(uint32_t lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, LEAF_ONE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <bool COMPACT, bool COUNT, int WPS>
-static hipError_t trav2_set_lds(uint32_t lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav2_kernel<COMPACT, COUNT, WPS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
-template <bool COMPACT, int WPS>
-static hipError_t trav2_occupancy(uint32_t lds2, int* blocks_per_cu) {
-    hipError_t e;
-    if ((e = trav2_set_lds<COMPACT, false, WPS>(lds2)) != hipSuccess) return e;
-    if ((e = trav2_set_lds<COMPACT, true, WPS>(lds2)) != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav2_kernel<COMPACT, false, WPS>, 256, lds2);
-}
-
-// two_queries: 0 = wf_trav_kernel; 1 / 2 = wf_trav2_kernel built for three / four workgroups per CU
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, uint32_t two, int* blocks_per_cu) {
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
-    if (two) {
-        const uint32_t lds2 = trav_lds_bytes(compact, stack_lds, hot_records, true);
-        if (compact) return two == 2u ? trav2_occupancy<true, 4>(lds2, blocks_per_cu) : trav2_occupancy<true, 3>(lds2, blocks_per_cu);
-        return two == 2u ? trav2_occupancy<false, 4>(lds2, blocks_per_cu) : trav2_occupancy<false, 3>(lds2, blocks_per_cu);
-    }
     const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
     if (compact) {
-        if ((e = trav_set_lds<true, false, false>(lds)) != hipSuccess) return e;
-        if ((e = trav_set_lds<true, false, true>(lds)) != hipSuccess) return e;
-        if ((e = trav_set_lds<true, true, false>(lds)) != hipSuccess) return e;
-        if ((e = trav_set_lds<true, true, true>(lds)) != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, true>, 256, lds);
+        if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
+        if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false>, 256, lds);
     }
-    if ((e = trav_set_lds<false, false, false>(lds)) != hipSuccess) return e;
-    if ((e = trav_set_lds<false, false, true>(lds)) != hipSuccess) return e;
-    if ((e = trav_set_lds<false, true, false>(lds)) != hipSuccess) return e;
-    if ((e = trav_set_lds<false, true, true>(lds)) != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, true>, 256, lds);
+    if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
+    if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
                          const WfDev& wf, uint32_t blocks, hipStream_t stream) {
-    const bool lean = eager_light;
-    if (rp.hit_wps3 && compact && !lean) {  // (the experiment is built for the headline's variant only)
-        hipLaunchKernelGGL((wf_hit_kernel<true, false, 3>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
-        return hipGetLastError();
-    }
-    if (compact && lean)
-        hipLaunchKernelGGL((wf_hit_kernel<true, true, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    if (compact && eager_light)
+        hipLaunchKernelGGL((wf_hit_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else if (compact)
-        hipLaunchKernelGGL((wf_hit_kernel<true, false, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
-    else if (lean)
-        hipLaunchKernelGGL((wf_hit_kernel<false, true, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+    else if (eager_light)
+        hipLaunchKernelGGL((wf_hit_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     else
-        hipLaunchKernelGGL((wf_hit_kernel<false, false, 2>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
+        hipLaunchKernelGGL((wf_hit_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, sc, cam, rp, wf);
     return hipGetLastError();
 }
 

@@ -17,7 +17,9 @@ def run(cfg, w, h, spp, chunk=0, level=None, count=False, ranks=1):
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=0)
     tune = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_TUNING", "").split(",") if kv)}
     if tune:
-        scene.set_tuning(**tune)
+        public = {k: v for k, v in tune.items() if k in ("pool_slots", "local_pool")}
+        scene.set_tuning(**public)
+        scene.lab_set(**{k: v for k, v in tune.items() if k not in public})
     tb = time.time() - t
     cam = rayrs_amd.Camera(*cam_args)
     info = scene.info()

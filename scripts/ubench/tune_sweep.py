@@ -1,7 +1,8 @@
-"""Same-box sweep of rayrs_tuning settings on one scene built once (development aid).
+"""Same-box sweep of rayrs_tuning / rayrs_lab.h settings on one scene built once (development aid).
 usage: python scripts/ubench/tune_sweep.py <config> <res> <spp> "k=v,k=v" "k=v" ...   ("" = defaults)
 Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render.
-TILE_RANKS=n in the environment renders rank 0's share of n (what one GPU of n does); CHUNK=n another sample chunk."""
+TILE_RANKS=n in the environment renders one rank's share of n (what one GPU of n does; TILE_RANK=r which, default 0,
+"all" = every rank in turn, slowest reported last); CHUNK=n another sample chunk."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayrs_amd
@@ -18,9 +19,22 @@ chunk = int(os.environ.get("CHUNK", "0")) or rayrs_amd.frame_sample_chunk(res, r
 rayrs_amd.render(scene, cam, 4, mb, sample_chunk=0)  # warm
 ref = None
 for s in settings + settings[::-1]:
-    kw = {k: int(v) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
-    scene.set_tuning(**kw)
-    img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, tile_ranks=int(os.environ.get("TILE_RANKS", "1")))
+    kw = {k: int(v, 0) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
+    public = {k: v for k, v in kw.items() if k in ("pool_slots", "local_pool")}
+    scene.set_tuning(**public)
+    scene.lab_set(**{k: v for k, v in kw.items() if k not in public})
+    n_ranks = int(os.environ.get("TILE_RANKS", "1"))
+    which = os.environ.get("TILE_RANK", "0")
+    ranks = range(n_ranks) if which == "all" else [int(which)]
+    img, worst = None, None
+    for r in ranks:
+        img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, tile_rank=r, tile_ranks=n_ranks, out=img)
+        if len(ranks) > 1:
+            print(f"   rank {r}: trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f}  hit {st['hit_ms']:7.1f} miss {st['miss_ms']:7.1f} "
+                  f"rounds {st['kernel_launches']:4d}  Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}", flush=True)
+        if worst is None or st["trace_ms"] > worst["trace_ms"]:
+            worst = st
+    st = worst
     if ref is None:
         ref = img.copy()
     same = bool((img.view("u4") == ref.view("u4")).all())

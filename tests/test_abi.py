@@ -162,16 +162,30 @@ def test_frame_sample_chunk_depends_on_the_frame_only():
 def test_tuning_is_validated_and_needs_no_gpu():
     cam_args, objs, heur = scenes.diffuse_single_sphere()
     sc = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
-    sc.set_tuning(stack_lds=2, refill_min=40)
+    sc.set_tuning(pool_slots=65536, local_pool=1)
     with pytest.raises(_ffi.RayrsError):
-        sc.set_tuning(static_pct=101)
+        sc.set_tuning(local_pool=2)
     with pytest.raises(ValueError):
         sc.set_tuning(no_such_knob=1)
-    for bad in (dict(stack_lds=65), dict(local_pool=2), dict(leaf_group=2), dict(trav_queries=4), dict(stream_pool=2),
-                dict(hit_blocks_per_cu=4), dict(pipelines=3)):
+    # the development knobs (rayrs_amd/csrc/rayrs_lab.h): validated too
+    sc.lab_set(stack_lds=2, refill_min=40, streams=4, band_rows=8, local_reserve=64, local_segment_items=65536)
+    for bad in (dict(stack_lds=65), dict(static_pct=101), dict(refill_min=65), dict(streams=3), dict(local_reserve=5),
+                dict(local_segment_items=1000), dict(force_rccl=2)):
         with pytest.raises(_ffi.RayrsError):
-            sc.set_tuning(**bad)
-    sc.set_tuning(local_pool=1, leaf_group=1, trav_queries=2, stream_pool=1, hit_blocks_per_cu=3)
+            sc.lab_set(**bad)
+    with pytest.raises(ValueError):
+        sc.lab_set(no_such_knob=1)
+
+
+def test_the_public_header_lists_no_experiment_selector():
+    """include/rayrs_hip.h is the reference's interface for this path plus what a caller may legitimately choose; the
+    kernels' development knobs live in rayrs_amd/csrc/rayrs_lab.h, which nothing outside tests/ and scripts/ needs."""
+    hdr = open(os.path.join(ROOT, "include", "rayrs_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {\n    uint32_t pool_slots;"):hdr.index("} rayrs_tuning;")]
+    assert re.findall(r"uint32_t (\w+);", body) == ["pool_slots", "local_pool"]
+    for word in ("leaf_group", "trav_queries", "stream_pool", "hit_blocks_per_cu", "pipelines", "rayrs_lab", "refill_min"):
+        assert not re.search(rf"\b{word}\b(?!\.h)", hdr), word
+    assert not os.path.exists(os.path.join(ROOT, "rayrs_amd", "csrc", "stream_pool.hip"))
 
 
 def test_which_route_a_scene_takes_is_decided_at_scene_new_and_needs_no_gpu():

@@ -97,7 +97,7 @@ def test_gpu_intersections_and_frame(name):
     o, d = G.rays(256, 11)
     t = np.zeros(len(o))
     obj = np.zeros(len(o), dtype=np.int64)
-    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data,
+    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), 0, t.ctypes.data,
                                              obj.ctypes.data), "rayrs_test_intersect")
     assert np.array_equal(obj, GOLD[f"isect/{name}/obj"])
     assert np.array_equal(bits(t), bits(GOLD[f"isect/{name}/t"]))

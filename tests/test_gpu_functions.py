@@ -163,7 +163,7 @@ def test_bvh_intersect_matches_reference_traversal(name):
     o, d = _rays(3000, 17)
     t = np.zeros(len(o))
     obj = np.zeros(len(o), dtype=np.int64)
-    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data,
+    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), 0, t.ctypes.data,
                                              obj.ctypes.data), "rayrs_test_intersect")
     # against the reference's recursive, un-narrowed traversal (bvh.rs:391-415)
     rt, robj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
@@ -204,12 +204,63 @@ def test_bvh_intersect_degenerate_rays_on_an_integer_grid():
         osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
         t = np.zeros(n)
         obj = np.zeros(n, dtype=np.int64)
-        _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, n, t.ctypes.data,
+        _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, n, 0, t.ctypes.data,
                                                  obj.ctypes.data), "rayrs_test_intersect")
         rt, robj = osc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
         assert (robj >= 0).sum() > 500
         assert np.array_equal(obj, robj)
         assert np.array_equal(bits(t), bits(rt))
+
+
+def _gpu_intersect(scene, o, d, exact):
+    t = np.zeros(len(o))
+    obj = np.zeros(len(o), dtype=np.int64)
+    _ffi.check(scene._L.rayrs_test_intersect(scene._h, o.ctypes.data, d.ctypes.data, len(o), int(exact), t.ctypes.data,
+                                             obj.ctypes.data), "rayrs_test_intersect")
+    return t, obj
+
+
+def test_exact_traversal_returns_the_reference_hit_where_culling_loses_it():
+    """rayrs_render_params.exact_traversal / rayrs_test_intersect(exact = 1): the walk culls nothing (cull margin
+    +infinity), so it visits exactly the boxes BvhTree::intersect visits and returns the reference's closest hit BY
+    CONSTRUCTION -- also for the pinned ray of tests/test_walk_tree.py, within 1e-9 rad of a triangle's plane, whose
+    hit the default margin of 2^-10 loses (the default walk returns what the oracle's culled walk returns: the
+    neighbour 2 % behind), and for grazing rays of ANY angle, which the default only gets right from 1e-7 rad up."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_traversal as F
+    hdri = np.zeros((2, 2, 3), dtype=np.float32)
+    objs, heur, scale, verts, idx = F.scene_for(79)
+    t0, t1 = 1e-6 * scale, 1e9 * scale
+    scene = Scene(objs, t0, t1, heur, hdri, device=0)
+    osc = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(scene)
+    o = np.array([[0.8461539702186601, -0.3178647511202013, 1.6666324107517303]])
+    d = np.array([[-4.878144810174007e-10, -0.00017608737629874798, -0.004121392011531156]])
+    rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)     # the reference's recursion
+    wt, wobj = osc.intersect_batch(o, d, t0, t1, traversal=2)     # the walk with the default margin
+    assert robj[0] >= 0 and wobj[0] != robj[0]
+    t, obj = _gpu_intersect(scene, o, d, exact=0)
+    assert obj[0] == wobj[0] and bits(t)[0] == bits(wt)[0]       # the heuristic's known failure, reproduced
+    t, obj = _gpu_intersect(scene, o, d, exact=1)
+    assert obj[0] == robj[0] and bits(t)[0] == bits(rt)[0]       # no culling: the reference's answer
+    # rays aimed along triangles' own planes at every angle down to 1e-12 rad, and general rays, on sliver meshes and
+    # nearly flat sheets: exact = 1 equals the recursion on all of them
+    n_hits = 0
+    for seed in (1, 2, 3, 5, 79):
+        objs, heur, scale, verts, idx = F.scene_for(seed)
+        t0, t1 = 1e-6 * scale, 1e9 * scale
+        scene = Scene(objs, t0, t1, heur, hdri, device=0)
+        osc = _oracle.OracleScene(objs, t0, t1, heur, hdri)
+        rr = np.random.default_rng(seed * 104729 + 5)
+        og, dg = F.rays_for(rr, verts, scale, 20_000)
+        oz, dz, eps = F.grazing_rays(rr, verts, idx, scale, 60_000)
+        assert (eps < 1e-9).any() and (eps > 1e-5).any()
+        o, d = np.ascontiguousarray(np.vstack([og, oz])), np.ascontiguousarray(np.vstack([dg, dz]))
+        rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)
+        t, obj = _gpu_intersect(scene, o, d, exact=1)
+        assert np.array_equal(obj, robj) and np.array_equal(bits(t), bits(rt)), seed
+        n_hits += int((robj >= 0).sum())
+    assert n_hits > 50_000
 
 
 MATERIALS = {

@@ -164,7 +164,7 @@ def test_segments_of_whole_tiles_are_resolved_behind_their_launch():
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
     cam = rayrs_amd.Camera(*cam_args)
     one, st1 = rayrs_amd.render(scene, cam, 64, 32, seed=9, sample_chunk=4, out_f64=True)
-    scene.set_tuning(pool_slots=65536)
+    scene.lab_set(local_segment_items=65536)
     many, stn = rayrs_amd.render(scene, cam, 64, 32, seed=9, sample_chunk=4, out_f64=True)
     assert st1["kernel_launches"] == 1 and stn["kernel_launches"] == 7   # 390 tiles x 16 chunks x 64 = 399360 items
     assert stn["rays"] == st1["rays"] and stn["paths"] == 203 * 117 * 64

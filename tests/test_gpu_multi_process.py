@@ -38,3 +38,21 @@ def test_bench_with_n_ranks_assembles_the_single_rank_frame(world):
     assert many["rays_per_step"] == one["rays_per_step"]
     assert many["config"]["sample_chunk"] == one["config"]["sample_chunk"]
     assert many["scaling"] == "strong" and many["value"] > 0
+
+
+def test_bench_with_one_rank_runs_the_rccl_reduce():
+    """The RCCL calls of an N-GPU run -- init_process_group("nccl", device_id=...), one reduce of the framebuffer on
+    the render's stream, the all_reduce of the timing line -- executed on the one GPU there is: bench.py under
+    torch.distributed.run with ONE rank and --force-dist.  A reduce over one rank must leave the frame alone (sha256
+    equal to the plain run's) and RCCL must really be what ran (librccl mapped into the process)."""
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
+    port = 29700 + (os.getpid() % 1000)
+    forced = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                  "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1",
+                  "--force-dist", "--backend", "nccl"] + COMMON)
+    assert one["config"]["collective"] is None
+    coll = forced["config"]["collective"]
+    assert coll["backend"] == "nccl" and coll["world"] == 1 and coll["forced_single_rank"]
+    assert coll["librccl_mapped"] and "librccl" in coll["librccl_mapped"]
+    assert forced["framebuffer_sha256"] == one["framebuffer_sha256"]
+    assert forced["rays_per_step"] == one["rays_per_step"] and forced["n_gpus"] == 1

@@ -101,7 +101,7 @@ def test_traversal_stack_overflow_strip():
     strip (device_path.h LaneStack).  With only two entries in LDS nearly every query uses the
     strip; the frame and the work counters must not change."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 64, 48, 4)
-    scene.set_tuning(stack_lds=2)
+    scene.lab_set(stack_lds=2)
     assert scene.info()["wide_depth"] > 8
     img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
     ref, ost = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
@@ -213,6 +213,50 @@ def test_render_multi_on_logical_ranks_equals_the_single_device_frame(n, lit):
     assert_same_frame(img64, ref)
 
 
+@pytest.mark.parametrize("route", ["streaming", "local_pool"])
+def test_render_multi_runs_its_rccl_reduce_on_one_device(route):
+    """What a multi-GPU node executes after the ranks have rendered -- dlopen of librccl, ncclCommInitAll, the grouped
+    in-place ncclReduce to rank 0 -- is skipped when every handle sits on one device (there is nothing to reduce).
+    rayrs_lab.h force_rccl runs it anyway, with a communicator of that one device: the frame must not change by a bit,
+    with one handle and with three (summed on the device first), on either route, and librccl must really be mapped."""
+    fn = (lambda: scenes.mesh_scene(3, area_light=True)) if route == "streaming" else scenes.cook_torrance_spheres_metallic
+    scene, cam, osc, ocam = both(fn, 77, 45, 6)
+    assert scene.info()["local_pool"] == (1 if route == "local_pool" else 0)
+    full, st = rayrs_amd.render(scene, cam, 6, sample_chunk=4)
+    scene.lab_set(force_rccl=1)
+    clones = [scene] + [scene.clone_to_device(0) for _ in range(2)]   # clones take the scene's settings along
+    for handles in (clones[:1], clones):
+        img, mst = rayrs_amd.render_multi(handles, cam, 6, sample_chunk=4)
+        assert np.array_equal(img.view(np.uint32), full.view(np.uint32)), len(handles)
+        assert mst["rays"] == st["rays"] and mst["paths"] == st["paths"] == 77 * 45 * 6
+        assert mst["local_pool"] == st["local_pool"]
+    assert any("librccl" in line for line in open("/proc/self/maps")), "RCCL was never loaded"
+    img64, _ = rayrs_amd.render_multi(clones, cam, 6, sample_chunk=4, out_f64=True)   # ncclFloat64
+    ref, _ = osc.render(ocam, 6, sample_chunk=4)
+    assert_same_frame(img64, ref)
+
+
+def test_exact_traversal_renders_the_same_frame_with_more_visits():
+    """rayrs_render_params.exact_traversal = 1: nothing is culled by the closest hit so far -- the reference's own
+    visit set (bvh.rs:391-415).  The frame is the oracle's and the default's; the walk visits more records and tests
+    more primitives (what the default saves), and equals the oracle's walk with its margin set to infinity."""
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 96, 64, 4)
+    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, exact_traversal=True)
+    ref, ost = osc.render(ocam, 4, traversal=0)
+    assert_same_frame(a, ref)
+    assert_same_frame(b, ref)
+    assert sa["rays"] == sb["rays"] == ost["rays"]
+    assert sb["interior_visits"] > sa["interior_visits"] and sb["tri_tests"] > sa["tri_tests"]
+    try:
+        _oracle.set_cull_margin(float("inf"))
+        _, wst = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
+    finally:
+        _oracle.set_cull_margin(2.0 ** -10)
+    for k in ("interior_visits", "tri_tests", "plane_tests"):
+        assert sb[k] == wst[k], k
+
+
 def test_render_multi_rejects_bad_handles():
     from rayrs_amd import _ffi
     scene, cam, osc, ocam = both(scenes.diffuse_single_sphere, 16, 16, 1)
@@ -243,24 +287,47 @@ def test_glass_on_a_triangle_mesh():
     assert_same_frame(img, ref)
 
 
-def test_two_pipelines_render_the_same_frame():
-    """rayrs_tuning.pipelines = 2: the pool as two halves on two streams (one half's hit/miss kernels beside the
-    other's traversal kernel).  Items are handed out in a different order, every item's samples are still
-    summed in order: the frame must not change by a bit, nor the ray count."""
-    _two_pipelines(True)
-    _two_pipelines(False)  # one-line slots
-
-
-def _two_pipelines(lit):
+@pytest.mark.parametrize("lit", [True, False])
+def test_item_streams_and_pool_regions_render_the_same_frame(lit):
+    """The streaming route cuts the rank's tiles into item streams and the pool into as many regions, one per XCD
+    (wavefront.h WfDev); a region's slots take their items from its stream, then from the others, and a traversal
+    wave takes its region's windows, then the others'.  Who renders an item never changes it: 1, 2, 4 and 8
+    streams -- also with a pool so small that most regions run dry and steal at once -- give the same bits, the same
+    counts, and the oracle's frame."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), 256, 256, 16)
+    scene.lab_set(streams=1)
     one, st1 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
-    scene.set_tuning(pipelines=2, trav_blocks_per_cu=4)
-    two, st2 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
-    assert st2["kernel_launches"] > st1["kernel_launches"]  # two traversal launches per round
-    assert st1["rays"] == st2["rays"] and st1["paths"] == st2["paths"]
-    assert np.array_equal(one.view(np.uint64), two.view(np.uint64))
     ref, ost = osc.render(ocam, 16, sample_chunk=4, rows=(120, 136))
-    assert np.array_equal(two[120:136].view(np.uint64), ref[120:136].view(np.uint64))
+    assert np.array_equal(one[120:136].view(np.uint64), ref[120:136].view(np.uint64))
+    for streams, pool in ((2, 0), (4, 0), (8, 0), (8, 8192), (4, 3072), (0, 0)):
+        scene.lab_set(streams=streams)
+        scene.set_tuning(pool_slots=pool)
+        img, st = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
+        assert st["rays"] == st1["rays"] and st["paths"] == st1["paths"] == 256 * 256 * 16, (streams, pool)
+        assert st["escaped_paths"] == st1["escaped_paths"]
+        assert np.array_equal(one.view(np.uint64), img.view(np.uint64)), (streams, pool)
+
+
+@pytest.mark.parametrize("w,h,ranks", [(200, 120, 1), (203, 117, 3), (256, 64, 8), (61, 19, 2), (512, 512, 8)])
+def test_tile_order_is_a_permutation_of_the_ranks_tiles(w, h, ranks):
+    """Tiles become items band by band, each band column by column (layout.h TileOrder), so that the items in flight
+    together cover a block of the image.  Any band height -- one row, more rows than the grid has, a ragged last row,
+    a last band of one row -- must enumerate every tile of the rank exactly once: each rank's frame equals the
+    row-major order's frame bit for bit, on exactly the rank's pixels."""
+    from rayrs_amd import tiles
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(2), w, h, 4)
+    for rank in sorted({0, ranks - 1, ranks // 2}):
+        scene.lab_set(band_rows=0xffffffff, streams=1)   # row-major tiles, one stream: the order until round 3
+        want = np.full((h, w, 3), -1.0)
+        _, st0 = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=want)
+        mask = tiles.tile_mask(w, h, rank, ranks)
+        assert (want[~mask] == -1.0).all() and (want[mask] != -1.0).any()
+        for rows in (1, 2, 3, 5, 7, 1000, 0):
+            scene.lab_set(band_rows=rows, streams=2)
+            got = np.full((h, w, 3), -1.0)
+            _, st = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=got)
+            assert st["rays"] == st0["rays"] and st["paths"] == st0["paths"] == int(mask.sum()) * 4, (rank, rows)
+            assert np.array_equal(want.view(np.uint64), got.view(np.uint64)), (rank, rows)
 
 
 def _mesh_from(origin, lookat):
@@ -369,12 +436,12 @@ def test_random_scenes_render_the_oracles_frame(seed):
 def test_light_side_array_eager_and_on_demand():
     """A path's light is +0 until it meets an emitter, and lives in a side array only from then on (wavefront.h
     PathSlot).  Where a surface emits the kernels request the side entry with the slot (eager); elsewhere they
-    would fetch it on demand.  rayrs_tuning.eager_light forces the eager kernels on a scene without emitters:
+    would fetch it on demand.  rayrs_lab.h eager_light forces the eager kernels on a scene without emitters:
     same frame.  The scene WITH an emissive rectangle exercises the stored light, and must equal the oracle."""
     for fn, chunk in ((lambda: scenes.mesh_scene(3), 4), (scenes.material_test, 0), (scenes.glass_single_sphere, 5)):
         scene, cam, osc, ocam = both(fn, 72, 40, 12)
         demand, st1 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
-        scene.set_tuning(eager_light=1)
+        scene.lab_set(eager_light=1)
         eager, st2 = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True)
         ref, ost = osc.render(ocam, 12, 50, sample_chunk=chunk, traversal=0)
         for k in ("rays", "paths", "escaped_paths", "nan_pixels", "neg_pixels"):
@@ -395,23 +462,3 @@ def test_light_side_array_eager_and_on_demand():
     ref, ost = osc.render(ocam, 16, 50, sample_chunk=4, traversal=0)
     assert st["rays"] == ost["rays"]
     assert_same_frame(img, ref)
-
-
-@pytest.mark.parametrize("lit,w,h,spp,chunk", [(True, 200, 120, 8, 0), (False, 96, 64, 12, 4), (True, 61, 19, 5, 2)])
-def test_stream_pool_renders_the_streaming_kernels_frame(lit, w, h, spp, chunk):
-    """rayrs_tuning.stream_pool = 1 (an experiment of round 3, off by default): everything of a path except its deep
-    BVH walks in one kernel that keeps the path in LDS between two walks (stream_pool.hip) -- queries that enter no
-    interior slot of the walk tree's root record are answered there.  Same frame bits, same ray / path / escaped
-    counts and the walk's own work counters as the hit and miss kernels and the oracle; no item is lost when slots
-    change waves' pools (200 x 120 x 8 lost 14 pixels' items in the first version, which dealt windows dynamically)."""
-    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), w, h, spp)
-    a, sa = rayrs_amd.render(scene, cam, spp, 50, seed=7, sample_chunk=chunk, out_f64=True, count_work=True)
-    scene.set_tuning(stream_pool=1)
-    b, sb = rayrs_amd.render(scene, cam, spp, 50, seed=7, sample_chunk=chunk, out_f64=True, count_work=True)
-    assert sa["local_pool"] == 0 and sb["local_pool"] == 2
-    ref, ost = osc.render(ocam, spp, 50, seed=7, sample_chunk=chunk, traversal=0)
-    assert_same_frame(b, ref)
-    assert_same_frame(a, ref)
-    for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "surface_hits"):
-        assert sa[k] == sb[k], k
-    assert sb["rays"] == ost["rays"] and sb["paths"] == ost["paths"] == w * h * spp
