@@ -23,7 +23,6 @@ using namespace rayrs;
 
 namespace {
 thread_local std::string g_last_error;
-constexpr double TRAV_CULL_MARGIN_HOST = 1.0 + 0x1p-10;  // device_path.h TRAV_CULL_MARGIN (a device-only header)
 constexpr uint32_t TRAV_STACK_LDS = 12;
 constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 }  // namespace
@@ -543,7 +542,7 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
-    sc.cull_margin = exact ? (double)INFINITY : TRAV_CULL_MARGIN_HOST;
+    sc.exact = exact ? 1u : 0u;
     return sc;
 }
 
@@ -562,30 +561,6 @@ static CameraDev make_camera_dev(const rayrs_camera* c) {
     cam.W = c->x_pixels;
     cam.H = c->y_pixels;
     return cam;
-}
-
-// The order in which a rank's tiles become items (layout.h TileOrder): bands of `rows` grid rows, column by column.
-static TileOrder make_tile_order(uint32_t n_local, uint32_t tiles_x, uint32_t tile_ranks, uint32_t rows_wanted) {
-    TileOrder to;
-    std::memset(&to, 0, sizeof(to));
-    if (rows_wanted == 0u || n_local == 0u) return to;  // row-major
-    // the local tiles as a grid: when the ranks divide a row of tiles a grid row IS an image row of this rank's tiles;
-    // otherwise a grid row is tiles_x consecutive local tiles (tile_ranks image rows' worth)
-    to.width = tiles_x % tile_ranks == 0u ? tiles_x / tile_ranks : tiles_x;
-    const uint32_t grid_rows = (n_local + to.width - 1u) / to.width;
-    to.ragged = n_local % to.width;
-    to.rows = rows_wanted < grid_rows ? rows_wanted : grid_rows;
-    const uint32_t n_bands = (grid_rows + to.rows - 1u) / to.rows;
-    to.band_cells = to.rows * to.width;
-    to.last_base = (n_bands - 1u) * to.rows;
-    to.last_first = to.last_base * to.width;
-    to.last_rows = grid_rows - to.last_base;
-    to.last_cut = to.ragged ? to.ragged * to.last_rows : to.last_rows * to.width;
-    to.inv_band_cells = 1.0 / (double)to.band_cells;
-    to.inv_rows = 1.0 / (double)to.rows;
-    to.inv_last_rows = 1.0 / (double)to.last_rows;
-    to.inv_last_rows_m1 = to.last_rows > 1u ? 1.0 / (double)(to.last_rows - 1u) : 1.0;
-    return to;
 }
 
 int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const rayrs_render_params* params,
@@ -635,7 +610,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.out = out_device;
     rp.counters = scene->d_counters;
     rp.n_streams = 1;
-    rp.stream_end[0] = rp.total_items;
+    StreamTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    tab.n_streams = 1;
+    tab.stream_end[0] = rp.total_items;
 
     // Item sums: 24 bytes per (pixel, chunk) item, added per pixel in chunk order by the resolve kernel.  The streaming
     // kernels finish items in no particular order, so the array covers the frame.  The local-pool route renders the frame
@@ -704,7 +682,23 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     WfDev wf = pl.wf;
     uint32_t flat_blocks = 0;
     if (!use_local && rp.total_items > 0) {  // (the local-pool route keeps its paths in LDS)
-        const uint32_t np = (uint32_t)((live_total + 1023ull) & ~1023ull);  // whole windows
+        uint32_t np = (uint32_t)((live_total + 1023ull) & ~1023ull);  // whole windows
+        // ---- item streams and pool regions (wavefront.h StreamTable): one per XCD when the pool is large enough for that
+        // to mean anything -- at least 64 windows (32 k slots) and 16 tiles per stream; rayrs_lab.h streams overrides
+        uint32_t ns = lab.streams ? lab.streams : MAX_STREAMS;
+        {
+            const uint32_t n_win0 = np / wf_window_slots();
+            if (lab.streams) {
+                while (ns > 1u && (n_win0 < ns || n_local < ns)) ns /= 2u;  // (a test may ask for tiny regions; not for empty ones)
+            } else {
+                while (ns > 1u && (n_win0 < 64u * ns || n_local < 16u * ns)) ns /= 2u;
+            }
+        }
+        const uint32_t granule_shift = lab.region_granule ? lab.region_granule - 1u : 0xffffffffu;
+        if (granule_shift != 0xffffffffu) {  // interleaved regions: whole granules for every region (padding slots are DEAD)
+            const uint32_t unit = (wf_window_slots() * ns) << granule_shift;
+            np = (np + unit - 1u) / unit * unit;
+        }
         const size_t block_bytes = (size_t)np * (slot_bytes + 1u);
         if (block_bytes > pl.block_bytes || !pl.block) {
             if (pl.block) HIP_TRY(hipFree(pl.block));
@@ -719,37 +713,36 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         wf = pl.wf;
         wf.np = np;
         const uint32_t n_windows = np / wf_window_slots();
-
-        // ---- item streams and pool regions (wavefront.h WfDev): one per XCD when the pool is large enough for that
-        // to mean anything -- at least 64 windows (32 k slots) and 16 tiles per stream; rayrs_lab.h streams overrides
-        uint32_t ns = lab.streams ? lab.streams : MAX_STREAMS;
-        if (lab.streams) {
-            while (ns > 1u && (n_windows < ns || n_local < ns)) ns /= 2u;  // (a test may ask for tiny regions; not for empty ones)
-        } else {
-            while (ns > 1u && (n_windows < 64u * ns || n_local < 16u * ns)) ns /= 2u;
+        tab.granule_shift = granule_shift;
+        rp.n_streams = tab.n_streams = ns;
+        tab.stream_shift = ns == 8u ? 3u : ns == 4u ? 2u : ns == 2u ? 1u : 0u;
+        // tiles become items stripe by stripe, each stripe row by row; by default one stripe per stream
+        {
+            const uint32_t width = tile_grid_width(rp.tiles_x, rp.tile_ranks);
+            uint32_t cols = (width + ns - 1u) / ns;
+            if (lab.stripe_cols == 0xffffffffu) cols = 0;
+            else if (lab.stripe_cols) cols = lab.stripe_cols;
+            rp.order = make_tile_order((uint32_t)n_local, rp.tiles_x, rp.tile_ranks, cols);
         }
-        rp.n_streams = wf.n_streams = ns;
-        wf.stream_shift = ns == 8u ? 3u : ns == 4u ? 2u : ns == 2u ? 1u : 0u;
-        for (uint32_t s = 0; s < ns; s++) {
-            rp.stream_end[s] = (n_local * (s + 1u) / ns) * tile_items;  // whole tiles
-            wf.win_lo[s] = (uint32_t)((uint64_t)n_windows * s / ns);
+        {
+            // a stream is a stripe when there are as many of one as of the other (the last also takes the ragged row's
+            // tiles); otherwise an equal share of the tiles in item order
+            const TileOrder& to = rp.order;
+            const uint32_t n_stripes = to.cols ? (to.width + to.cols - 1u) / to.cols : 0u;
+            for (uint32_t s = 0; s < ns; s++) {
+                uint64_t end_tile = n_local * (s + 1u) / ns;
+                if (n_stripes == ns) end_tile = s + 1u < ns ? (uint64_t)(s + 1u) * to.stripe_cells : n_local;
+                tab.stream_end[s] = end_tile * tile_items;  // whole tiles
+                tab.win_lo[s] = (uint32_t)((uint64_t)n_windows * s / ns);
+            }
         }
-        wf.win_lo[ns] = n_windows;
+        tab.win_lo[ns] = n_windows;
+        if (granule_shift != 0xffffffffu) tab.win_lo[1] = n_windows / ns;  // interleaved: every region's window count
         for (uint32_t s = 0; s < ns; s++) {
             // whole round-robin rounds covering about static_pct % of the region's windows
-            const uint64_t n = wf.win_lo[s + 1] - wf.win_lo[s], n_waves = (uint64_t)((trav_blocks - s + ns - 1u) / ns) * 4u;
-            wf.win_static[s] = n_waves ? (uint32_t)(n * static_pct / 100u / n_waves * n_waves) : 0u;
-        }
-        // tiles become items band by band, each band column by column: by default a band is what one stream holds
-        // of the grid's rows (the streams' tiles are then blocks of the image), at most 32 rows
-        {
-            const uint32_t width = rp.tiles_x % rp.tile_ranks == 0u ? rp.tiles_x / rp.tile_ranks : rp.tiles_x;
-            const uint32_t grid_rows = (uint32_t)((n_local + width - 1u) / width);
-            uint32_t rows = (grid_rows + ns - 1u) / ns;
-            if (rows > 32u) rows = 32u;
-            if (lab.band_rows == 0xffffffffu) rows = 0;
-            else if (lab.band_rows) rows = lab.band_rows;
-            rp.order = make_tile_order((uint32_t)n_local, rp.tiles_x, rp.tile_ranks, rows);
+            const uint64_t n = granule_shift != 0xffffffffu ? n_windows / ns : tab.win_lo[s + 1] - tab.win_lo[s];
+            const uint64_t n_waves = (uint64_t)((trav_blocks - s + ns - 1u) / ns) * 4u;
+            tab.win_static[s] = n_waves ? (uint32_t)(n * static_pct / 100u / n_waves * n_waves) : 0u;
         }
 
         // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three: one
@@ -843,7 +836,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
         scene->rounds = (uint32_t)n_seg;
     } else if (rp.total_items > 0) {
-        HIP_TRY(wf_launch_init(rp, wf, (uint32_t)live_total, stream));
+        HIP_TRY(wf_launch_init(rp, wf, tab, (uint32_t)live_total, stream));
         HIP_TRY(wf_launch_gen(compact, sc, cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
         pl.h_live[0] = pl.h_live[1] = (uint32_t)live_total;
         // Rounds are enqueued in batches; the live-slot count of batch b is read back while batch b+1 is

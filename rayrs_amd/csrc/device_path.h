@@ -274,12 +274,12 @@ RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 // is decided from it.
 constexpr uint32_t TRAV_DONE = 0xffffffffu;
 // Closest-hit culling is the one place where the walk departs from the reference's: BvhTree::intersect never culls
-// (bvh.rs:391-415), the walk skips a slot whose box is entered beyond best_t * SceneDev::cull_margin.  That loses a
+// (bvh.rs:391-415), the walk skips a slot whose box is entered beyond best_t * TRAV_CULL_MARGIN.  That loses a
 // hit only if a primitive's COMPUTED t lies in front of the entry parameter of a box around it by more than the margin
 // AND another accepted hit falls in between.  Moeller-Trumbore's t has a relative error of about eps * (distance / size)
 // / (grazing angle) -- unbounded as the ray approaches the triangle's plane -- and which triangles lie behind a box is
 // not known without reading them, so NO margin computed from the ray and the box alone is sound: culling is either off
-// (cull_margin = +infinity, rayrs_render_params.exact_traversal: the reference's visit set by construction, at the
+// (EXACT: the margin is +infinity, rayrs_render_params.exact_traversal: the reference's visit set by construction, at the
 // reference's cost) or a bet.  The default margin is the bet measured with scripts/fuzz_traversal.py
 // (profiles/r03_fuzz_traversal.txt: 10^8 rays on sliver meshes and nearly flat sheets, origins up to 10^6 scene sizes
 // away): rays at 10^-7 rad and more off a triangle's plane put t at most 2^-11.1 in front of a box; between 10^-9 and
@@ -294,19 +294,15 @@ constexpr double TRAV_CULL_MARGIN = 1.0 + 0x1p-10;
 // instead of the bound is what lets five workgroups share a CU on the 1M-triangle scene.
 struct LaneStack {
     uint32_t* lds;  // cap entries and one spare (never read) that branch-free pushes may scribble on
-    uint32_t* spill_base;  // wave-uniform: the strips of all threads of the launch; this lane's is found from its thread
-                           // index when an entry does go there (a per-lane pointer would live in two registers for good)
+    uint32_t* spill;
     uint32_t cap, stride;
-    RR_DEV size_t spill_at(int k) const {
-        uint32_t tid = blockIdx.x * 256u + threadIdx.x;  // workgroups of 256 threads
-        asm volatile("" : "+v"(tid));  // (worked out where it is used: hoisted out of the walk it costs the loop two registers)
-        return (size_t)((uint32_t)k - cap) * stride + tid;
-    }
     RR_DEV void put(int k, uint32_t v) const {
         if ((uint32_t)k < cap) lds[k * 64] = v;
-        else spill_base[spill_at(k)] = v;
+        else spill[(size_t)((uint32_t)k - cap) * stride] = v;
     }
-    RR_DEV uint32_t get(int k) const { return (uint32_t)k < cap ? lds[k * 64] : spill_base[spill_at(k)]; }
+    RR_DEV uint32_t get(int k) const {
+        return (uint32_t)k < cap ? lds[k * 64] : spill[(size_t)((uint32_t)k - cap) * stride];
+    }
 };
 
 struct Trav {
@@ -375,7 +371,7 @@ struct HotNodes {
     RR_DEV static constexpr uint32_t stride() { return COMPACT ? 9u : 17u; }  // granules
 };
 
-template <bool COMPACT, bool COUNT>
+template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
                                WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
@@ -427,7 +423,7 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     // Unused slots need no special case here: they carry the inverted box (scene_host.cpp), for
     // which the slab test above says "missed".  Boxes entered beyond the closest hit so far are
-    // skipped -- beyond it by SceneDev::cull_margin (see TRAV_CULL_MARGIN): a primitive's computed t and the entry parameter of the
+    // skipped -- beyond it by TRAV_CULL_MARGIN (unless EXACT): a primitive's computed t and the entry parameter of the
     // box around it are rounded independently (and t badly so on grazing rays), so a hit computed in
     // front of its own box must not be lost to a farther one (every primitive that is tested is judged
     // by the reference's rule, so a wider margin only costs visits, never the answer).
@@ -435,7 +431,9 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // compare writes its mask to a scalar register pair) and combined there: "b before a" and its complement are
     // one comparison and one scalar operation, where the compiler, given lane booleans, issues a second f64
     // compare for every complement.
-    const double cull = tv.best_t * sc.cull_margin;
+    // (a compile-time choice: the margin as a kernel argument is one more scalar pair alive across the walk, which the
+    // traversal kernel answers by re-loading arguments from memory inside its loop -- +27 % kernel time, measured)
+    const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
     const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
     const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
@@ -506,7 +504,7 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
-template <bool COMPACT, bool COUNT>
+template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
@@ -514,7 +512,7 @@ RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack
     const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
-            trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
+            trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
         else
             trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }

@@ -117,14 +117,15 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // sc.stack_lds entries of the stack in LDS, the rest in the strip `spill` (as in the traversal kernel)
-    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill, sc.stack_lds,
+    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill + i, sc.stack_lds,
                           gridDim.x * blockDim.x};
     if (i >= n) return;
     double t = 0.0;
     uint32_t prim = 0;
     WorkCount wc{0, 0, 0, 0, 0};
-    const bool hit = bvh_intersect<COMPACT, false>(sc, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]),
-                                                   mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), stack, t, prim, wc);
+    const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const bool hit = sc.exact ? bvh_intersect<COMPACT, false, true>(sc, ro, rd, stack, t, prim, wc)
+                              : bvh_intersect<COMPACT, false, false>(sc, ro, rd, stack, t, prim, wc);
     t_out[i] = hit ? t : 0.0;
     prim_out[i] = hit ? (long long)prim : -1ll;
 }

@@ -33,8 +33,11 @@ typedef struct {
     uint32_t force_rccl;    /* rayrs_render_multi: run the RCCL reduce even when every handle sits on one device
                                (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
     uint32_t streams;       /* streaming route: item streams / pool regions (one per XCD), 1..8 (8) */
-    uint32_t band_rows;     /* streaming route: tile rows per band of the column-major tile order, 0 = default,
+    uint32_t stripe_cols;   /* streaming route: width, in columns of the rank's tile grid, of the vertical stripes in
+                               which tiles become items (layout.h TileOrder); 0 = default (one stripe per stream),
                                0xffffffff = row-major tiles (the order until round 3) */
+    uint32_t region_granule; /* streaming route: 0 = a pool region is one contiguous range of windows; g + 1 = regions are
+                               interleaved 2^g windows at a time */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

@@ -100,20 +100,30 @@ constexpr uint32_t FEED_LIST = WINDOW + 64;  // entries per wave
 // (b / n_streams) * 4 + wave-in-workgroup of the region's waves.  Wave-uniform.
 struct StreamSeat {
     uint32_t stream, wave, n_waves;  // region, index among its waves, number of its waves
-    uint32_t win_lo, win_hi;         // the region's windows
+    uint32_t n_win;                  // windows in the region
 };
+// the k-th window of region s
+RR_DEV uint32_t region_window(const StreamTable& tab, uint32_t s, uint32_t k) {
+    if (tab.granule_shift == 0xffffffffu) return tab.win_lo[s] + k;
+    const uint32_t g = tab.granule_shift;
+    return ((((k >> g) << tab.stream_shift) + s) << g) + (k & ((1u << g) - 1u));
+}
+RR_DEV uint32_t region_windows(const StreamTable& tab, uint32_t s) {
+    return tab.granule_shift == 0xffffffffu ? tab.win_lo[s + 1u] - tab.win_lo[s] : tab.win_lo[1];
+}
 RR_DEV StreamSeat stream_seat(const WfDev& wf) {
     StreamSeat st;
-    const uint32_t ns = wf.n_streams, sh = wf.stream_shift;  // ns = 1 << sh
+    const StreamTable& tab = wf.ctl->tab;
+    const uint32_t ns = tab.n_streams, sh = tab.stream_shift;  // ns = 1 << sh
     st.stream = blockIdx.x & (ns - 1u);
     st.wave = (blockIdx.x >> sh) * 4u + (threadIdx.x >> 6);
     st.n_waves = ((gridDim.x - st.stream + ns - 1u) >> sh) * 4u;
-    st.win_lo = wf.win_lo[st.stream], st.win_hi = wf.win_lo[st.stream + 1u];
+    st.n_win = region_windows(tab, st.stream);
     return st;
 }
 
 struct BatchFeed {
-    uint32_t next_win, n_waves, win_hi, count, k, total;  // wave-uniform
+    uint32_t next_win, n_waves, win_hi, stream, count, k, total;  // wave-uniform; next_win, win_hi: region-relative
     StateWords ahead;                                     // state bytes of window next_win
     uint8_t want;
     uint32_t* list;
@@ -137,10 +147,10 @@ RR_DEV uint32_t compact_words_abs(const StateWords& sw, uint8_t want, uint32_t b
 
 // the seat's windows win_lo + wave, + n_waves, ... of its region
 RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, const StreamSeat& seat, uint8_t want, uint32_t* list) {
-    f.next_win = seat.win_lo + seat.wave, f.n_waves = seat.n_waves, f.win_hi = seat.win_hi;
+    f.next_win = seat.wave, f.n_waves = seat.n_waves, f.win_hi = seat.n_win, f.stream = seat.stream;
     f.count = 0, f.k = 0, f.total = 0, f.want = want, f.list = list;
     f.ahead.w[0] = f.ahead.w[1] = 0;
-    if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, f.next_win);
+    if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, region_window(wf.ctl->tab, f.stream, f.next_win));
 }
 
 // Next batch: false when the wave's windows are exhausted.
@@ -150,12 +160,12 @@ RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid
         const uint32_t left = f.count - f.k;  // < 64: one entry per lane, moved to the front
         const uint32_t carry = lane < left ? f.list[f.k + lane] : 0u;
         if (lane < left) f.list[lane] = carry;
-        const uint32_t fresh = compact_words_abs(f.ahead, f.want, f.next_win * WINDOW, f.list + left);
+        const uint32_t fresh = compact_words_abs(f.ahead, f.want, region_window(wf.ctl->tab, f.stream, f.next_win) * WINDOW, f.list + left);
         f.total += fresh;
         f.count = left + fresh;
         f.k = 0;
         f.next_win += f.n_waves;
-        if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, f.next_win);
+        if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, region_window(wf.ctl->tab, f.stream, f.next_win));
     }
     if (f.k >= f.count) return false;
     valid = f.k + lane < f.count;
@@ -187,14 +197,15 @@ RR_DEV double* light_slot(const WfDev& wf, uint32_t slot) { return wf.light + (s
 
 // ------------------------------------------------------------------- init
 
-__global__ void __launch_bounds__(256) wf_init_kernel(RenderDev rp, WfDev wf, uint32_t live) {
+__global__ void __launch_bounds__(256) wf_init_kernel(RenderDev rp, WfDev wf, StreamTable tab, uint32_t live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         WfCtl* c = wf.ctl;
         for (uint32_t s = 0; s < MAX_STREAMS; s++) c->next_window[s] = 0;
         c->live_slots = live;
+        c->tab = tab;
     }
-    if (i < rp.n_streams) rp.next_item[i] = i ? rp.stream_end[i - 1u] : 0ull;  // every stream's counter at its first item
+    if (i < tab.n_streams) rp.next_item[i] = i ? tab.stream_end[i - 1u] : 0ull;  // every stream's counter at its first item
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
@@ -262,7 +273,7 @@ RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r)
 
 // Refills an empty range from the streams' counters, the wave's own stream first.  False when every stream has run
 // out.  Wave-uniform (one lane asks, all lanes get the answer).
-RR_DEV bool refill_item_range(const RenderDev& rp, uint32_t own_stream, ItemRange& range) {
+RR_DEV bool refill_item_range(const RenderDev& rp, const WfDev& wf, uint32_t own_stream, ItemRange& range) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t all = (1u << rp.n_streams) - 1u;
     while (range.gone != all) {
@@ -273,7 +284,7 @@ RR_DEV bool refill_item_range(const RenderDev& rp, uint32_t own_stream, ItemRang
         const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
         const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
         first = ((unsigned long long)fhi << 32) | flo;
-        const unsigned long long end = rp.stream_end[s];
+        const unsigned long long end = wf.ctl->tab.stream_end[s];
         if (first >= end) {
             range.gone |= 1u << s;
             continue;
@@ -326,7 +337,7 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         bool dead = false;
         unsigned long long need_mask = __ballot(need);
         while (need_mask != 0ull) {
-            if (range.next >= range.end && !refill_item_range(rp, own_stream, range)) {  // wave-uniform
+            if (range.next >= range.end && !refill_item_range(rp, wf, own_stream, range)) {  // wave-uniform
                 if (need) dead = true;  // every stream has run out: these slots are done
                 break;
             }
@@ -421,7 +432,8 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const StreamSeat seat = stream_seat(wf);
     SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
-    for (uint32_t win = seat.win_lo + seat.wave; win < seat.win_hi; win += seat.n_waves) {
+    for (uint32_t rel = seat.wave; rel < seat.n_win; rel += seat.n_waves) {
+        const uint32_t win = region_window(wf.ctl->tab, seat.stream, rel);
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
@@ -444,7 +456,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-template <bool COMPACT, bool COUNT>
+template <bool COMPACT, bool COUNT, bool EXACT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -452,7 +464,8 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
-    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, wf.stack_spill, sc.stack_lds, wf.trav_threads};
+    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane,
+                          wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
     uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u) + wave * WINDOW;
     uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u + 4u * WINDOW / 2u);
     {
@@ -476,8 +489,9 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     // everything.
     // (what says which windows are the wave's is worked out again each time a window is fetched, once per 512 slots:
     // kept across the traversal loop, those scalars crowd the register file the loop needs)
-    uint32_t static_next = (blockIdx.x >> wf.stream_shift) * 4u + wave;  // wave-uniform: next of the wave's dealt windows (region-relative)
+    uint32_t static_next = (blockIdx.x >> ctl->tab.stream_shift) * 4u + wave;  // wave-uniform: next of the wave's dealt windows (region-relative)
     uint32_t steal = 0;                                                  // wave-uniform: regions whose cursor the wave has seen run out
+    const bool deal_all = ctl->live_slots < wf.np / 4u;                  // (read once: its line belongs to the hit and miss kernels' atomics)
     uint32_t list_pos = 0, list_len = 0, list_base = 0;  // wave-uniform
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
@@ -516,23 +530,23 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                 if (list_pos >= list_len) {
                     uint32_t w = 0xffffffffu;
                     const StreamSeat seat = stream_seat(wf);
-                    const bool deal_all = ctl->live_slots < wf.np / 4u;
-                    const uint32_t static_windows = deal_all ? seat.win_hi - seat.win_lo : wf.win_static[seat.stream];
+                    const StreamTable& tab = ctl->tab;
+                    const uint32_t static_windows = deal_all ? seat.n_win : tab.win_static[seat.stream];
                     if (static_next < static_windows) {
-                        w = seat.win_lo + static_next;
+                        w = region_window(tab, seat.stream, static_next);
                         static_next += seat.n_waves;
                     } else {
                         // the region's cursor, then the others' in turn
-                        while (steal < wf.n_streams) {
-                            const uint32_t r = (seat.stream + steal) & (wf.n_streams - 1u);
-                            const uint32_t lo = wf.win_lo[r], n = wf.win_lo[r + 1u] - lo;
+                        while (steal < tab.n_streams) {
+                            const uint32_t r = (seat.stream + steal) & (tab.n_streams - 1u);
+                            const uint32_t n = region_windows(tab, r);
                             // (a region's dealt share is its own waves': its cursor starts behind it)
-                            const uint32_t r_static = deal_all ? n : wf.win_static[r];
+                            const uint32_t r_static = deal_all ? n : tab.win_static[r];
                             uint32_t k = 0;
                             if (lane == 0) k = atomicAdd(&ctl->next_window[r], 1u);
                             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                             if (r_static + k < n) {
-                                w = lo + r_static + k;
+                                w = region_window(tab, r, r_static + k);
                                 break;
                             }
                             steal++;
@@ -588,7 +602,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                trav_interior_step<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
+                trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -845,8 +859,8 @@ static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t
 
 uint32_t wf_window_slots() { return WINDOW; }
 
-hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, uint32_t live, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, rp, wf, live);
+hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, const StreamTable& tab, uint32_t live, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, rp, wf, tab, live);
     return hipGetLastError();
 }
 
@@ -861,7 +875,8 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -876,7 +891,10 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
 
 template <bool COMPACT, bool COUNT>
 static hipError_t trav_set_lds(uint32_t lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -886,11 +904,11 @@ hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_reco
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false>, 256, lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, false>, 256, lds);
     }
     if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
     if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, false>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,

@@ -310,20 +310,20 @@ def test_item_streams_and_pool_regions_render_the_same_frame(lit):
 
 @pytest.mark.parametrize("w,h,ranks", [(200, 120, 1), (203, 117, 3), (256, 64, 8), (61, 19, 2), (512, 512, 8)])
 def test_tile_order_is_a_permutation_of_the_ranks_tiles(w, h, ranks):
-    """Tiles become items band by band, each band column by column (layout.h TileOrder), so that the items in flight
-    together cover a block of the image.  Any band height -- one row, more rows than the grid has, a ragged last row,
-    a last band of one row -- must enumerate every tile of the rank exactly once: each rank's frame equals the
-    row-major order's frame bit for bit, on exactly the rank's pixels."""
+    """Tiles become items stripe by stripe, each stripe row by row (layout.h TileOrder), so that the items in flight
+    together cover a block of the image per stream.  Any stripe width -- one column, wider than the grid, a narrower
+    last stripe, a ragged last grid row, a grid of less than one row -- must enumerate every tile of the rank exactly
+    once: each rank's frame equals the row-major order's frame bit for bit, on exactly the rank's pixels."""
     from rayrs_amd import tiles
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(2), w, h, 4)
     for rank in sorted({0, ranks - 1, ranks // 2}):
-        scene.lab_set(band_rows=0xffffffff, streams=1)   # row-major tiles, one stream: the order until round 3
+        scene.lab_set(stripe_cols=0xffffffff, streams=1)   # row-major tiles, one stream: the order until round 3
         want = np.full((h, w, 3), -1.0)
         _, st0 = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=want)
         mask = tiles.tile_mask(w, h, rank, ranks)
         assert (want[~mask] == -1.0).all() and (want[mask] != -1.0).any()
         for rows in (1, 2, 3, 5, 7, 1000, 0):
-            scene.lab_set(band_rows=rows, streams=2)
+            scene.lab_set(stripe_cols=rows, streams=2 if rows != 3 else 8)
             got = np.full((h, w, 3), -1.0)
             _, st = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=got)
             assert st["rays"] == st0["rays"] and st["paths"] == st0["paths"] == int(mask.sum()) * 4, (rank, rows)
