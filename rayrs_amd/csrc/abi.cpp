@@ -311,7 +311,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         HIP_TRY(hipHostMalloc((void**)&pl.h_live, 2 * sizeof(uint32_t), hipHostMallocDefault));
         for (auto& e : pl.ev_batch) HIP_TRY(hipEventCreate(&e));
     }
-    HIP_TRY(hipMalloc((void**)&s->d_next_item, MAX_STREAMS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&s->d_next_item, sizeof(unsigned long long)));
     if (s->local_ok) {
         HIP_TRY(lp_configure());
         // (from about 13 primitives and surface rows up three workgroups' LDS no longer fit a CU: ask, do not assume)
@@ -447,8 +447,6 @@ int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
-    if (lab->streams != 0u && lab->streams != 1u && lab->streams != 2u && lab->streams != 4u && lab->streams != 8u)
-        return RAYRS_INVALID_ARG;
     const int st = scene_quiesce(scene);
     if (st != RAYRS_OK) return st;
     scene->lab = *lab;
@@ -534,6 +532,8 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.hdri = s->d_hdri;
     sc.hdri_w = s->flat.hdri_w;
     sc.hdri_h = s->flat.hdri_h;
+    sc.hdri_wm1 = (double)(s->flat.hdri_w - 1u);
+    sc.hdri_hm1 = (double)(s->flat.hdri_h - 1u);
     sc.root_ref = s->flat.wide_root_ref;
     sc.stack_depth = s->flat.wide_depth ? s->flat.wide_depth : 1;
     sc.stack_lds = s->stack_lds;
@@ -609,11 +609,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.out_format = params->out_format;
     rp.out = out_device;
     rp.counters = scene->d_counters;
-    rp.n_streams = 1;
-    StreamTable tab;
-    std::memset(&tab, 0, sizeof(tab));
-    tab.n_streams = 1;
-    tab.stream_end[0] = rp.total_items;
 
     // Item sums: 24 bytes per (pixel, chunk) item, added per pixel in chunk order by the resolve kernel.  The streaming
     // kernels finish items in no particular order, so the array covers the frame.  The local-pool route renders the frame
@@ -682,23 +677,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     WfDev wf = pl.wf;
     uint32_t flat_blocks = 0;
     if (!use_local && rp.total_items > 0) {  // (the local-pool route keeps its paths in LDS)
-        uint32_t np = (uint32_t)((live_total + 1023ull) & ~1023ull);  // whole windows
-        // ---- item streams and pool regions (wavefront.h StreamTable): one per XCD when the pool is large enough for that
-        // to mean anything -- at least 64 windows (32 k slots) and 16 tiles per stream; rayrs_lab.h streams overrides
-        uint32_t ns = lab.streams ? lab.streams : MAX_STREAMS;
-        {
-            const uint32_t n_win0 = np / wf_window_slots();
-            if (lab.streams) {
-                while (ns > 1u && (n_win0 < ns || n_local < ns)) ns /= 2u;  // (a test may ask for tiny regions; not for empty ones)
-            } else {
-                while (ns > 1u && (n_win0 < 64u * ns || n_local < 16u * ns)) ns /= 2u;
-            }
-        }
-        const uint32_t granule_shift = lab.region_granule ? lab.region_granule - 1u : 0xffffffffu;
-        if (granule_shift != 0xffffffffu) {  // interleaved regions: whole granules for every region (padding slots are DEAD)
-            const uint32_t unit = (wf_window_slots() * ns) << granule_shift;
-            np = (np + unit - 1u) / unit * unit;
-        }
+        const uint32_t np = (uint32_t)((live_total + 1023ull) & ~1023ull);  // whole windows
         const size_t block_bytes = (size_t)np * (slot_bytes + 1u);
         if (block_bytes > pl.block_bytes || !pl.block) {
             if (pl.block) HIP_TRY(hipFree(pl.block));
@@ -713,44 +692,17 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         wf = pl.wf;
         wf.np = np;
         const uint32_t n_windows = np / wf_window_slots();
-        tab.granule_shift = granule_shift;
-        rp.n_streams = tab.n_streams = ns;
-        tab.stream_shift = ns == 8u ? 3u : ns == 4u ? 2u : ns == 2u ? 1u : 0u;
-        // tiles become items stripe by stripe, each stripe row by row; by default one stripe per stream
         {
-            const uint32_t width = tile_grid_width(rp.tiles_x, rp.tile_ranks);
-            uint32_t cols = (width + ns - 1u) / ns;
-            if (lab.stripe_cols == 0xffffffffu) cols = 0;
-            else if (lab.stripe_cols) cols = lab.stripe_cols;
-            rp.order = make_tile_order((uint32_t)n_local, rp.tiles_x, rp.tile_ranks, cols);
-        }
-        {
-            // a stream is a stripe when there are as many of one as of the other (the last also takes the ragged row's
-            // tiles); otherwise an equal share of the tiles in item order
-            const TileOrder& to = rp.order;
-            const uint32_t n_stripes = to.cols ? (to.width + to.cols - 1u) / to.cols : 0u;
-            for (uint32_t s = 0; s < ns; s++) {
-                uint64_t end_tile = n_local * (s + 1u) / ns;
-                if (n_stripes == ns) end_tile = s + 1u < ns ? (uint64_t)(s + 1u) * to.stripe_cells : n_local;
-                tab.stream_end[s] = end_tile * tile_items;  // whole tiles
-                tab.win_lo[s] = (uint32_t)((uint64_t)n_windows * s / ns);
-            }
-        }
-        tab.win_lo[ns] = n_windows;
-        if (granule_shift != 0xffffffffu) tab.win_lo[1] = n_windows / ns;  // interleaved: every region's window count
-        for (uint32_t s = 0; s < ns; s++) {
-            // whole round-robin rounds covering about static_pct % of the region's windows
-            const uint64_t n = granule_shift != 0xffffffffu ? n_windows / ns : tab.win_lo[s + 1] - tab.win_lo[s];
-            const uint64_t n_waves = (uint64_t)((trav_blocks - s + ns - 1u) / ns) * 4u;
-            tab.win_static[s] = n_waves ? (uint32_t)(n * static_pct / 100u / n_waves * n_waves) : 0u;
+            // whole round-robin rounds covering about static_pct % of the pool's windows
+            const uint64_t n_waves = (uint64_t)trav_blocks * 4u;
+            rp.static_windows = (uint32_t)((uint64_t)n_windows * static_pct / 100u / n_waves * n_waves);
         }
 
         // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three: one
-        // wave per window, at most eight workgroups per CU, and as many workgroups for every region
+        // wave per window, at most eight workgroups per CU
         uint32_t fb = (n_windows + 3u) / 4u;
         const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
         if (fb > flat_cap) fb = flat_cap;
-        fb = (fb + ns - 1u) / ns * ns;
         flat_blocks = fb;
         wf.n_flat_waves = fb * 4u;
         if (wf.n_flat_waves > pl.wave_items_cap) {
@@ -779,6 +731,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     pl.timed_rounds = 0;
 
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(Counters), stream));
+    HIP_TRY(hipMemsetAsync(scene->d_next_item, 0, sizeof(unsigned long long), stream));
     if (use_local) HIP_TRY(hipMemsetAsync(scene->d_local_items, 0, LOCAL_MAX_SEGMENTS * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(scene->ev[0], stream));
     scene->rounds = 0;
@@ -836,7 +789,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
         scene->rounds = (uint32_t)n_seg;
     } else if (rp.total_items > 0) {
-        HIP_TRY(wf_launch_init(rp, wf, tab, (uint32_t)live_total, stream));
+        HIP_TRY(wf_launch_init(wf, (uint32_t)live_total, stream));
         HIP_TRY(wf_launch_gen(compact, sc, cam, rp, wf, flat_blocks, stream));  // initial fill; later samples start in hit/miss
         pl.h_live[0] = pl.h_live[1] = (uint32_t)live_total;
         // Rounds are enqueued in batches; the live-slot count of batch b is read back while batch b+1 is

@@ -27,6 +27,12 @@ struct V3 {
     double x, y, z;
 };
 
+// Number of set bits of a wave mask below this lane: the rank of a lane in a ballot (v_mbcnt: no per-lane
+// "lanes below me" mask has to live in two registers for it).
+RR_DEV uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 RR_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
 RR_DEV V3 v_add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 RR_DEV V3 v_sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -883,8 +889,8 @@ RR_DEV V3 background(const SceneDev& sc, V3 dir) {
     dir = v_unit(dir);
     const double phi = rr_atan2(dir.z, dir.x) + RR_PI;
     const double theta = rr_acos(dir.y);
-    const double x = phi / (2.0 * RR_PI) * (double)(sc.hdri_w - 1);
-    const double y = theta / RR_PI * (double)(sc.hdri_h - 1);
+    const double x = phi / (2.0 * RR_PI) * sc.hdri_wm1;
+    const double y = theta / RR_PI * sc.hdri_hm1;
     const double x_f = rr_floor(x), x_c = rr_ceil(x), y_f = rr_floor(y), y_c = rr_ceil(y);
     const uint32_t i = f64_as_index(y_f);
     const uint32_t j = f64_as_index(x_f);

@@ -14,8 +14,8 @@ __global__ void __launch_bounds__(256) resolve_kernel(CameraDev cam, RenderDev r
     const uint64_t n = (uint64_t)n_lt * 64u;  // the rank's tiles lt0 .. lt0 + n_lt - 1
     if (idx >= n) return;
     const uint32_t pit = (uint32_t)(idx & 63u);
-    const uint32_t lt = lt0 + (uint32_t)(idx >> 6);  // in item order (layout.h TileOrder)
-    const uint32_t tile = local_tile_of(rp.order, lt) * rp.tile_ranks + rp.tile_rank;
+    const uint32_t lt = lt0 + (uint32_t)(idx >> 6);
+    const uint32_t tile = lt * rp.tile_ranks + rp.tile_rank;
     const uint32_t row = (tile / rp.tiles_x) * 8u + (pit >> 3);
     const uint32_t col = (tile % rp.tiles_x) * 8u + (pit & 7u);
     if (row >= cam.H || col >= cam.W) return;

@@ -101,6 +101,8 @@ struct SceneDev {
     uint32_t pad0;
     double root_box[6];
     double t0, t1;  // Scene::t_range, lib.rs:218
+    double hdri_wm1, hdri_hm1;  // (hdri_w - 1) as f64 and (hdri_h - 1) as f64, lib.rs:262-263 (converted on the host: a kernel
+                                // that converts them hoists the results into vector registers for its whole run)
     // rayrs_render_params.exact_traversal: the walk culls nothing by the closest hit so far, as BvhTree::intersect
     // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
     uint32_t exact, pad1;
@@ -123,29 +125,6 @@ struct Counters {
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
 };
 
-// Item streams (wavefront.hip): the rank's tiles, in item order, are cut into n_streams contiguous ranges, each with an
-// item counter of its own; the pool's windows are cut into as many regions, region s served by the workgroups of one
-// XCD and fed from stream s first (from the others once it has run out).
-constexpr uint32_t MAX_STREAMS = 8;
-
-// The order in which a rank's tiles become items.  Row-major until round 3; now stripe by stripe: the rank's LOCAL tiles
-// l = 0 .. n_local - 1 (global tile t = l * tile_ranks + tile_rank, row-major in the image) are laid out as a grid `width`
-// wide, the grid's full rows are cut into vertical stripes `cols` columns wide, and a stripe is walked row by row.  With
-// one stripe per item stream (wavefront.h StreamTable) the tiles whose items are in flight together form one block of the
-// image per stream -- all at about the same height, so that the streams hold the same mix of sky, floor and mesh --
-// instead of one strip across it.  The cells of a ragged last grid row keep their places at the end.
-struct TileOrder {
-    uint32_t cols;          // stripe width in grid columns; 0 = row-major (no permutation)
-    uint32_t width;         // local tiles per grid row
-    uint32_t rect;          // tiles in the grid's full rows: item-order tiles from here on are not permuted
-    uint32_t stripe_cells;  // cols * full rows
-    uint32_t last_first;    // first item-order tile of the last stripe (which may be narrower)
-    uint32_t last_col0;     // its first grid column
-    uint32_t last_cols;     // its width
-    uint32_t pad;
-    double inv_stripe_cells, inv_cols, inv_last_cols;  // reciprocals for udiv_by()
-};
-
 struct RenderDev {
     uint32_t spp, max_bounces;
     uint64_t seed;
@@ -157,12 +136,11 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
+    uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
-    uint32_t n_streams;             // item streams = pool regions, 1 .. MAX_STREAMS (wavefront.h StreamTable)
-    TileOrder order;
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)
     uint64_t partial_item0;
-    unsigned long long* next_item;  // n_streams item counters; counter s starts at stream s's first item
+    unsigned long long* next_item;  // device-wide item counter
     Counters* counters;
     void* out;
 };
@@ -184,52 +162,12 @@ RR_LAYOUT_FN uint32_t udiv_by(uint32_t n, uint32_t d, double inv_d, uint32_t& re
     return q;
 }
 
-// Item-order tile j of the rank -> its local tile l (TileOrder above).
-RR_LAYOUT_FN uint32_t local_tile_of(const TileOrder& to, uint32_t j) {
-    if (to.cols == 0u || j >= to.rect) return j;
-    uint32_t row, c, col0;
-    if (j < to.last_first) {
-        uint32_t rem;
-        col0 = udiv_by(j, to.stripe_cells, to.inv_stripe_cells, rem) * to.cols;
-        row = udiv_by(rem, to.cols, to.inv_cols, c);
-    } else {
-        col0 = to.last_col0;
-        row = udiv_by(j - to.last_first, to.last_cols, to.inv_last_cols, c);
-    }
-    return row * to.width + col0 + c;
-}
-
-// Host side of TileOrder: the grid's width, and the order for stripes `cols_wanted` columns wide (0 = row-major).
-static inline uint32_t tile_grid_width(uint32_t tiles_x, uint32_t tile_ranks) {
-    // when the ranks divide a row of tiles a grid row IS an image row of this rank's tiles; otherwise a grid row is
-    // tiles_x consecutive local tiles (tile_ranks image rows' worth)
-    return tiles_x % tile_ranks == 0u ? tiles_x / tile_ranks : tiles_x;
-}
-static inline TileOrder make_tile_order(uint32_t n_local, uint32_t tiles_x, uint32_t tile_ranks, uint32_t cols_wanted) {
-    TileOrder to = {};
-    to.width = tile_grid_width(tiles_x, tile_ranks);
-    const uint32_t full_rows = n_local / to.width;
-    if (cols_wanted == 0u || full_rows == 0u) return to;  // row-major
-    to.cols = cols_wanted < to.width ? cols_wanted : to.width;
-    const uint32_t n_stripes = (to.width + to.cols - 1u) / to.cols;
-    to.rect = full_rows * to.width;
-    to.stripe_cells = to.cols * full_rows;
-    to.last_first = (n_stripes - 1u) * to.stripe_cells;
-    to.last_col0 = (n_stripes - 1u) * to.cols;
-    to.last_cols = to.width - to.last_col0;
-    to.inv_stripe_cells = 1.0 / (double)to.stripe_cells;
-    to.inv_cols = 1.0 / (double)to.cols;
-    to.inv_last_cols = 1.0 / (double)to.last_cols;
-    return to;
-}
-
 // The pixel, and the sample range, of item `item`: 64 pixels of a tile x the tile's chunks (main.rs:65-68).
 RR_LAYOUT_FN void item_geometry(const RenderDev& rp, uint32_t item, uint32_t& row, uint32_t& col, uint32_t& s_begin,
                                 uint32_t& s_end) {
     const uint32_t pit = item & 63u;
     uint32_t chunk, tile_col;
-    const uint32_t j = udiv_by(item >> 6, rp.nchunks, rp.inv_nchunks, chunk);
-    const uint32_t tile = local_tile_of(rp.order, j) * rp.tile_ranks + rp.tile_rank;
+    const uint32_t tile = udiv_by(item >> 6, rp.nchunks, rp.inv_nchunks, chunk) * rp.tile_ranks + rp.tile_rank;
     row = udiv_by(tile, rp.tiles_x, rp.inv_tiles_x, tile_col) * 8u + (pit >> 3);
     col = tile_col * 8u + (pit & 7u);
     s_begin = chunk * rp.chunk;

@@ -111,7 +111,6 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
                        const RenderDev& rp, const LocalDev& lp, LpRange& range, LpCount& n, V3& ray_o, V3& ray_d,
                        V3& ray_inv) {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     const uint32_t w = pl.u(U_SCUR, p);
     bool has_item = valid && (w >> 31) != 0u;
     uint32_t s_cur = w & SLOT_SAMPLE_MASK, item = pl.u(U_ITEM, p);
@@ -143,7 +142,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
             range.end = (uint64_t)first + lp.reserve < lp.item_count ? first + lp.reserve : (uint32_t)lp.item_count;
         }
         const uint32_t avail = range.end - range.next;
-        const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+        const uint32_t rank = lanes_below(need_mask);
         if (need && rank < avail) {
             item = (uint32_t)(lp.item_base + range.next + rank);
             uint32_t s_begin;
@@ -268,56 +267,70 @@ RR_DEV uint32_t lp_background(const Pool& pl, bool valid, uint32_t p, const Scen
 }
 
 // ---- SHADE_k: lib.rs:528-551 for a closest hit on a surface of material kind k (wave-uniform).
+// A path's fields wait in LDS; each is read where it is needed and not before -- position and direction for the normal
+// and the view vector, the draw index for the RNG, and throughput, light, bounce and cursor only BEHIND
+// Material::evaluate, whose arms need the registers (held across it, they cost the kernel 16 spilled registers at
+// three workgroups per CU).
 template <bool COMPACT>
 RR_DEV uint32_t lp_shade(const Pool& pl, bool valid, uint32_t p, int kind, const CameraDev& cam, const RenderDev& rp,
                          const LocalDev& lp, const SurfaceDev* s_surf, const uint4* s_prims, uint32_t& hit_sid) {
-    const V3 position = pl.v3(F_OX, p), d = pl.v3(F_DX, p);
-    V3 thr = pl.v3(F_TX, p);
     const uint32_t prim = valid ? pl.u(U_PRIM, p) : 0u;
-    const uint32_t bd = pl.u(U_BD, p), w = pl.u(U_SCUR, p);
-    const uint32_t bounce = bd & LP_BOUNCE_MASK;
-    // the RNG key of the sample in flight: the item's pixel and the sample before the cursor
-    uint32_t row, col, s_first, s_end;
-    item_geometry(rp, pl.u(U_ITEM, p), row, col, s_first, s_end);
-    Rng rng{rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)((w & SLOT_SAMPLE_MASK) - 1u)), bd >> 16};
-    V3 light = mk(0.0, 0.0, 0.0);
-    if (valid && ((w >> 30) & 1u)) {
-        const double* l = lp_light(lp, p);
-        light = mk(l[0], l[1], l[2]);
-    }
     const PrimRec<COMPACT> rec = load_prim_lds<COMPACT>(s_prims, prim);
-    const V3 normal = prim_normal<COMPACT>(rec, position);
-    const V3 view = v_unit(v_scale(d, -1.0));
     const uint32_t sid = rec.tag() >> 8;
     hit_sid = valid ? (sid < 7u ? sid : 7u) : 8u;
     const SurfaceDev* surf = &s_surf[sid];
-    const Scatter ev = material_evaluate_kind(kind, surf, normal, view, rng);
-    bool goes_on = false;
-    if (ev.scatter) {
-        light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
-        thr = v_mul(thr, ev.color);
-        const double pr = rr_max(rr_max(thr.x, thr.y), thr.z);
-        if (!(rng.next() > pr) && bounce < rp.max_bounces) {  // roulette lib.rs:539; loop bound lib.rs:525, :559
-            thr = mk(thr.x / pr, thr.y / pr, thr.z / pr);     // DivAssign, vecmath.rs:708-714
-            goes_on = true;
+    Scatter ev;
+    uint32_t draw;
+    {
+        const V3 normal = prim_normal<COMPACT>(rec, pl.v3(F_OX, p));   // F_OX holds the hit position (lp_isect)
+        const V3 view = v_unit(v_scale(pl.v3(F_DX, p), -1.0));
+        // the RNG key of the sample in flight: the item's pixel and the sample before the cursor
+        uint32_t row, col, s_first, s_end;
+        item_geometry(rp, pl.u(U_ITEM, p), row, col, s_first, s_end);
+        Rng rng{rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)((pl.u(U_SCUR, p) & SLOT_SAMPLE_MASK) - 1u)),
+                pl.u(U_BD, p) >> 16};
+        ev = material_evaluate_kind(kind, surf, normal, view, rng);
+        draw = rng.draw;
+        if (ev.scatter) {  // the roulette's draw (lib.rs:539), taken here so that the key need not outlive the block
+            const double u = rng.next();
+            draw = rng.draw;
+            const uint32_t bd = pl.u(U_BD, p), w = pl.u(U_SCUR, p);
+            const uint32_t bounce = bd & LP_BOUNCE_MASK;
+            V3 thr = pl.v3(F_TX, p);
+            V3 light = mk(0.0, 0.0, 0.0);
+            if (valid && ((w >> 30) & 1u)) {
+                const double* l = lp_light(lp, p);
+                light = mk(l[0], l[1], l[2]);
+            }
+            light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
+            thr = v_mul(thr, ev.color);
+            const double pr = rr_max(rr_max(thr.x, thr.y), thr.z);
+            if (!valid) return LP_DEAD;
+            if (!(u > pr) && bounce < rp.max_bounces) {            // roulette lib.rs:539; loop bound lib.rs:525, :559
+                thr = mk(thr.x / pr, thr.y / pr, thr.z / pr);     // DivAssign, vecmath.rs:708-714
+                pl.set_v3(F_DX, p, ev.dir);                        // (F_OX keeps the position: the new ray's origin)
+                pl.set_v3(F_TX, p, thr);
+                pl.u(U_BD, p) = (bounce + 1u) | (draw << 16);
+                const bool keep_light = !((rr_f64_bits(light.x) | rr_f64_bits(light.y) | rr_f64_bits(light.z)) == 0ull);
+                if (keep_light) {
+                    double* l = lp_light(lp, p);
+                    l[0] = light.x, l[1] = light.y, l[2] = light.z;
+                }
+                pl.u(U_SCUR, p) = (w & ~SLOT_LIGHT_BIT) | (keep_light ? SLOT_LIGHT_BIT : 0u);
+                return LP_ISECT;
+            }
+            // radiance() returns `light` (lib.rs:559, or the roulette's return); main.rs:69 adds it to the pixel
+            pl.f(F_AX, p) += light.x, pl.f(F_AY, p) += light.y, pl.f(F_AZ, p) += light.z;
+            return LP_GEN;
         }
     }
+    // NoScatter: radiance() returns `light` without the surface's emission (lib.rs:550)
     if (!valid) return LP_DEAD;
-    if (goes_on) {
-        pl.set_v3(F_OX, p, position);
-        pl.set_v3(F_DX, p, ev.dir);
-        pl.set_v3(F_TX, p, thr);
-        pl.u(U_BD, p) = (bounce + 1u) | (rng.draw << 16);
-        const bool keep_light = !((rr_f64_bits(light.x) | rr_f64_bits(light.y) | rr_f64_bits(light.z)) == 0ull);
-        if (keep_light) {
-            double* l = lp_light(lp, p);
-            l[0] = light.x, l[1] = light.y, l[2] = light.z;
-        }
-        pl.u(U_SCUR, p) = (w & ~SLOT_LIGHT_BIT) | (keep_light ? SLOT_LIGHT_BIT : 0u);
-        return LP_ISECT;
+    const uint32_t w = pl.u(U_SCUR, p);
+    if ((w >> 30) & 1u) {
+        const double* l = lp_light(lp, p);
+        pl.f(F_AX, p) += l[0], pl.f(F_AY, p) += l[1], pl.f(F_AZ, p) += l[2];
     }
-    // radiance() returns `light` (lib.rs:550, :559, or the roulette's return); main.rs:69 adds it to the pixel
-    pl.f(F_AX, p) += light.x, pl.f(F_AY, p) += light.y, pl.f(F_AZ, p) += light.z;
     return LP_GEN;
 }
 
@@ -351,7 +364,6 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
     extern __shared__ __align__(16) unsigned char lp_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     unsigned char* base = lp_lds + wave * LP_WAVE_BYTES;
     Pool pl;
     pl.f64 = reinterpret_cast<double*>(base);
@@ -401,8 +413,8 @@ __global__ void __launch_bounds__(256, LP_WPS) lp_path_kernel(SceneDev sc, Local
         const bool m0 = st0 == ph, m1 = st1 == ph;
         const unsigned long long mask0 = __ballot(m0), mask1 = __ballot(m1);
         const uint32_t n0 = (uint32_t)__popcll(mask0);
-        if (m0) pl.list[__popcll(mask0 & lanemask_lt)] = (uint8_t)lane;
-        const uint32_t r1 = n0 + (uint32_t)__popcll(mask1 & lanemask_lt);
+        if (m0) pl.list[lanes_below(mask0)] = (uint8_t)lane;
+        const uint32_t r1 = n0 + lanes_below(mask1);
         if (m1 && r1 < 64u) pl.list[r1] = (uint8_t)(lane + 64u);
         const uint32_t count = most < 64u ? most : 64u;
         const bool valid = lane < count;

@@ -20,7 +20,7 @@ extern "C" {
 typedef struct {
     uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
     uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (32) */
-    uint32_t static_pct;    /* traversal: share of a stream's windows dealt round robin, 1..100 (50) */
+    uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
     uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
     uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
                                0xffffffff = none */
@@ -32,12 +32,6 @@ typedef struct {
                                as far as needed to keep a frame within 64 segments */
     uint32_t force_rccl;    /* rayrs_render_multi: run the RCCL reduce even when every handle sits on one device
                                (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
-    uint32_t streams;       /* streaming route: item streams / pool regions (one per XCD), 1..8 (8) */
-    uint32_t stripe_cols;   /* streaming route: width, in columns of the rank's tile grid, of the vertical stripes in
-                               which tiles become items (layout.h TileOrder); 0 = default (one stripe per stream),
-                               0xffffffff = row-major tiles (the order until round 3) */
-    uint32_t region_granule; /* streaming route: 0 = a pool region is one contiguous range of windows; g + 1 = regions are
-                               interleaved 2^g windows at a time */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

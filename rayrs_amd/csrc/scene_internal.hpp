@@ -53,7 +53,7 @@ struct rayrs_scene {
         uint32_t timed_rounds = 0;
     };
     Pool pool;
-    unsigned long long* d_next_item = nullptr;  // the item counters, one per stream (layout.h MAX_STREAMS)
+    unsigned long long* d_next_item = nullptr;  // the device-wide item counter
     uint32_t rounds = 0;
     // Scenes whose walk tree is at most one record are rendered by local_pool.hip: every path resident in LDS.
     bool local_ok = false;

@@ -57,34 +57,16 @@ constexpr uint8_t WF_HIT = 2;    // closest hit found: hit_kernel's input
 constexpr uint8_t WF_MISS = 3;   // no hit: miss_kernel's input
 constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)
 
-// Pool regions and item streams.  Region s = the windows win_lo[s] .. win_lo[s + 1] - 1 of the pool, worked on by the
-// workgroups b with b % n_streams == s -- workgroups are dealt round robin over the 8 XCDs, so a region stays with one
-// XCD (two or four for fewer regions) -- and its slots take their items from stream s first: the items stream_end[s - 1]
-// (0 for s = 0) .. stream_end[s] - 1, whole tiles, with a counter of their own (RenderDev::next_item[s]).  So the rays
-// an XCD's L2 sees come from one part of the image.  Placement is for speed only; nothing depends on it.
-// The table lives in device memory, not in the kernel arguments: the kernels index it with run-time values, and an
-// argument structure that is indexed that way is read from memory field by field, inside the traversal loop too
-// (measured: +27 % traversal time).
-struct StreamTable {
-    uint32_t n_streams, stream_shift;  // n_streams = 1 << stream_shift: 1, 2, 4 or 8
-    uint32_t win_lo[MAX_STREAMS + 1];
-    uint32_t win_static[MAX_STREAMS];  // leading windows of a region dealt round robin to its traversal waves (whole rounds)
-    uint32_t granule_shift;  // 0xffffffff: a region is a contiguous range of windows (win_lo); else regions are interleaved
-                             // 1 << granule_shift windows at a time, every region holding win_lo[1] windows
-    uint64_t stream_end[MAX_STREAMS];
-};
-
-// Three 128-byte lines, by who writes them: the window cursors take the traversal kernel's atomics, live_slots the hit
-// and miss kernels', the table nobody's.  A scalar load from a line that atomics are hammering pays the trip to memory
-// every time -- the table and live_slots in the cursors' line cost the traversal kernel 27 %, one such load per window.
+// Two 128-byte lines, by who writes them: the window cursor takes the traversal kernel's atomics, live_slots the hit and
+// miss kernels'.  A scalar load from a line that atomics are hammering pays the trip to memory every time: live_slots
+// read in the cursor's line once per window fetch cost the traversal kernel 27 % (profiles/r04_xcd_streams.txt).
 struct alignas(128) WfCtl {
-    uint32_t next_window[MAX_STREAMS];  // per pool region: cursor over the windows the traversal kernel hands out on demand
-    uint32_t pad0[32 - MAX_STREAMS];
-    uint32_t live_slots;                // slots that still have or can get work
+    uint32_t next_window;  // cursor over the windows the traversal kernel hands out on demand
+    uint32_t pad0[31];
+    uint32_t live_slots;   // slots that still have or can get work
     uint32_t pad1[31];
-    StreamTable tab;                    // written by wf_init_kernel, read-only afterwards
 };
-static_assert(sizeof(StreamTable) == 144 && offsetof(WfCtl, live_slots) == 128 && offsetof(WfCtl, tab) == 256, "WfCtl lines");
+static_assert(offsetof(WfCtl, live_slots) == 128 && sizeof(WfCtl) == 256, "WfCtl lines");
 
 struct WfDev {
     PathSlot* slots;
@@ -103,7 +85,7 @@ struct WfDev {
 };
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
-hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, const StreamTable& tab, uint32_t live, hipStream_t stream);
+hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream);
 hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,

@@ -52,7 +52,7 @@ RR_DEV StateWords load_state_words(const WfDev& wf, uint32_t win) {
 
 RR_DEV uint32_t compact_words(const StateWords& sw, uint8_t want, uint16_t* list) {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;  // (v_mbcnt here costs the traversal kernel its last registers)
     const uint32_t* words = sw.w;
     uint32_t count = 0;
 #pragma unroll
@@ -96,34 +96,8 @@ RR_DEV uint32_t compact_window_ready(const WfDev& wf, uint32_t win, uint16_t* li
 // frame's 58 % / 34 % of a window that is 4.6 instead of 5 and 2.7 instead of 3 batches per window.
 constexpr uint32_t FEED_LIST = WINDOW + 64;  // entries per wave
 
-// A wave's place in its stream (WfDev: pool regions): workgroup b serves region b % n_streams, as wave
-// (b / n_streams) * 4 + wave-in-workgroup of the region's waves.  Wave-uniform.
-struct StreamSeat {
-    uint32_t stream, wave, n_waves;  // region, index among its waves, number of its waves
-    uint32_t n_win;                  // windows in the region
-};
-// the k-th window of region s
-RR_DEV uint32_t region_window(const StreamTable& tab, uint32_t s, uint32_t k) {
-    if (tab.granule_shift == 0xffffffffu) return tab.win_lo[s] + k;
-    const uint32_t g = tab.granule_shift;
-    return ((((k >> g) << tab.stream_shift) + s) << g) + (k & ((1u << g) - 1u));
-}
-RR_DEV uint32_t region_windows(const StreamTable& tab, uint32_t s) {
-    return tab.granule_shift == 0xffffffffu ? tab.win_lo[s + 1u] - tab.win_lo[s] : tab.win_lo[1];
-}
-RR_DEV StreamSeat stream_seat(const WfDev& wf) {
-    StreamSeat st;
-    const StreamTable& tab = wf.ctl->tab;
-    const uint32_t ns = tab.n_streams, sh = tab.stream_shift;  // ns = 1 << sh
-    st.stream = blockIdx.x & (ns - 1u);
-    st.wave = (blockIdx.x >> sh) * 4u + (threadIdx.x >> 6);
-    st.n_waves = ((gridDim.x - st.stream + ns - 1u) >> sh) * 4u;
-    st.n_win = region_windows(tab, st.stream);
-    return st;
-}
-
 struct BatchFeed {
-    uint32_t next_win, n_waves, win_hi, stream, count, k, total;  // wave-uniform; next_win, win_hi: region-relative
+    uint32_t next_win, n_waves, n_windows, count, k, total;  // wave-uniform
     StateWords ahead;                                     // state bytes of window next_win
     uint8_t want;
     uint32_t* list;
@@ -131,7 +105,6 @@ struct BatchFeed {
 
 RR_DEV uint32_t compact_words_abs(const StateWords& sw, uint8_t want, uint32_t base, uint32_t* list) {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
     const uint32_t* words = sw.w;
     uint32_t count = 0;
 #pragma unroll
@@ -139,33 +112,32 @@ RR_DEV uint32_t compact_words_abs(const StateWords& sw, uint8_t want, uint32_t b
         const uint32_t s = (words[j >> 2] >> ((j & 3) * 8)) & 0xffu;
         const bool m = s == (uint32_t)want;
         const unsigned long long mask = __ballot(m);
-        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = base + lane * SPL + (uint32_t)j;
+        if (m) list[count + lanes_below(mask)] = base + lane * SPL + (uint32_t)j;
         count += (uint32_t)__popcll(mask);
     }
     return count;
 }
 
-// the seat's windows win_lo + wave, + n_waves, ... of its region
-RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, const StreamSeat& seat, uint8_t want, uint32_t* list) {
-    f.next_win = seat.wave, f.n_waves = seat.n_waves, f.win_hi = seat.n_win, f.stream = seat.stream;
+RR_DEV void feed_init(BatchFeed& f, const WfDev& wf, uint32_t wave, uint32_t n_waves, uint8_t want, uint32_t* list) {
+    f.next_win = wave, f.n_waves = n_waves, f.n_windows = wf.np / WINDOW;
     f.count = 0, f.k = 0, f.total = 0, f.want = want, f.list = list;
     f.ahead.w[0] = f.ahead.w[1] = 0;
-    if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, region_window(wf.ctl->tab, f.stream, f.next_win));
+    if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
 }
 
 // Next batch: false when the wave's windows are exhausted.
 RR_DEV bool feed_next(BatchFeed& f, const WfDev& wf, uint32_t& slot, bool& valid) {
     const uint32_t lane = threadIdx.x & 63u;
-    while (f.count - f.k < 64u && f.next_win < f.win_hi) {
+    while (f.count - f.k < 64u && f.next_win < f.n_windows) {
         const uint32_t left = f.count - f.k;  // < 64: one entry per lane, moved to the front
         const uint32_t carry = lane < left ? f.list[f.k + lane] : 0u;
         if (lane < left) f.list[lane] = carry;
-        const uint32_t fresh = compact_words_abs(f.ahead, f.want, region_window(wf.ctl->tab, f.stream, f.next_win) * WINDOW, f.list + left);
+        const uint32_t fresh = compact_words_abs(f.ahead, f.want, f.next_win * WINDOW, f.list + left);
         f.total += fresh;
         f.count = left + fresh;
         f.k = 0;
         f.next_win += f.n_waves;
-        if (f.next_win < f.win_hi) f.ahead = load_state_words(wf, region_window(wf.ctl->tab, f.stream, f.next_win));
+        if (f.next_win < f.n_windows) f.ahead = load_state_words(wf, f.next_win);
     }
     if (f.k >= f.count) return false;
     valid = f.k + lane < f.count;
@@ -197,15 +169,13 @@ RR_DEV double* light_slot(const WfDev& wf, uint32_t slot) { return wf.light + (s
 
 // ------------------------------------------------------------------- init
 
-__global__ void __launch_bounds__(256) wf_init_kernel(RenderDev rp, WfDev wf, StreamTable tab, uint32_t live) {
+__global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         WfCtl* c = wf.ctl;
-        for (uint32_t s = 0; s < MAX_STREAMS; s++) c->next_window[s] = 0;
+        c->next_window = 0;
         c->live_slots = live;
-        c->tab = tab;
     }
-    if (i < tab.n_streams) rp.next_item[i] = i ? tab.stream_end[i - 1u] : 0ull;  // every stream's counter at its first item
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
@@ -243,58 +213,49 @@ RR_DEV uint64_t sample_key(const RenderDev& rp, const CameraDev& cam, const Item
     return rr_path_key(rp.seed, (uint64_t)(ir.pix >> 16) * cam.W + (ir.pix & 0xffffu), (uint64_t)(ir.s_cur - 1u));
 }
 
-// A wave's private range of reserved item ids [next, end).  Items are taken from a stream's counter ITEM_RESERVE
-// at a time (one atomic), not one batch at a time: with ~10^5 batches per round finishing items, per-batch atomics
-// on one counter word (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
-// A wave asks its own stream first (StreamSeat) and, once that has run out, the others in turn; `gone` has a bit
-// for every stream the wave has seen exhausted, so that at the end of a frame nobody keeps asking.  The range
-// lives in registers during a launch and in WfDev::wave_items between launches.
+// A wave's private range of reserved item ids [next, end).  Items are taken from the
+// device-wide counter ITEM_RESERVE at a time (one atomic), not one batch at a time: with
+// ~10^5 batches per round finishing items, per-batch atomics on the single counter word
+// (which saturates near 90 updates/us on this chip) would cost more than the shading itself.
+// The range lives in registers during a launch and in WfDev::wave_items between launches.
 constexpr uint32_t ITEM_RESERVE = 256;
+constexpr unsigned long long ITEMS_GONE = ~0ull;  // ItemRange::end of a wave that found the counter exhausted
 
 struct ItemRange {
     unsigned long long next, end;
-    uint32_t gone;  // bit s: stream s's counter has run out
 };
 
 RR_DEV ItemRange load_item_range(const WfDev& wf, uint32_t wave) {
     ItemRange r;
     r.next = wf.wave_items[2 * (size_t)wave];
-    const unsigned long long w = wf.wave_items[2 * (size_t)wave + 1];
-    r.end = w & 0xffffffffffffull;
-    r.gone = (uint32_t)(w >> 48);
+    r.end = wf.wave_items[2 * (size_t)wave + 1];
     return r;
 }
 RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r) {
     if ((threadIdx.x & 63u) == 0) {
         wf.wave_items[2 * (size_t)wave] = r.next;
-        wf.wave_items[2 * (size_t)wave + 1] = r.end | ((unsigned long long)r.gone << 48);
+        wf.wave_items[2 * (size_t)wave + 1] = r.end;
     }
 }
 
-// Refills an empty range from the streams' counters, the wave's own stream first.  False when every stream has run
-// out.  Wave-uniform (one lane asks, all lanes get the answer).
-RR_DEV bool refill_item_range(const RenderDev& rp, const WfDev& wf, uint32_t own_stream, ItemRange& range) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t all = (1u << rp.n_streams) - 1u;
-    while (range.gone != all) {
-        uint32_t s = own_stream;
-        while ((range.gone >> s) & 1u) s = s + 1u == rp.n_streams ? 0u : s + 1u;
-        unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(&rp.next_item[s], (unsigned long long)ITEM_RESERVE);
+// Refills an empty range from the device-wide counter.  False when the counter has run out -- which the wave then
+// remembers (range.end = ITEMS_GONE, kept in WfDev::wave_items between launches): at the end of a frame every batch of
+// every wave would otherwise ask the one counter word again, which serves ~90 atomics per microsecond.  Wave-uniform.
+RR_DEV bool refill_item_range(const RenderDev& rp, ItemRange& range) {
+    unsigned long long first = ITEMS_GONE;
+    if (range.end != ITEMS_GONE) {
+        if ((threadIdx.x & 63u) == 0) first = atomicAdd(rp.next_item, (unsigned long long)ITEM_RESERVE);
         const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)first);
         const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
         first = ((unsigned long long)fhi << 32) | flo;
-        const unsigned long long end = wf.ctl->tab.stream_end[s];
-        if (first >= end) {
-            range.gone |= 1u << s;
-            continue;
-        }
-        range.next = first;
-        range.end = first + ITEM_RESERVE < end ? first + ITEM_RESERVE : end;
-        return true;
     }
-    range.next = range.end = 0ull;
-    return false;
+    if (first >= rp.total_items) {
+        range.next = range.end = ITEMS_GONE;
+        return false;
+    }
+    range.next = first;
+    range.end = first + ITEM_RESERVE < rp.total_items ? first + ITEM_RESERVE : rp.total_items;
+    return true;
 }
 
 // What the kernels that start samples count per lane.
@@ -311,10 +272,8 @@ struct SampleCount {
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
 template <bool COMPACT>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
-                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, uint32_t own_stream,
-                        ItemRange& range, SampleCount& sn) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
+                        SampleCount& sn) {
     bool todo = want;  // lanes still without a ray for their slot
     bool has_item = want && ir.has_item != 0u;
     uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
@@ -337,12 +296,12 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         bool dead = false;
         unsigned long long need_mask = __ballot(need);
         while (need_mask != 0ull) {
-            if (range.next >= range.end && !refill_item_range(rp, wf, own_stream, range)) {  // wave-uniform
-                if (need) dead = true;  // every stream has run out: these slots are done
+            if (range.next >= range.end && !refill_item_range(rp, range)) {  // wave-uniform
+                if (need) dead = true;  // the counter has run out: these slots are done
                 break;
             }
             const uint32_t avail = (uint32_t)(range.end - range.next);
-            const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
+            const uint32_t rank = lanes_below(need_mask);
             if (need && rank < avail) {
                 item = (uint32_t)(range.next + rank);
                 uint32_t s_begin;
@@ -429,11 +388,11 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const StreamSeat seat = stream_seat(wf);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_windows = wf.np / WINDOW;
     SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
-    for (uint32_t rel = seat.wave; rel < seat.n_win; rel += seat.n_waves) {
-        const uint32_t win = region_window(wf.ctl->tab, seat.stream, rel);
+    for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
@@ -442,7 +401,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
             ItemRegs ir;
             ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
             ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;
-            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, seat.stream, range, sn);
+            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -478,20 +437,18 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     const HotNodes hot{hot_lds, sc.hot_records};
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
 
-    // A workgroup works on the windows of its pool region (StreamSeat: one region per XCD).  They are handed out in
-    // two ways.  The first static_pct % of the region are dealt round robin: the region's wave g takes its windows g,
-    // g + n_waves, ... and asks nobody.  The rest go to whoever runs dry first, through the region's atomic cursor
-    // (WfCtl::next_window), which evens out the waves' finishing times -- and a wave that finds its own region's
-    // cursor at the end goes on with the other regions' (`steal`), so that the XCDs finish together too.  All of
-    // the pool through one cursor costs a fifth of the waves' time waiting for it: a single word takes about 90
-    // atomics per microsecond on this chip.  Once most slots have run out of work (the tail of a frame, long on a
-    // small tile share) the cursors' atomics are all a launch would wait for, and balance no longer matters: deal
-    // everything.
-    // (what says which windows are the wave's is worked out again each time a window is fetched, once per 512 slots:
-    // kept across the traversal loop, those scalars crowd the register file the loop needs)
-    uint32_t static_next = (blockIdx.x >> ctl->tab.stream_shift) * 4u + wave;  // wave-uniform: next of the wave's dealt windows (region-relative)
-    uint32_t steal = 0;                                                  // wave-uniform: regions whose cursor the wave has seen run out
-    const bool deal_all = ctl->live_slots < wf.np / 4u;                  // (read once: its line belongs to the hit and miss kernels' atomics)
+    const uint32_t n_windows = wf.np / WINDOW;
+    // Windows of the pool are handed out in two ways.  The first rp.static_windows windows are
+    // dealt round robin: wave g takes g, g + n_waves, ... and asks nobody.  The rest go to whoever
+    // runs dry first, through one atomic cursor (WfCtl::next_window), which evens out the
+    // waves' finishing times.  (Round 1: all of the pool through the cursor cost a fifth of the waves'
+    // time; with persistent waves taking ~43 windows each per launch the cursor serves 25 atomics per
+    // microsecond of the ~90 it can, and a dealt share of 5 % is as good as 50 %: profiles/r04_xcd_streams.txt.)
+    // Once most slots have run out of work (the tail of a frame, long on a small tile share) the
+    // cursor's atomics are all a launch would wait for, and balance no longer matters: deal everything.
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t static_windows = ctl->live_slots < wf.np / 4u ? n_windows : rp.static_windows;
+    uint32_t static_next = blockIdx.x * 4u + wave;       // wave-uniform
     uint32_t list_pos = 0, list_len = 0, list_base = 0;  // wave-uniform
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
@@ -528,31 +485,14 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
-                    uint32_t w = 0xffffffffu;
-                    const StreamSeat seat = stream_seat(wf);
-                    const StreamTable& tab = ctl->tab;
-                    const uint32_t static_windows = deal_all ? seat.n_win : tab.win_static[seat.stream];
-                    if (static_next < static_windows) {
-                        w = region_window(tab, seat.stream, static_next);
-                        static_next += seat.n_waves;
+                    uint32_t w = static_next;
+                    if (w < static_windows) {
+                        static_next += n_waves;
                     } else {
-                        // the region's cursor, then the others' in turn
-                        while (steal < tab.n_streams) {
-                            const uint32_t r = (seat.stream + steal) & (tab.n_streams - 1u);
-                            const uint32_t n = region_windows(tab, r);
-                            // (a region's dealt share is its own waves': its cursor starts behind it)
-                            const uint32_t r_static = deal_all ? n : tab.win_static[r];
-                            uint32_t k = 0;
-                            if (lane == 0) k = atomicAdd(&ctl->next_window[r], 1u);
-                            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                            if (r_static + k < n) {
-                                w = region_window(tab, r, r_static + k);
-                                break;
-                            }
-                            steal++;
-                        }
+                        if (lane == 0) w = static_windows + atomicAdd(&ctl->next_window, 1u);
+                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
                     }
-                    if (w == 0xffffffffu) {
+                    if (w >= n_windows) {
                         no_more = true;
                         break;
                     }
@@ -677,12 +617,12 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     __syncthreads();
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const StreamSeat seat = stream_seat(wf);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     SampleCount sn{0, 0, 0};
-    if (blockIdx.x == 0 && threadIdx.x < MAX_STREAMS) wf.ctl->next_window[threadIdx.x] = 0;  // the traversal kernel's window cursors
+    if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
-    feed_init(feed, wf, seat, WF_HIT, list);
+    feed_init(feed, wf, wave, n_waves, WF_HIT, list);
     // Three fetches per hit depend on each other: slot -> primitive record -> surface row.  The slot records of
     // batch b + 1 are requested before batch b is computed; the primitive records of batch b + 1 as soon as batch
     // b's arithmetic is done -- before batch b's stores, so that the wait for them is not behind the stores
@@ -778,7 +718,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, seat.stream, range, sn);
+            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
         }
         cur = nxt;
         rec_cur = rec_nxt;
@@ -816,12 +756,12 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const StreamSeat seat = stream_seat(wf);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
     SampleCount sn{0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
-    feed_init(feed, wf, seat, WF_MISS, list);
+    feed_init(feed, wf, wave, n_waves, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
     if (have) load_miss_in<EAGER>(wf, cur);
@@ -841,7 +781,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
-        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, seat.stream, range, sn);
+        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
         cur = nxt;
         have = have_next;
     }
@@ -859,8 +799,8 @@ static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t
 
 uint32_t wf_window_slots() { return WINDOW; }
 
-hipError_t wf_launch_init(const RenderDev& rp, const WfDev& wf, const StreamTable& tab, uint32_t live, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, rp, wf, tab, live);
+hipError_t wf_launch_init(const WfDev& wf, uint32_t live, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init_kernel, dim3((wf.np + 255u) / 256u), dim3(256), 0, stream, wf, live);
     return hipGetLastError();
 }
 

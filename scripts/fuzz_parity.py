@@ -39,8 +39,6 @@ for seed in range(first, first + count):
     ocam = _oracle.OracleCamera(*cam_args)
     if seed % 5 == 0:
         scene.set_tuning(pool_slots=int(r.integers(1, 40)) * 1024)
-    if seed % 4 == 0:   # item streams / pool regions and the tile order (rayrs_lab.h): who renders an item never changes it
-        scene.lab_set(streams=int(r.choice([1, 2, 4, 8])), stripe_cols=int(r.choice([0, 1, 2, 3, 5, 0xffffffff])))
     img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
     ref0, ost0 = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)   # the reference's recursion
     ok = np.array_equal(img.view(np.uint64), ref0.view(np.uint64))

@@ -168,8 +168,8 @@ def test_tuning_is_validated_and_needs_no_gpu():
     with pytest.raises(ValueError):
         sc.set_tuning(no_such_knob=1)
     # the development knobs (rayrs_amd/csrc/rayrs_lab.h): validated too
-    sc.lab_set(stack_lds=2, refill_min=40, streams=4, stripe_cols=8, local_reserve=64, local_segment_items=65536)
-    for bad in (dict(stack_lds=65), dict(static_pct=101), dict(refill_min=65), dict(streams=3), dict(local_reserve=5),
+    sc.lab_set(stack_lds=2, refill_min=40, local_reserve=64, local_segment_items=65536)
+    for bad in (dict(stack_lds=65), dict(static_pct=101), dict(refill_min=65), dict(local_reserve=5),
                 dict(local_segment_items=1000), dict(force_rccl=2)):
         with pytest.raises(_ffi.RayrsError):
             sc.lab_set(**bad)

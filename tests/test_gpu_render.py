@@ -287,49 +287,6 @@ def test_glass_on_a_triangle_mesh():
     assert_same_frame(img, ref)
 
 
-@pytest.mark.parametrize("lit", [True, False])
-def test_item_streams_and_pool_regions_render_the_same_frame(lit):
-    """The streaming route cuts the rank's tiles into item streams and the pool into as many regions, one per XCD
-    (wavefront.h WfDev); a region's slots take their items from its stream, then from the others, and a traversal
-    wave takes its region's windows, then the others'.  Who renders an item never changes it: 1, 2, 4 and 8
-    streams -- also with a pool so small that most regions run dry and steal at once -- give the same bits, the same
-    counts, and the oracle's frame."""
-    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=lit), 256, 256, 16)
-    scene.lab_set(streams=1)
-    one, st1 = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
-    ref, ost = osc.render(ocam, 16, sample_chunk=4, rows=(120, 136))
-    assert np.array_equal(one[120:136].view(np.uint64), ref[120:136].view(np.uint64))
-    for streams, pool in ((2, 0), (4, 0), (8, 0), (8, 8192), (4, 3072), (0, 0)):
-        scene.lab_set(streams=streams)
-        scene.set_tuning(pool_slots=pool)
-        img, st = rayrs_amd.render(scene, cam, 16, sample_chunk=4, out_f64=True)
-        assert st["rays"] == st1["rays"] and st["paths"] == st1["paths"] == 256 * 256 * 16, (streams, pool)
-        assert st["escaped_paths"] == st1["escaped_paths"]
-        assert np.array_equal(one.view(np.uint64), img.view(np.uint64)), (streams, pool)
-
-
-@pytest.mark.parametrize("w,h,ranks", [(200, 120, 1), (203, 117, 3), (256, 64, 8), (61, 19, 2), (512, 512, 8)])
-def test_tile_order_is_a_permutation_of_the_ranks_tiles(w, h, ranks):
-    """Tiles become items stripe by stripe, each stripe row by row (layout.h TileOrder), so that the items in flight
-    together cover a block of the image per stream.  Any stripe width -- one column, wider than the grid, a narrower
-    last stripe, a ragged last grid row, a grid of less than one row -- must enumerate every tile of the rank exactly
-    once: each rank's frame equals the row-major order's frame bit for bit, on exactly the rank's pixels."""
-    from rayrs_amd import tiles
-    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(2), w, h, 4)
-    for rank in sorted({0, ranks - 1, ranks // 2}):
-        scene.lab_set(stripe_cols=0xffffffff, streams=1)   # row-major tiles, one stream: the order until round 3
-        want = np.full((h, w, 3), -1.0)
-        _, st0 = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=want)
-        mask = tiles.tile_mask(w, h, rank, ranks)
-        assert (want[~mask] == -1.0).all() and (want[mask] != -1.0).any()
-        for rows in (1, 2, 3, 5, 7, 1000, 0):
-            scene.lab_set(stripe_cols=rows, streams=2 if rows != 3 else 8)
-            got = np.full((h, w, 3), -1.0)
-            _, st = rayrs_amd.render(scene, cam, 4, sample_chunk=2, tile_rank=rank, tile_ranks=ranks, out_f64=True, out=got)
-            assert st["rays"] == st0["rays"] and st["paths"] == st0["paths"] == int(mask.sum()) * 4, (rank, rows)
-            assert np.array_equal(want.view(np.uint64), got.view(np.uint64)), (rank, rows)
-
-
 def _mesh_from(origin, lookat):
     def fn():
         cam_args, objs, heur = scenes.mesh_scene(3, area_light=True)
