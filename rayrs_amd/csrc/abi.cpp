@@ -439,6 +439,18 @@ int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning) {
     return RAYRS_OK;
 }
 
+#ifdef RAYRS_LAB_TICKS
+// development build only (make LAB=1): the tick counters of the last render
+extern "C" int rayrs_lab_ticks(rayrs_scene* scene, uint64_t out[16]) {
+    if (!scene || !out || scene->device < 0) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    Counters c;
+    HIP_TRY(hipMemcpy(&c, scene->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) out[i] = c.lab_ticks[i];
+    return RAYRS_OK;
+}
+#endif
+
 // rayrs_lab.h: the kernels' development knobs (tests/ and scripts/ubench/ only)
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;

@@ -123,6 +123,9 @@ struct Counters {
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
+#ifdef RAYRS_LAB_TICKS
+    unsigned long long lab_ticks[16];  // development build only (make LAB=1): shader-clock shares of the hit / miss loops
+#endif
 };
 
 struct RenderDev {

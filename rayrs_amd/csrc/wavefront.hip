@@ -260,9 +260,10 @@ RR_DEV bool refill_item_range(const RenderDev& rp, ItemRange& range) {
 
 // What the kernels that start samples count per lane.
 struct SampleCount {
-    unsigned long long paths;   // samples started
-    unsigned long long direct;  // of them: primary rays that missed the root box (answered here, below)
-    uint32_t retired;           // slots that found no further item
+    unsigned long long paths;     // samples started
+    unsigned long long direct;    // of them: primary rays that missed the root box (answered here, below)
+    unsigned long long deferred;  // of them: primary rays that missed the root box, left to the miss kernel (DEFER)
+    uint32_t retired;             // slots that found no further item
 };
 
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
@@ -270,7 +271,12 @@ struct SampleCount {
 // sending the ray through the traversal and miss kernels for the same answer: the lane goes on to the
 // item's next sample, and to the next item, until it holds a ray that enters the root box.  From the
 // reference's obj_scene camera that is every seventh primary ray (the sky above the floor's far edge).
-template <bool COMPACT>
+// DEFER (the hit kernel): such a ray is written to its slot like any other and the slot left in state MISS -- the miss
+// kernel runs behind the hit kernel in the same round and finishes the sample there.  Answering it here means a texel
+// fetch that the lane waits for with everything the wave has stored so far still in flight (a wave's memory operations
+// complete in order), in nearly every batch (a seventh of the new samples, ~25 of them per batch), and another turn of
+// the loop below: the hit kernel has bandwidth to spare and no latency to spare; the miss kernel does this work anyway.
+template <bool COMPACT, bool DEFER = false>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
                         const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
                         SampleCount& sn) {
@@ -339,7 +345,8 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
             sn.paths++;
             s_cur++;
-            if (!root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z))) {
+            const bool enters = root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z));
+            if (!enters && !DEFER) {
                 // radiance() with the first query a Miss: light 0 + throughput 1 * background (lib.rs:522-523, :555)
                 const V3 result = v_add(mk(0.0, 0.0, 0.0), v_mul(mk(1.0, 1.0, 1.0), background(sc, d)));
                 acc0 += result.x;
@@ -360,7 +367,12 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                     t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
                 if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                wf.state[slot] = ready_state(d);
+                if (DEFER && !enters) {
+                    wf.state[slot] = WF_MISS;  // the root box test was this ray's query (bvh.rs:394): the miss kernel's
+                    sn.deferred++;
+                } else {
+                    wf.state[slot] = ready_state(d);
+                }
                 todo = false;
             }
         }
@@ -371,11 +383,11 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
 // rays and samples the sample-starting kernels account for, one atomic each per wave
 RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const SampleCount& sn) {
     wave_atomic_add(&rp.counters->paths, sn.paths);
-    const unsigned long long direct = wave_sum(sn.direct);
-    if ((threadIdx.x & 63u) == 0 && direct) {
-        atomicAdd(&rp.counters->rays, direct);
-        atomicAdd(&rp.counters->escaped_paths, direct);
-        atomicAdd(&rp.counters->direct_rays, direct);
+    const unsigned long long direct = wave_sum(sn.direct), deferred = wave_sum(sn.deferred);
+    if ((threadIdx.x & 63u) == 0 && (direct | deferred)) {
+        atomicAdd(&rp.counters->rays, direct + deferred);
+        if (direct) atomicAdd(&rp.counters->escaped_paths, direct);  // (the miss kernel counts the deferred ones' escape)
+        atomicAdd(&rp.counters->direct_rays, direct + deferred);
     }
     const uint32_t r = (uint32_t)wave_sum(sn.retired);
     if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
@@ -390,7 +402,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -618,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -634,11 +646,18 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
         load_hit_in<EAGER>(wf, cur);
         rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
     }
+#ifdef RAYRS_LAB_TICKS
+    unsigned long long tk[5] = {0, 0, 0, 0, 0}, tk_n = 0, tk_last = clock64();
+#define RR_TICK(i) { const unsigned long long now_ = clock64(); tk[i] += now_ - tk_last, tk_last = now_; }
+#else
+#define RR_TICK(i)
+#endif
     while (have) {
         HitIn nxt;
         bool have_next = false;
         have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
         if (have_next) load_hit_in<EAGER>(wf, nxt);
+        RR_TICK(0)
         PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
@@ -692,8 +711,10 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     acc_changed = !light_is_plus_zero(light);
                 }
             }
+            RR_TICK(1)
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
             if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
+            RR_TICK(2)
             if (goes_on) {
                 RaySlot* rs = ray_slot(wf, slot);
                 rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
@@ -718,12 +739,24 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&rp.counters->surface_hits[k], (unsigned long long)c);
                 }
             }
-            next_sample<COMPACT>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
+            RR_TICK(3)
+            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
+            RR_TICK(4)
         }
         cur = nxt;
         rec_cur = rec_nxt;
         have = have_next;
+#ifdef RAYRS_LAB_TICKS
+        tk_n++;
+#endif
     }
+#ifdef RAYRS_LAB_TICKS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&rp.counters->lab_ticks[i], tk[i]);
+        atomicAdd(&rp.counters->lab_ticks[5], tk_n);
+    }
+#endif
+#undef RR_TICK
     store_item_range(wf, wave, range);
     store_sample_count(rp, wf, sn);
 }
@@ -758,17 +791,24 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
-    SampleCount sn{0, 0, 0};
+    SampleCount sn{0, 0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
     if (have) load_miss_in<EAGER>(wf, cur);
+#ifdef RAYRS_LAB_TICKS
+    unsigned long long tk[3] = {0, 0, 0}, tk_n = 0, tk_last = clock64();
+#define RR_TICK(i) { const unsigned long long now_ = clock64(); tk[i] += now_ - tk_last, tk_last = now_; }
+#else
+#define RR_TICK(i)
+#endif
     while (have) {
         MissIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
         if (have_next) load_miss_in<EAGER>(wf, nxt);
+        RR_TICK(0)
         ItemRegs ir = cur.ir;
         if (cur.valid) {
             // throughput and light are loaded unconditionally and ignored while bounce == 1 (lib.rs:522-523)
@@ -781,10 +821,22 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
+        RR_TICK(1)
         next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        RR_TICK(2)
         cur = nxt;
         have = have_next;
+#ifdef RAYRS_LAB_TICKS
+        tk_n++;
+#endif
     }
+#ifdef RAYRS_LAB_TICKS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int i = 0; i < 3; i++) atomicAdd(&rp.counters->lab_ticks[8 + i], tk[i]);
+        atomicAdd(&rp.counters->lab_ticks[11], tk_n);
+    }
+#endif
+#undef RR_TICK
     n_escaped = feed.total;
     store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
