@@ -1,12 +1,13 @@
-# Same-box A/B of several builds of the library: usage (GPU box): bash scripts/ubench/ab_libs.sh "<tune_sweep args>" lib1.so lib2.so ...
-# Each library (paths relative to the repo root; "tree" = the tree's own) renders the sweep once, in the order
-# given and then reversed.
+# Same-box A/B of two builds of the library (same ABI): scripts/ubench/alt/prev.so against the tree's own, through
+# tune_sweep.py (kernel times from the library's own stats).  usage (GPU box): bash scripts/ubench/ab_libs.sh <config> <res> <spp> [env...]
+# order: current previous previous current
 ROOT=${GRAFT_REPO_ROOT:-.}
 cd $ROOT
-ARGS=$1; shift
-cp rayrs_amd/librayrs_hip.so /tmp/tree.so
-run() { if [ "$1" = tree ]; then cp /tmp/tree.so rayrs_amd/librayrs_hip.so; else cp $1 rayrs_amd/librayrs_hip.so; fi; echo "== $1"; python scripts/ubench/tune_sweep.py $ARGS 2>&1 | grep trace | head -1; }
-LIBS=("$@")
-for l in "${LIBS[@]}"; do run $l; done
-for ((i=${#LIBS[@]}-1; i>=0; i--)); do run ${LIBS[$i]}; done
-cp /tmp/tree.so rayrs_amd/librayrs_hip.so
+cp rayrs_amd/librayrs_hip.so /tmp/cur.so
+run() { cp $1 rayrs_amd/librayrs_hip.so; echo "== $2"; python scripts/ubench/tune_sweep.py $CFG $RES $SPP "" 2>&1 | grep -v "^compact" | tail -n ${LINES_OUT:-1}; }
+CFG=${1:-5}; RES=${2:-2048}; SPP=${3:-1024}
+run /tmp/cur.so current
+run scripts/ubench/alt/prev.so previous
+run scripts/ubench/alt/prev.so previous
+run /tmp/cur.so current
+cp /tmp/cur.so rayrs_amd/librayrs_hip.so
