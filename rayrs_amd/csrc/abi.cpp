@@ -451,6 +451,25 @@ extern "C" int rayrs_lab_ticks(rayrs_scene* scene, uint64_t out[16]) {
 }
 #endif
 
+// rayrs_lab.h: HIP-event times of the last render's path rounds, three per round (traversal, hit, miss kernel; the
+// local-pool route: its launch, 0, 0).  Returns the number of rounds; writes at most cap_rounds of them.
+extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_rounds) {
+    if (!scene || scene->device < 0 || scene->pending) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    const rayrs_scene::Pool& pl = scene->pool;
+    for (uint32_t r = 0; r < pl.timed_rounds && r < cap_rounds && out; r++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r], pl.ev_round[4 * r + 1]));
+        out[3 * r] = ms, out[3 * r + 1] = out[3 * r + 2] = 0.f;
+        if (scene->last_local) continue;
+        HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r + 1], pl.ev_round[4 * r + 2]));
+        out[3 * r + 1] = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, pl.ev_round[4 * r + 2], pl.ev_round[4 * r + 3]));
+        out[3 * r + 2] = ms;
+    }
+    return (int)pl.timed_rounds;
+}
+
 // rayrs_lab.h: the kernels' development knobs (tests/ and scripts/ubench/ only)
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;

@@ -37,6 +37,11 @@ typedef struct {
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab);
 
+/* HIP-event times (ms) of the last finished render's path rounds, three per round: traversal, hit, miss kernel (the
+ * local-pool route: its launch, 0, 0).  Returns the number of rounds (negative: rayrs_status); writes min(rounds,
+ * cap_rounds) * 3 floats. */
+int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_rounds);
+
 #ifdef __cplusplus
 }
 #endif
