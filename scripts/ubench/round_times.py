@@ -13,6 +13,9 @@ cam_args = scenes.camera_for_resolution(cam_args, res, res)
 scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, procedural.make_hdri(1024, 512), device=0)
 cam = rayrs_amd.Camera(*cam_args)
 chunk = rayrs_amd.frame_sample_chunk(res, res, spp)
+lab = {k: int(v, 0) for k, v in (kv.split("=") for kv in os.environ.get("LAB", "").split(",") if kv)}
+if lab:
+    scene.lab_set(**lab)
 rayrs_amd.render(scene, cam, 4, mb)
 img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, tile_rank=rank, tile_ranks=ranks)
 L = _ffi.lib()
