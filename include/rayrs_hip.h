@@ -214,8 +214,9 @@ typedef struct {
      * of a box around it, which Moeller-Trumbore's t does for rays within about 10^-7 rad of a triangle's plane
      * (measured: one ray in 10^7 of that family returns another primitive; none on any rendered frame;
      * tests/test_walk_tree.py pins a failing ray).  1: nothing is culled -- the reference's visit set by
-     * construction, bit-identical closest hits for every ray, at several times the traversal cost.  The
-     * local-pool route never culls. */
+     * construction, bit-identical closest hits for every ray; measured on the 1.3 M-triangle headline frame:
+     * 6.33 instead of 4.47 records and 6.93 instead of 5.63 primitive tests per query, traversal +59 %, frame
+     * +35 % (profiles/r04_exact_traversal.txt).  The local-pool route never culls. */
     uint32_t exact_traversal;
 } rayrs_render_params;
 

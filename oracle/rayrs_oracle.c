@@ -2009,15 +2009,20 @@ int orc_cull_margin_probe(const orc_scene* s, uint64_t n, const double* o, const
     if (nthreads > 256) nthreads = 256;
     batch_job jobs[256];
     pthread_t th[256];
-    static double worst[256][3];
+    int started[256];
+    double worst[256][3];  /* per call: concurrent probes do not share it */
     for (int k = 0; k < nthreads; k++) {
         worst[k][0] = -1.0, worst[k][1] = worst[k][2] = 0.0;
         batch_job j = {s, n, o, d, tmin, tmax, 2, nthreads, k, NULL, NULL, worst[k]};
         jobs[k] = j;
     }
-    for (int k = 1; k < nthreads; k++) pthread_create(&th[k], NULL, margin_probe_worker, &jobs[k]);
+    /* a worker that could not be started is run here: every share of the rays is probed */
+    for (int k = 1; k < nthreads; k++) started[k] = pthread_create(&th[k], NULL, margin_probe_worker, &jobs[k]) == 0;
     margin_probe_worker(&jobs[0]);
-    for (int k = 1; k < nthreads; k++) pthread_join(th[k], NULL);
+    for (int k = 1; k < nthreads; k++) {
+        if (started[k]) pthread_join(th[k], NULL);
+        else margin_probe_worker(&jobs[k]);
+    }
     out[0] = -1.0, out[1] = out[2] = 0.0;
     for (int k = 0; k < nthreads; k++) {
         if (worst[k][0] > out[0]) out[0] = worst[k][0];
