@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
         rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
     }
 #ifdef RAYRS_LAB_TICKS
-    unsigned long long tk[5] = {0, 0, 0, 0, 0}, tk_n = 0, tk_last = clock64();
+    unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, tk_n = 0, tk_last = clock64();
 #define RR_TICK(i) { const unsigned long long now_ = clock64(); tk[i] += now_ - tk_last, tk_last = now_; }
 #else
 #define RR_TICK(i)
@@ -656,6 +656,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
         HitIn nxt;
         bool have_next = false;
         have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
+        RR_TICK(5)
         if (have_next) load_hit_in<EAGER>(wf, nxt);
         RR_TICK(0)
         PrimRec<COMPACT> rec_nxt;
@@ -668,6 +669,10 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             V3 thr = mk(1.0, 1.0, 1.0), light = mk(0.0, 0.0, 0.0), position = mk(0.0, 0.0, 0.0), dir = mk(0.0, 0.0, 1.0);
             uint32_t bd_next = 0;
             if (valid) {
+#ifdef RAYRS_LAB_TICKS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (LAB build: the wait for this batch's records, apart from the arithmetic)
+                RR_TICK(6)
+#endif
                 const V3 o = cur.o;
                 const V3 d = cur.d;
                 const double t = cur.t;
@@ -754,6 +759,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     if ((threadIdx.x & 63u) == 0) {
         for (int i = 0; i < 5; i++) atomicAdd(&rp.counters->lab_ticks[i], tk[i]);
         atomicAdd(&rp.counters->lab_ticks[5], tk_n);
+        atomicAdd(&rp.counters->lab_ticks[6], tk[5]), atomicAdd(&rp.counters->lab_ticks[7], tk[6]);
     }
 #endif
 #undef RR_TICK

@@ -20,9 +20,9 @@ print(f"trace {st['trace_ms']:.1f} ms trav {st['kernel_ms']:.1f} hit {st['hit_ms
 hb = max(t[5], 1)
 names = ["feed + issue next batch's slot loads", "wait for this batch's data + Material::evaluate", "issue next batch's primitive loads",
          "stores of this batch", "next_sample"]
-tot = sum(t[:5])
-print(f"hit kernel: {hb} batches, {tot / hb:.0f} ticks per batch (shader clock, 100 MHz)")
-for n, v in zip(names, t[:5]):
+tot = sum(t[:5]) + t[6] + t[7]
+print(f"hit kernel: {hb} batches, {tot / hb:.0f} ticks per batch (shader clock)")
+for n, v in zip(["window list (feed_next)", "issuing next batch's slot loads"] + ["waiting for this batch's slot + primitive records (vmcnt(0))", "Material::evaluate + roulette"] + names[2:], [t[6], t[0], t[7], t[1]] + t[2:5]):
     print(f"   {v / hb:8.1f} ticks  {v / tot:6.1%}  {n}")
 mb_ = max(t[11], 1)
 tot = sum(t[8:11])
