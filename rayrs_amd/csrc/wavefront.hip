@@ -178,8 +178,9 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
     }
     if (i < 2u * wf.n_flat_waves) wf.wave_items[i] = 0ull;
     if (i >= wf.np) return;
+    // (the slot records are not touched: an IDLE slot has no item by definition -- wf_gen_kernel reads nothing of it --
+    // and nothing ever reads a DEAD one; round 3 wrote every slot's cursor word here, 3.9 GB per headline frame)
     wf.state[i] = i < live ? WF_IDLE : WF_DEAD;
-    tail_slot(wf, i)->s_cur = 0;  // no item
 }
 
 // -------------------------------------------------------------------- gen
