@@ -144,11 +144,14 @@ typedef struct {
     uint64_t device_bytes; /* total scene footprint in HBM */
     double root_box[6];    /* xmin,xmax,ymin,ymax,zmin,zmax */
     double build_seconds;
-    uint32_t n_wide;        /* four-slot records of the walk tree the kernels traverse */
+    uint32_t n_wide;        /* four-slot records of the tree the kernels walk by default (rayrs_scene_export_wide) */
     uint32_t wide_root_ref;
     uint32_t wide_depth;    /* stack entries the traversal can need */
-    uint32_t local_pool;    /* 1 = the walk tree is at most one record: renders keep every path in LDS
+    uint32_t local_pool;    /* 1 = the gate tree is at most one record: renders keep every path in LDS
                                (rayrs_tuning.local_pool, local_pool.hip) */
+    uint32_t gate_n_wide;   /* the same three for the gate tree (rayrs_scene_export_gate_tree), which */
+    uint32_t gate_root_ref; /* rayrs_render_params.exact_traversal walks */
+    uint32_t gate_depth;
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -163,15 +166,22 @@ int rayrs_scene_device(const rayrs_scene* scene);
  * 1 = 1..4 primitives behind a box test (payload = first<<2 | count-1),
  * 2 = one primitive with no box test (payload = prim<<2). */
 int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t* child_ref, uint32_t* prim_object);
-/* The records the kernels actually walk (wide_box: n_wide*4*6 f64, wide_ref: n_wide*4 u32, kind 3 =
- * unused slot): NOT the reference's topology but a tree built for traversal speed over the reference's
- * leaf groups.  A leaf slot (kind 1) is one group -- the 1..4 leaves that share a parent Node, contiguous
- * in depth-first order -- behind exactly the box that gates the reference's access to it (the parent
- * Node's box; boxes on a root path nest exactly and the slab test is monotone, so passing it implies
- * passing every box above).  An interior slot (kind 0) carries the union of the boxes below it: a ray
- * that misses it misses every gating box inside.  Every group appears exactly once
- * (tests/test_bvh_builder.py checks all of this from the two exports alone). */
+/* The records the kernels walk (wide_box: n*4*6 f64, wide_ref: n*4 u32, kind 3 = unused slot): NOT the
+ * reference's topology but trees built for traversal speed.  What decides whether BvhTree::intersect reaches a
+ * primitive is one box, its GATING box -- the box of the Node it hangs under; boxes on a root path nest exactly and
+ * the slab test is monotone in the bounds, so passing it implies passing every box above.
+ *   rayrs_scene_export_gate_tree (n = gate_n_wide): a leaf slot (kind 1) is one of the reference's groups -- the
+ * 1..4 leaves that share a parent Node, contiguous in depth-first order -- behind exactly its gating box; an
+ * interior slot (kind 0) carries the union of the boxes below it, so a ray that misses it misses every gating box
+ * inside.  Every group appears exactly once: the primitives this tree reaches are the primitives the reference
+ * reaches.  Walked by rayrs_render_params.exact_traversal and the source of the local-pool route's gates.
+ *   rayrs_scene_export_wide (n = n_wide), the default: a leaf slot is ONE primitive behind its own bounding box
+ * (Bvh::build's, geometry.rs bbox) widened on every side by 1/64 of its largest extent, rounded outwards to f32 and
+ * clipped to its gating box.  It reaches a subset of what the reference reaches (see exact_traversal for what the
+ * subset leaves out and why that is the reference's answer all the same).
+ * tests/test_bvh_builder.py checks all of this from the exports alone. */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
+int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -208,15 +218,23 @@ typedef struct {
     uint32_t tile_rank, tile_ranks;
     uint32_t out_format;   /* RAYRS_OUT_F32: f32x3 (image.rs:224-229), RAYRS_OUT_F64: f64x3 */
     uint32_t count_work;   /* 1 = also count traversal work (slower; for the roofline figure) */
-    /* Closest-hit culling.  BvhTree::intersect visits every Node whose box the ray enters and never compares a box
-     * with the closest hit so far (bvh.rs:391-415).  0 (default): the walk skips a box entered beyond
-     * best_t * (1 + 2^-10) -- the reference's answer unless a primitive's COMPUTED t lies more than that in front
-     * of a box around it, which Moeller-Trumbore's t does for rays within about 10^-7 rad of a triangle's plane
-     * (measured: one ray in 10^7 of that family returns another primitive; none on any rendered frame;
-     * tests/test_walk_tree.py pins a failing ray).  1: nothing is culled -- the reference's visit set by
-     * construction, bit-identical closest hits for every ray; measured on the 1.3 M-triangle headline frame:
-     * 6.33 instead of 4.47 records and 6.93 instead of 5.63 primitive tests per query, traversal +59 %, frame
-     * +35 % (profiles/r04_exact_traversal.txt).  The local-pool route never culls. */
+    /* BvhTree::intersect tests every primitive whose enclosing Node boxes the ray enters and never compares a box
+     * with the closest hit so far (bvh.rs:391-415).
+     * 0 (default): the walk makes two bets on the reference's arithmetic, each measured, neither a construction:
+     *   - closest-hit culling: a box entered beyond best_t * (1 + 2^-10) is skipped -- the reference's answer
+     *     unless a primitive's COMPUTED t lies more than that in front of a box around it;
+     *   - tight leaf boxes (rayrs_scene_export_wide): a primitive is tested only if the ray enters its own bounding
+     *     box widened by 1/64 of its size (inside the reference's gating box, so nothing extra is ever tested) --
+     *     the reference's answer unless its own test accepts a hit on a primitive the ray passes beside by more
+     *     than that.
+     *   Both fail only for rays within about 1e-7 rad of a primitive's plane seen from many thousand primitive sizes
+     *   away, where Moeller-Trumbore's own result is rounding noise (scripts/fuzz_traversal.py counts them:
+     *   profiles/r04_tight_leaves.txt; tests/test_walk_tree.py pins one failing ray of each kind); no rendered
+     *   frame, of any size, has differed in a bit.
+     * 1: the walk over the reference's leaf groups behind their exact gating boxes (rayrs_scene_export_gate_tree)
+     *   with nothing culled: the reference's visit set by construction, bit-identical closest hits for every ray.
+     *   Measured cost on the 1.3 M-triangle headline frame: profiles/r04_exact_traversal.txt.
+     * The local-pool route always takes the gate tree and never culls. */
     uint32_t exact_traversal;
 } rayrs_render_params;
 

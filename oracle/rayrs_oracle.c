@@ -1398,6 +1398,18 @@ int orc_scene_bbox(const orc_scene* s, double box[6], double center[3], double* 
     return 0;
 }
 
+/* The bounding boxes Bvh::build starts from (bvh.rs:212-226: object.bbox() of every object, geometry.rs), in
+ * insertion order: boxes = nobjs * 6 (xmin xmax ymin ymax zmin zmax). */
+int orc_object_boxes(const orc_scene* s, double* boxes) {
+    if (!s) return -1;
+    for (size_t i = 0; i < s->nobjs; i++) {
+        aabb_t b = shape_bbox(&s->objs[i].geom);
+        double* o = boxes + i * 6;
+        o[0] = b.xmin; o[1] = b.xmax; o[2] = b.ymin; o[3] = b.ymax; o[4] = b.zmin; o[5] = b.zmax;
+    }
+    return 0;
+}
+
 /* ---- traversal ---- */
 
 typedef struct {

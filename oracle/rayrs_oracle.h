@@ -155,6 +155,7 @@ void orc_triangle_normal(const double p1[3], const double p2[3], const double p3
 /* AxisAlignedBoundingBox helpers for the doc-test scalars, geometry.rs:544-683.
  * Fills box[6], center[3], volume, surface_area of the scene's object list. */
 int orc_scene_bbox(const orc_scene* s, double box[6], double center[3], double* volume, double* surface_area);
+int orc_object_boxes(const orc_scene* s, double* boxes); /* nobjs * 6, insertion order */
 
 /* Bvh::intersect; returns object index (insertion order) or -1, *t. */
 int64_t orc_bvh_intersect(const orc_scene* s, const double o[3], const double d[3], double tmin, double tmax,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
     "rayrs_object_from_spheres", "rayrs_object_box_geom",
     "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
-    "rayrs_scene_export_wide", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
+    "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
     "rayrs_camera_new",
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout",
@@ -51,7 +51,8 @@ class SceneInfo(C.Structure):
                 ("n_surfaces", C.c_uint32), ("node_bytes", C.c_uint32), ("prim_bytes", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
                 ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
-                ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32)]
+                ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32), ("gate_n_wide", C.c_uint32),
+                ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
@@ -131,6 +132,7 @@ def lib():
     L.rayrs_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
+    L.rayrs_scene_export_gate_tree.argtypes = [vp, vp, vp]
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]

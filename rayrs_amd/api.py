@@ -339,13 +339,23 @@ class Scene:
         return box[:i["n_interior"]], ref[:i["n_interior"]], prim[:i["n_prims"]]
 
     def export_wide(self):
-        """The four-slot records the kernels walk: (box[n_wide,4,6], ref[n_wide,4])."""
+        """The four-slot records the kernels walk by default: (box[n_wide,4,6], ref[n_wide,4])."""
         i = self.info()
         box = np.zeros((max(i["n_wide"], 1), 4, 6), dtype=np.float64)
         ref = np.zeros((max(i["n_wide"], 1), 4), dtype=np.uint32)
         _ffi.check(self._L.rayrs_scene_export_wide(self._h, box.ctypes.data, ref.ctypes.data),
                    "rayrs_scene_export_wide")
         return box[:i["n_wide"]], ref[:i["n_wide"]]
+
+    def export_gate_tree(self):
+        """The records exact_traversal walks (the reference's leaf groups behind their gating boxes):
+        (box[gate_n_wide,4,6], ref[gate_n_wide,4])."""
+        i = self.info()
+        box = np.zeros((max(i["gate_n_wide"], 1), 4, 6), dtype=np.float64)
+        ref = np.zeros((max(i["gate_n_wide"], 1), 4), dtype=np.uint32)
+        _ffi.check(self._L.rayrs_scene_export_gate_tree(self._h, box.ctypes.data, ref.ctypes.data),
+                   "rayrs_scene_export_gate_tree")
+        return box[:i["gate_n_wide"]], ref[:i["gate_n_wide"]]
 
     def close(self):
         if self._h is not None:

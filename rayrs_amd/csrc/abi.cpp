@@ -193,7 +193,8 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     if (s->device < 0) return;
     (void)hipSetDevice(s->device);
     if (s->pending && s->last_stream) (void)hipStreamSynchronize(s->last_stream);
-    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    for (auto& w : s->trav)
+        if (w.d_nodes) (void)hipFree(w.d_nodes);
     if (s->d_prims) (void)hipFree(s->d_prims);
     if (s->d_surfaces) (void)hipFree(s->d_surfaces);
     if (s->d_hdri) (void)hipFree(s->d_hdri);
@@ -233,16 +234,20 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 // five workgroups (the kernel's launch bound) share a CU's 160 KiB.
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;
-    const uint32_t depth = f.wide_depth ? f.wide_depth : 1;
-    uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
-    s->stack_lds = want < depth ? want : depth;
-    const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
-    uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
-    if (s->lab.hot_records == 0xffffffffu) hot = 0;
-    else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
-    s->hot_records = hot < f.n_wide() ? hot : f.n_wide();
-    HIP_TRY(wf_trav_occupancy(f.compact, s->stack_lds, s->hot_records, &s->blocks_per_cu));
-    if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    for (int x = 0; x < 2; x++) {
+        const WalkTree& t = s->tree(x != 0);
+        rayrs_scene::Walk& w = s->trav[x];
+        const uint32_t depth = t.depth ? t.depth : 1;
+        uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
+        w.stack_lds = want < depth ? want : depth;
+        const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
+        uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
+        if (s->lab.hot_records == 0xffffffffu) hot = 0;
+        else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
+        w.hot_records = hot < t.n() ? hot : t.n();
+        HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.hot_records, &w.blocks_per_cu));
+        if (w.blocks_per_cu < 1) w.blocks_per_cu = 1;
+    }
     return RAYRS_OK;
 }
 
@@ -254,7 +259,8 @@ static void scene_configure_local(rayrs_scene* s) {
     LocalScene& ls = s->local;
     std::memset(&ls, 0, sizeof(ls));
     s->local_ok = false;
-    if (f.n_wide() > 1 || f.n_prims() == 0 || f.n_prims() > LP_MAX_PRIMS || s->surfaces.size() > LP_MAX_PRIMS) return;
+    const WalkTree& t = f.gate;  // (the groups behind their gating boxes: this route makes neither of the default walk's bets)
+    if (t.n() > 1 || f.n_prims() == 0 || f.n_prims() > LP_MAX_PRIMS || s->surfaces.size() > LP_MAX_PRIMS) return;
     auto add_gate = [&](const double* box, uint32_t ref) {
         if ((ref >> 30) != REF_RANGE) return false;
         const uint32_t g = ls.n_gates++;
@@ -263,20 +269,20 @@ static void scene_configure_local(rayrs_scene* s) {
         ls.count[g] = (ref & 3u) + 1u;
         return true;
     };
-    if (f.n_wide() == 0) {  // the root group behind the root Node's box (trav_init)
-        if (!add_gate(f.root_box, f.wide_root_ref)) return;
+    if (t.n() == 0) {  // the root group behind the root Node's box (trav_init)
+        if (!add_gate(f.root_box, t.root_ref)) return;
     } else {
-        if ((f.wide_root_ref >> 30) != REF_INTERIOR) return;
+        if ((t.root_ref >> 30) != REF_INTERIOR) return;
         for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t ref = f.wide_ref[k];
+            const uint32_t ref = t.ref[k];
             if ((ref >> 30) == REF_NONE) continue;
-            if (!add_gate(&f.wide_box[(size_t)k * 6], ref)) return;  // an interior slot: not a one-record tree
+            if (!add_gate(&t.box[(size_t)k * 6], ref)) return;  // an interior slot: not a one-record tree
         }
     }
     uint32_t covered = 0;
     for (uint32_t g = 0; g < ls.n_gates; g++) covered += ls.count[g];
     if (covered != f.n_prims()) return;
-    ls.n_records = f.n_wide();
+    ls.n_records = t.n();
     ls.n_prims = f.n_prims();
     for (const SurfaceDev& sf : s->surfaces) ls.kind_mask |= 1u << (uint32_t)sf.kind;
     s->local_ok = true;
@@ -288,8 +294,11 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->cu_count = prop.multiProcessorCount;
     const FlatScene& f = s->flat;
-    HIP_TRY(hipMalloc(&s->d_nodes, f.node_bytes.size()));
-    HIP_TRY(hipMemcpy(s->d_nodes, f.node_bytes.data(), f.node_bytes.size(), hipMemcpyHostToDevice));
+    for (int x = 0; x < 2; x++) {
+        const WalkTree& t = s->tree(x != 0);
+        HIP_TRY(hipMalloc(&s->trav[x].d_nodes, t.node_bytes.size()));
+        HIP_TRY(hipMemcpy(s->trav[x].d_nodes, t.node_bytes.data(), t.node_bytes.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
     HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
@@ -299,7 +308,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -331,11 +340,11 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     std::unique_ptr<rayrs_scene> s(new rayrs_scene());
     int st = build_flat_scene(objs->list, z_near, z_far, heuristic, splits, hdri_w, hdri_h, hdri_rgb, &s->flat);
     if (st != RAYRS_OK) return st;
-    // Every traversal lane gets a stack of wide_depth entries (12 in LDS, the rest in HBM: 1.3 MB per entry on a
+    // Every traversal lane gets a stack of WalkTree::depth entries (12 in LDS, the rest in HBM: 1.3 MB per entry on a
     // 256-CU device).  The reference recurses as deep as its tree; a tree that needs more than 4096 pending
     // entries (a chain of thousands of nested objects) is refused instead of allocating gigabytes for it.
-    if (s->flat.wide_depth > 4096u) {
-        g_last_error = "walk tree needs " + std::to_string(s->flat.wide_depth) + " stack entries (limit 4096)";
+    if (std::max(s->flat.walk.depth, s->flat.gate.depth) > 4096u) {
+        g_last_error = "walk tree needs " + std::to_string(std::max(s->flat.walk.depth, s->flat.gate.depth)) + " stack entries (limit 4096)";
         return RAYRS_UNSUPPORTED;
     }
     s->surfaces = objs->list.surfaces;
@@ -366,9 +375,12 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->compact = f.compact ? 1u : 0u;
     info->n_surfaces = (uint32_t)scene->surfaces.size();
     info->node_bytes = f.compact ? (uint32_t)sizeof(Node4F32) : (uint32_t)sizeof(Node4F64);
-    info->n_wide = f.n_wide();
-    info->wide_root_ref = f.wide_root_ref;
-    info->wide_depth = f.wide_depth;
+    info->n_wide = f.walk.n();
+    info->wide_root_ref = f.walk.root_ref;
+    info->wide_depth = f.walk.depth;
+    info->gate_n_wide = f.gate.n();
+    info->gate_root_ref = f.gate.root_ref;
+    info->gate_depth = f.gate.depth;
     info->local_pool = (scene->local_ok && scene->tuning.local_pool != 1u) ? 1u : 0u;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
@@ -389,9 +401,17 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
 
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
     if (!scene) return RAYRS_INVALID_ARG;
-    const FlatScene& f = scene->flat;
-    if (wide_box && !f.wide_box.empty()) std::memcpy(wide_box, f.wide_box.data(), f.wide_box.size() * 8);
-    if (wide_ref && !f.wide_ref.empty()) std::memcpy(wide_ref, f.wide_ref.data(), f.wide_ref.size() * 4);
+    const WalkTree& t = scene->flat.walk;
+    if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
+    if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
+    return RAYRS_OK;
+}
+
+int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
+    if (!scene) return RAYRS_INVALID_ARG;
+    const WalkTree& t = scene->flat.gate;
+    if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
+    if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
     return RAYRS_OK;
 }
 
@@ -508,7 +528,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_camera, origin), RAYRS_FIELD(rayrs_camera, e_x), RAYRS_FIELD(rayrs_camera, e_y);
     RAYRS_FIELD(rayrs_camera, z), RAYRS_FIELD(rayrs_camera, width), RAYRS_FIELD(rayrs_camera, height);
     RAYRS_FIELD(rayrs_camera, ppc), RAYRS_FIELD(rayrs_camera, x_pixels), RAYRS_FIELD(rayrs_camera, y_pixels);
-    RAYRS_STRUCT(rayrs_scene_info_t, 16);
+    RAYRS_STRUCT(rayrs_scene_info_t, 19);
     RAYRS_FIELD(rayrs_scene_info_t, n_objects), RAYRS_FIELD(rayrs_scene_info_t, n_interior);
     RAYRS_FIELD(rayrs_scene_info_t, n_prims), RAYRS_FIELD(rayrs_scene_info_t, root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, depth), RAYRS_FIELD(rayrs_scene_info_t, compact);
@@ -517,6 +537,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, root_box), RAYRS_FIELD(rayrs_scene_info_t, build_seconds);
     RAYRS_FIELD(rayrs_scene_info_t, n_wide), RAYRS_FIELD(rayrs_scene_info_t, wide_root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, local_pool);
+    RAYRS_FIELD(rayrs_scene_info_t, gate_n_wide), RAYRS_FIELD(rayrs_scene_info_t, gate_root_ref);
+    RAYRS_FIELD(rayrs_scene_info_t, gate_depth);
     RAYRS_STRUCT(rayrs_render_params, 9);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
@@ -557,7 +579,9 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
-    sc.nodes = s->d_nodes;
+    const WalkTree& t = s->tree(exact);
+    const rayrs_scene::Walk& w = s->trav[exact ? 1 : 0];
+    sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
     sc.surfaces = s->d_surfaces;
     sc.hdri = s->d_hdri;
@@ -565,10 +589,10 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.hdri_h = s->flat.hdri_h;
     sc.hdri_wm1 = (double)(s->flat.hdri_w - 1u);
     sc.hdri_hm1 = (double)(s->flat.hdri_h - 1u);
-    sc.root_ref = s->flat.wide_root_ref;
-    sc.stack_depth = s->flat.wide_depth ? s->flat.wide_depth : 1;
-    sc.stack_lds = s->stack_lds;
-    sc.hot_records = s->hot_records;
+    sc.root_ref = t.root_ref;
+    sc.stack_depth = t.depth ? t.depth : 1;
+    sc.stack_lds = w.stack_lds;
+    sc.hot_records = w.hot_records;
     sc.n_surfaces = (uint32_t)s->surfaces.size();
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
@@ -691,7 +715,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[params->exact_traversal ? 1 : 0].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;
@@ -746,8 +770,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         wf.wave_items = pl.d_wave_items;
         wf.trav_threads = trav_blocks * 256u;
         {
-            const uint32_t total = scene->flat.wide_depth ? scene->flat.wide_depth : 1;
-            const size_t words = (size_t)(total - scene->stack_lds) * wf.trav_threads;
+            const size_t words = (size_t)(sc.stack_depth - sc.stack_lds) * wf.trav_threads;
             if (words > pl.stack_spill_words) {
                 if (pl.d_stack_spill) HIP_TRY(hipFree(pl.d_stack_spill));
                 pl.d_stack_spill = nullptr;

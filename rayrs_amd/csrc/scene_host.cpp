@@ -281,13 +281,13 @@ struct Builder {
 inline bool f32_exact(double v) { return (double)(float)v == v; }
 
 // Surface area of the box around a wide record's tested slots.
-double record_area(const FlatScene& f, uint32_t rec) {
+double record_area(const WalkTree& f, uint32_t rec) {
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     bool any = false;
     for (int i = 0; i < 4; i++) {
-        const uint32_t kind = f.wide_ref[(size_t)rec * 4 + i] >> 30;
+        const uint32_t kind = f.ref[(size_t)rec * 4 + i] >> 30;
         if (kind != REF_INTERIOR && kind != REF_RANGE) continue;
-        const double* b = &f.wide_box[((size_t)rec * 4 + i) * 6];
+        const double* b = &f.box[((size_t)rec * 4 + i) * 6];
         for (int a = 0; a < 3; a++) {
             if (!any || b[2 * a] < lo[a]) lo[a] = b[2 * a];
             if (!any || b[2 * a + 1] > hi[a]) hi[a] = b[2 * a + 1];
@@ -304,8 +304,8 @@ double record_area(const FlatScene& f, uint32_t rec) {
 // behind them.  A ray meets a box with probability proportional to its surface area, so
 // these are the records most queries read, and the traversal kernel keeps the first of them
 // in LDS (wavefront.hip) instead of asking the vector L1 for them.
-void front_largest(FlatScene& f) {
-    const uint32_t n = f.n_wide();
+void front_largest(WalkTree& f) {
+    const uint32_t n = f.n();
     const uint32_t k = n < WIDE_FRONT ? n : WIDE_FRONT;
     if (k == 0) return;
     std::vector<double> area(n);
@@ -321,20 +321,20 @@ void front_largest(FlatScene& f) {
         if (!in_front[r]) order[at++] = r;  // order[new] = old
     std::vector<uint32_t> new_of(n);
     for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
-    std::vector<double> box(f.wide_box.size());
-    std::vector<uint32_t> ref(f.wide_ref.size());
+    std::vector<double> box(f.box.size());
+    std::vector<uint32_t> ref(f.ref.size());
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t old = order[i];
         for (int c = 0; c < 4; c++) {
-            uint32_t r = f.wide_ref[(size_t)old * 4 + c];
+            uint32_t r = f.ref[(size_t)old * 4 + c];
             if ((r >> 30) == REF_INTERIOR) r = (REF_INTERIOR << 30) | new_of[r & 0x3fffffffu];
             ref[(size_t)i * 4 + c] = r;
         }
-        for (int c = 0; c < 24; c++) box[(size_t)i * 24 + c] = f.wide_box[(size_t)old * 24 + c];
+        for (int c = 0; c < 24; c++) box[(size_t)i * 24 + c] = f.box[(size_t)old * 24 + c];
     }
-    f.wide_box.swap(box);
-    f.wide_ref.swap(ref);
-    f.wide_root_ref = (REF_INTERIOR << 30) | new_of[f.wide_root_ref & 0x3fffffffu];
+    f.box.swap(box);
+    f.ref.swap(ref);
+    f.root_ref = (REF_INTERIOR << 30) | new_of[f.root_ref & 0x3fffffffu];
 }
 
 // ------------------------------------------------------------ the walk tree
@@ -568,11 +568,11 @@ struct WideCollapse {
 
 // One record per call: the slots the collapse gives node n's two subtrees.  Returns the record's reference;
 // *stack_need is the number of stack entries a traversal below it can have pending.
-uint32_t emit_wide(FlatScene& f, const WideCollapse& wc, int32_t n, uint32_t* stack_need) {
+uint32_t emit_wide(WalkTree& f, const WideCollapse& wc, int32_t n, uint32_t* stack_need) {
     const std::vector<WalkNode>& nodes = wc.nodes;
-    const uint32_t rec = f.n_wide();
-    f.wide_ref.resize(f.wide_ref.size() + 4, REF_NONE << 30);
-    f.wide_box.resize(f.wide_box.size() + 24, 0.0);
+    const uint32_t rec = f.n();
+    f.ref.resize(f.ref.size() + 4, REF_NONE << 30);
+    f.box.resize(f.box.size() + 24, 0.0);
     int32_t slots[4] = {-1, -1, -1, -1};
     int ns = 0;
     const int k = wc.argk[(size_t)n * 4];
@@ -587,29 +587,108 @@ uint32_t emit_wide(FlatScene& f, const WideCollapse& wc, int32_t n, uint32_t* st
             ref = emit_wide(f, wc, slots[i], &need);
             if (need > below) below = need;
         }
-        f.wide_ref[(size_t)rec * 4 + i] = ref;
-        for (int q = 0; q < 6; q++) f.wide_box[((size_t)rec * 4 + i) * 6 + q] = c.box[q];
+        f.ref[(size_t)rec * 4 + i] = ref;
+        for (int q = 0; q < 6; q++) f.box[((size_t)rec * 4 + i) * 6 + q] = c.box[q];
     }
     *stack_need = (uint32_t)(ns - 1) + below;
     return (REF_INTERIOR << 30) | rec;
 }
 
-void build_walk_tree(FlatScene& f) {
-    f.wide_box.clear();
-    f.wide_ref.clear();
-    f.wide_depth = 0;
+// The default tree's leaf slots: every primitive alone behind a box of its own -- its bounding box (the one
+// Bvh::build computes for it, geometry.rs bbox) widened on every side by LEAF_MARGIN of its largest extent,
+// rounded outwards to f32 and clipped to its group's gating box.
+//   Nothing is tested that the reference does not reach: the box lies inside the gating box, and the slab test is
+// monotone in the bounds, so passing it implies passing the gating box and everything around that.
+//   What is no longer tested is a primitive whose widened box the ray misses.  In exact arithmetic such a ray
+// misses the primitive by more than the widening; the reference's own test (Moeller-Trumbore, the sphere's
+// quadratic, the plane's rectangle) then rejects it unless its rounding moves the hit POINT by more than
+// LEAF_MARGIN of the primitive's size.  That error is about eps * |origin - primitive| / angle to the
+// primitive's plane: from 20 units away it takes a ray within 1e-11 rad of the plane of a primitive 0.02 across
+// that it passes beside (1e-8 rad from 1e4 scene sizes away, and so on) -- like closest-hit culling a bet on the
+// reference's arithmetic, measured (profiles/r04_tight_leaves.txt), not a construction;
+// rayrs_render_params.exact_traversal walks the gate tree, which makes neither bet.
+constexpr double LEAF_MARGIN = 0x1p-6;
+
+void tight_box(const Aabb& b, const double* gate, double* out) {
+    const double pb[6] = {b.xmin, b.xmax, b.ymin, b.ymax, b.zmin, b.zmax};
+    double ext = 0.0;
+    for (int a = 0; a < 3; a++) ext = std::max(ext, pb[2 * a + 1] - pb[2 * a]);
+    const double m = ext * LEAF_MARGIN;
+    for (int a = 0; a < 3; a++) {
+        double lo = pb[2 * a] - m, hi = pb[2 * a + 1] + m;
+        float lf = (float)lo, hf = (float)hi;
+        if ((double)lf > lo) lf = std::nextafterf(lf, -std::numeric_limits<float>::infinity());
+        if ((double)hf < hi) hf = std::nextafterf(hf, std::numeric_limits<float>::infinity());
+        lo = (double)lf, hi = (double)hf;
+        // (a bound that is not a number, from an object whose own box is not, leaves the gating box's bound)
+        out[2 * a] = lo > gate[2 * a] ? lo : gate[2 * a];
+        out[2 * a + 1] = hi < gate[2 * a + 1] ? hi : gate[2 * a + 1];
+    }
+}
+
+void split_groups(const std::vector<WalkGroup>& groups, const std::vector<Aabb>& prim_box, std::vector<WalkGroup>& out) {
+    out.reserve(groups.size() * 3);
+    for (const WalkGroup& g : groups) {
+        const uint32_t first = (g.ref & 0x3fffffffu) >> 2, count = (g.ref & 3u) + 1u;
+        for (uint32_t i = 0; i < count; i++) {
+            WalkGroup r;
+            tight_box(prim_box[first + i], g.box, r.box);
+            r.ref = (REF_RANGE << 30) | ((first + i) << 2);
+            out.push_back(r);
+        }
+    }
+}
+
+void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
+    WalkBuilder b(leaves);
+    b.build();
+    t.box.reserve(leaves.size() * 12);
+    t.ref.reserve(leaves.size() * 2);
+    const WideCollapse wc(b.nodes);
+    t.root_ref = emit_wide(t, wc, 0, &t.depth);
+    front_largest(t);
+}
+
+// prim_box[p]: the reference's bounding box of the object behind primitive record p
+void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
+    f.walk = WalkTree();
+    f.gate = WalkTree();
     if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
-        f.wide_root_ref = f.root_ref;
+        f.walk.root_ref = f.gate.root_ref = f.root_ref;
         return;
     }
     std::vector<WalkGroup> groups;
     collect_groups(f, f.root_ref & 0x3fffffffu, f.root_box, groups);
-    WalkBuilder b(groups);
-    b.build();
-    f.wide_box.reserve(groups.size() * 12);
-    f.wide_ref.reserve(groups.size() * 2);
-    const WideCollapse wc(b.nodes);
-    f.wide_root_ref = emit_wide(f, wc, 0, &f.wide_depth);
+    build_tree_over(groups, f.gate);
+    std::vector<WalkGroup> singles;
+    split_groups(groups, prim_box, singles);
+    build_tree_over(singles, f.walk);
+}
+
+inline bool boxes_f32_exact(const WalkTree& t) {
+    for (size_t r = 0; r < t.ref.size(); r++) {
+        if ((t.ref[r] >> 30) == REF_NONE) continue;  // box never read
+        for (int k = 0; k < 6; k++)
+            if (!f32_exact(t.box[r * 6 + k])) return false;
+    }
+    return true;
+}
+
+// The records as the kernels read them.  An unused slot gets the inverted box [+inf, -inf], which no ray
+// enters, so that the kernel's slab test says the right thing without looking at the kind.
+template <typename NODE, typename F>
+void fill_nodes(WalkTree& t) {
+    const uint32_t n = t.n();
+    const double inf = std::numeric_limits<double>::infinity();
+    t.node_bytes.assign((size_t)std::max(n, 1u) * sizeof(NODE), 0);
+    NODE* nodes = reinterpret_cast<NODE*>(t.node_bytes.data());
+    for (uint32_t r = 0; r < n; r++)
+        for (int ch = 0; ch < 4; ch++) {
+            const uint32_t ref = t.ref[(size_t)r * 4 + ch];
+            nodes[r].ref[ch] = ref;
+            for (int k = 0; k < 6; k++)
+                nodes[r].box[ch][k] = (ref >> 30) == REF_NONE ? ((k & 1) ? (F)-inf : (F)inf) : (F)t.box[((size_t)r * 4 + ch) * 6 + k];
+        }
 }
 
 void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
@@ -647,22 +726,15 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     f.root_box[0] = root.xmin, f.root_box[1] = root.xmax, f.root_box[2] = root.ymin;
     f.root_box[3] = root.ymax, f.root_box[4] = root.zmin, f.root_box[5] = root.zmax;
 
-    // ---- the tree the kernels walk
-    build_walk_tree(f);
-
-    front_largest(f);
+    // ---- the trees the kernels walk
+    {
+        std::vector<Aabb> prim_box(n);
+        for (size_t p = 0; p < n; p++) prim_box[p] = b.boxes[f.prim_object[p]];
+        build_walk_trees(f, prim_box);
+    }
 
     // ---- choose the layout
-    bool compact = true;
-    for (size_t r = 0; r < f.wide_ref.size() && compact; r++) {
-        const uint32_t kind = f.wide_ref[r] >> 30;
-        if (kind == REF_NONE) continue;  // box never read
-        for (int k = 0; k < 6; k++)
-            if (!f32_exact(f.wide_box[r * 6 + k])) {
-                compact = false;
-                break;
-            }
-    }
+    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk);
     for (size_t i = 0; i < n && compact; i++) {
         const Shape& s = objs.objs[i].geom;
         if (s.kind != PRIM_TRIANGLE) continue;
@@ -674,32 +746,9 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
             }
     }
     f.compact = compact;
-
-    // ---- wide interior records.  An unused slot gets the inverted box [+inf, -inf], which no
-    // ray enters, so that the kernel's slab test says the right thing without looking at the kind.
-    const uint32_t n_wide = f.n_wide();
-    const double inf = std::numeric_limits<double>::infinity();
-    auto slot_bound = [&](uint32_t r, int ch, int k) {
-        const uint32_t kind = f.wide_ref[(size_t)r * 4 + ch] >> 30;
-        if (kind == REF_NONE) return (k & 1) ? -inf : inf;
-        return f.wide_box[((size_t)r * 4 + ch) * 6 + k];
-    };
-    if (compact) {
-        f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F32), 0);
-        Node4F32* nodes = reinterpret_cast<Node4F32*>(f.node_bytes.data());
-        for (uint32_t r = 0; r < n_wide; r++)
-            for (int ch = 0; ch < 4; ch++) {
-                nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
-                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = (float)slot_bound(r, ch, k);
-            }
-    } else {
-        f.node_bytes.assign((size_t)std::max(n_wide, 1u) * sizeof(Node4F64), 0);
-        Node4F64* nodes = reinterpret_cast<Node4F64*>(f.node_bytes.data());
-        for (uint32_t r = 0; r < n_wide; r++)
-            for (int ch = 0; ch < 4; ch++) {
-                nodes[r].ref[ch] = f.wide_ref[(size_t)r * 4 + ch];
-                for (int k = 0; k < 6; k++) nodes[r].box[ch][k] = slot_bound(r, ch, k);
-            }
+    for (WalkTree* t : {&f.gate, &f.walk}) {
+        if (compact) fill_nodes<Node4F32, float>(*t);
+        else fill_nodes<Node4F64, double>(*t);
     }
 
     // ---- primitive records in DFS order

@@ -45,6 +45,15 @@ struct ObjectList {
 
 Aabb shape_bbox(const Shape& s);
 
+struct WalkTree {
+    std::vector<double> box;    // n * 24
+    std::vector<uint32_t> ref;  // n * 4
+    uint32_t root_ref = 0;
+    uint32_t depth = 0;         // stack entries the traversal can need
+    std::vector<uint8_t> node_bytes;  // the records as the kernels read them (Node4F32 / Node4F64)
+    uint32_t n() const { return (uint32_t)(ref.size() / 4); }
+};
+
 struct FlatScene {
     // logical tree (always f64, used for export and as the source of the device records)
     std::vector<double> child_box;  // n_interior * 12
@@ -52,15 +61,14 @@ struct FlatScene {
     std::vector<uint32_t> prim_object;
     uint32_t root_ref = 0;
     uint32_t depth = 0;
-    // the walk tree: four-slot records over the reference's leaf groups (what the kernels traverse)
-    std::vector<double> wide_box;    // n_wide * 24
-    std::vector<uint32_t> wide_ref;  // n_wide * 4
-    uint32_t wide_root_ref = 0;
-    uint32_t wide_depth = 0;         // stack entries the traversal can need
+    // The trees the kernels traverse (scene_host.cpp "the walk trees"): four-slot records whose leaf slots are
+    //   gate  the reference's leaf groups behind their exact gating boxes -- reaches exactly what the reference
+    //         reaches; walked when rayrs_render_params.exact_traversal is set, and by the local-pool route;
+    //   walk  single primitives behind their own widened boxes inside the gating box -- the default.
+    WalkTree walk, gate;
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
-    // device images
-    std::vector<uint8_t> node_bytes;
+    // device images (the trees' records are in WalkTree::node_bytes)
     std::vector<uint8_t> prim_bytes;
     std::vector<float> hdri_quads;  // 16 floats per texel: the 2x2 footprint of a lookup at (i, j), RGBA each
     uint32_t hdri_w = 0, hdri_h = 0;
@@ -68,7 +76,6 @@ struct FlatScene {
     double build_seconds = 0;
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }
-    uint32_t n_wide() const { return (uint32_t)(wide_ref.size() / 4); }
 };
 
 // Scene::new (lib.rs:227-245) minus the upload.  Returns RAYRS_* status.

@@ -21,7 +21,6 @@ struct rayrs_scene {
     std::vector<rayrs::SurfaceDev> surfaces;
     uint64_t n_objects = 0;
     int device = -1;
-    void* d_nodes = nullptr;
     void* d_prims = nullptr;
     rayrs::SurfaceDev* d_surfaces = nullptr;
     float* d_hdri = nullptr;
@@ -33,9 +32,16 @@ struct rayrs_scene {
     bool pending = false;
     bool last_count = false;
     int cu_count = 0;
-    int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
-    uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
-    uint32_t hot_records = 0;    // leading wide records kept in LDS
+    // How the traversal kernel walks each of the scene's two trees: [0] FlatScene::walk (the default),
+    // [1] FlatScene::gate (rayrs_render_params.exact_traversal).
+    struct Walk {
+        void* d_nodes = nullptr;
+        int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
+        uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
+        uint32_t hot_records = 0;    // leading records kept in LDS
+    };
+    Walk trav[2];
+    const rayrs::WalkTree& tree(bool exact) const { return exact ? flat.gate : flat.walk; }
     uint64_t device_bytes = 0;
     // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,
     // per-wave item ranges and traversal-stack overflow strips, kept between renders.

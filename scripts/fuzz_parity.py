@@ -41,7 +41,7 @@ for seed in range(first, first + count):
         scene.set_tuning(pool_slots=int(r.integers(1, 40)) * 1024)
     img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
     ref0, ost0 = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)   # the reference's recursion
-    if seed % 4 == 1:   # rayrs_render_params.exact_traversal: the walk without culling -- the same frame, by construction
+    if seed % 4 == 1:   # rayrs_render_params.exact_traversal: the gate tree without culling -- the same frame, by construction
         imgx, stx = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, exact_traversal=True)
         if not (np.array_equal(imgx.view(np.uint64), ref0.view(np.uint64)) and stx["rays"] == ost0["rays"]):
             bad += 1
@@ -49,7 +49,8 @@ for seed in range(first, first + count):
     ok = np.array_equal(img.view(np.uint64), ref0.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths"):
         ok = ok and st[k] == ost0[k]
-    ref, ost = osc.use_walk_tree(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+    # (the local-pool route walks the gate tree: the groups behind their gating boxes)
+    ref, ost = osc.use_walk_tree(scene, gate=bool(scene.info()["local_pool"])).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
     ok = ok and np.array_equal(img.view(np.uint64), ref.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
         ok = ok and st[k] == ost[k]

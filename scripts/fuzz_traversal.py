@@ -1,19 +1,27 @@
-"""CPU-only fuzz of the claim the traversal kernel rests on: the walk over the product's four-slot records
-(oracle traversal=2: nearest-first order, slots entered beyond closest_t * TRAV_CULL_MARGIN = 1 + 2^-10 culled)
-returns the hit of the reference's recursion (traversal=0: BvhTree::intersect, bvh.rs:391-415, which never
-culls) -- on the geometry and rays where Moeller-Trumbore's t is least accurate: sliver triangles, nearly
-coplanar tessellated sheets whose group boxes are almost flat (hits sit on box faces), origins up to 1e6 scene
-sizes away, and two families of directions:
+"""CPU-only fuzz of the claims the traversal kernel rests on.  The reference's recursion (oracle traversal=0:
+BvhTree::intersect, bvh.rs:391-415) tests every primitive whose gating box the ray enters and never culls.  Against it,
+on the product's own trees (host-only scene, device = -1), walked by the oracle with the kernel's rules (traversal=2):
+  exact     the gate tree with no culling (rayrs_render_params.exact_traversal): the reference's visit set by
+            construction -- REQUIRED to match on every ray of every family;
+  default   the tree of single primitives behind their widened boxes, slots entered beyond closest_t * (1 + 2^-10)
+            culled: two bets on the reference's arithmetic (include/rayrs_hip.h exact_traversal).  REQUIRED to match on
+            the general family and on grazing rays 1e-7 rad and more off the plane from origins within 10 scene
+            sizes; counted and reported elsewhere;
+  leaves    the default tree with no culling: which of the default's mismatches are the leaf boxes' alone.
+The geometry is where Moeller-Trumbore is least accurate: sliver triangles, nearly coplanar tessellated sheets whose
+group boxes are almost flat (hits sit on box faces), scene scales 1e-3 .. 1e3, origins up to 1e6 scene sizes away, and
+two families of directions:
   general   elevations 1e-7 .. 1 rad over the sheet's mean plane, axis-aligned directions (0 * inf in the slab test)
   grazing   IN the plane of a chosen triangle plus 1e-13 .. 1e-3 of its normal, aimed at a point inside it
-The culling is exact in practice, not by construction: the walk is REQUIRED to match on the general family and on
-grazing rays 1e-7 rad and more off the plane (exit code); closer than that mismatches are counted and reported
-(the error of t grows like eps * distance / triangle size / angle: at 1e-9 rad and 5000 triangle sizes it reaches the margin).
-Also measures the margin itself: the largest (box entry - t) / t over all accepted hits and the boxes on their
+            (near: the origin within 10 scene sizes -- where a camera stands and every bounce ray starts; far: beyond)
+Culling loses a hit when a primitive's computed t lies more than the margin in front of a box around it (the error of
+t grows like eps * distance / triangle size / angle: at 1e-9 rad and 5000 triangle sizes it reaches 2^-10).  A leaf box
+loses one when the reference's own test accepts a hit on a primitive the ray passes beside by more than 1/64 of its
+size (the hit POINT moves by eps * distance / angle: from 1e4 scene sizes away at 1e-7 rad).
+Also measures the cull margin itself: the largest (box entry - t) / t over all accepted hits and the boxes on their
 root paths (oracle: orc_cull_margin_probe), per family.
 
-usage: python scripts/fuzz_traversal.py [rays_in_millions=10] [first_seed=1]
-No GPU: the product's walk tree comes from a host-only scene (device = -1)."""
+usage: python scripts/fuzz_traversal.py [rays_in_millions=10] [first_seed=1]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -97,47 +105,74 @@ def rays_for(rng, verts, scale, n):
     return o, d
 
 
+NEAR = 10.0  # scene sizes
+
+
+def families(seed, verts, idx, scale, per_scene):
+    """[(family name, origins, directions)] for one scene."""
+    rr = np.random.default_rng(seed * 7919 + 1)
+    og, dg = rays_for(rr, verts, scale, per_scene // 2)
+    oz, dz, eps = grazing_rays(rr, verts, idx, scale, per_scene - per_scene // 2)
+    centre = 0.5 * (verts.min(axis=0).astype(np.float64) + verts.max(axis=0).astype(np.float64))
+    near = np.linalg.norm(oz - centre, axis=1) <= NEAR * 2.0 * scale  # (a sheet spans 2 * scale)
+    out = [("general", og, dg)]
+    for name, sel in (("grazing >= 1e-7", eps >= 1e-7), ("grazing 1e-9..1e-7", (eps < 1e-7) & (eps >= 1e-9)), ("grazing < 1e-9", eps < 1e-9)):
+        out.append((name + " near", oz[sel & near], dz[sel & near]))
+        out.append((name + " far", oz[sel & ~near], dz[sel & ~near]))
+    return out
+
+
+REQUIRED = ("general", "grazing >= 1e-7 near")
+
+
 def main():
     millions = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     per_scene = 250_000
     n_scenes = max(1, int(millions * 1e6 / per_scene))
     hdri = np.zeros((2, 2, 3), dtype=np.float32)
-    fam = {k: dict(rays=0, hits=0, bad=0, worst=-1.0, in_front=0, beyond=0) for k in ("general", "grazing >= 1e-7", "grazing 1e-9..1e-7", "grazing < 1e-9")}
+    fam = {}
     t0 = time.time()
+    exact_bad = 0
     for seed in range(first, first + n_scenes):
         objs, heur, scale, verts, idx = scene_for(seed)
         tmin, tmax = 1e-6 * scale, 1e9 * scale
         prod = rayrs_amd.Scene(objs, tmin, tmax, heur, hdri, device=-1)
         osc = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod)
-        rr = np.random.default_rng(seed * 7919 + 1)
-        og, dg = rays_for(rr, verts, scale, per_scene // 2)
-        oz, dz, eps = grazing_rays(rr, verts, idx, scale, per_scene - per_scene // 2)
-        far, near = eps >= 1e-7, eps < 1e-9
-        mid = ~far & ~near
-        for name, o, d in (("general", og, dg), ("grazing >= 1e-7", oz[far], dz[far]), ("grazing 1e-9..1e-7", oz[mid], dz[mid]),
-                           ("grazing < 1e-9", oz[near], dz[near])):
-            f = fam[name]
+        osg = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod, gate=True)
+        for name, o, d in families(seed, verts, idx, scale, per_scene):
+            f = fam.setdefault(name, dict(rays=0, hits=0, default=0, leaves=0, exact=0, worst=-1.0, in_front=0, beyond=0))
             ta, oa = osc.intersect_batch(o, d, tmin, tmax, traversal=0)
             tb, ob = osc.intersect_batch(o, d, tmin, tmax, traversal=2)
-            bad = (oa != ob) | (ta.view(np.uint64) != tb.view(np.uint64))
+            try:
+                _oracle.set_cull_margin(float("inf"))
+                tl, ol = osc.intersect_batch(o, d, tmin, tmax, traversal=2)
+                tx, ox = osg.intersect_batch(o, d, tmin, tmax, traversal=2)
+            finally:
+                _oracle.set_cull_margin(2.0 ** -10)
+            differs = lambda t, ob_: (oa != ob_) | (ta.view(np.uint64) != t.view(np.uint64))
+            bad, badl, badx = differs(tb, ob), differs(tl, ol), differs(tx, ox)
             w, nf, nb = osc.cull_margin_probe(o, d, tmin, tmax)
-            f["rays"] += len(o); f["hits"] += int((oa >= 0).sum()); f["bad"] += int(bad.sum())
+            f["rays"] += len(o); f["hits"] += int((oa >= 0).sum())
+            f["default"] += int(bad.sum()); f["leaves"] += int(badl.sum()); f["exact"] += int(badx.sum())
             f["worst"] = max(f["worst"], w); f["in_front"] += nf; f["beyond"] += nb
-            if bad.any() and name in ("general", "grazing >= 1e-7"):
-                i = int(np.argmax(bad))
-                print(f"MISMATCH ({name}) seed {seed}: o={o[i].tolist()} d={d[i].tolist()} reference=({oa[i]}, {ta[i]!r}) "
-                      f"walk=({ob[i]}, {tb[i]!r})", flush=True)
+            exact_bad += int(badx.sum())
+            for which, bb, tw, ow in (("default", bad, tb, ob), ("exact", badx, tx, ox)):
+                if bb.any() and (which == "exact" or name in REQUIRED):
+                    i = int(np.argmax(bb))
+                    print(f"MISMATCH ({which} walk, {name}) seed {seed}: o={o[i].tolist()} d={d[i].tolist()} reference=({oa[i]}, {ta[i]!r}) "
+                          f"walk=({ow[i]}, {tw[i]!r})", flush=True)
         if (seed - first) % 16 == 15 or seed == first + n_scenes - 1:
             for name, f in fam.items():
                 lw = np.log2(f["worst"]) if f["worst"] > 0 else float("-inf")
-                print(f"{name:18s} {f['rays'] / 1e6:7.2f} M rays {f['hits'] / 1e6:7.2f} M hits  mismatches {f['bad']:5d}  largest (entry - t)/t "
-                      f"{f['worst']:.3e} (2^{lw:.1f})  hits in front of a box {f['in_front']}, beyond the margin {f['beyond']}", flush=True)
+                print(f"{name:24s} {f['rays'] / 1e6:7.2f} M rays {f['hits'] / 1e6:7.2f} M hits  mismatches: default {f['default']:5d} (leaf boxes alone {f['leaves']:5d})  "
+                      f"exact {f['exact']}  largest (entry - t)/t {f['worst']:.3e} (2^{lw:.1f})  hits in front of a box {f['in_front']}, beyond the margin {f['beyond']}", flush=True)
             print(f"  {time.time() - t0:.0f} s", flush=True)
-    required = fam["general"]["bad"] + fam["grazing >= 1e-7"]["bad"]
-    print("done:", sum(f["rays"] for f in fam.values()), "rays; mismatches where the walk must match:", required,
-          "; at 1e-9..1e-7 rad off a triangle's plane:", fam["grazing 1e-9..1e-7"]["bad"], "; closer:", fam["grazing < 1e-9"]["bad"])
-    sys.exit(1 if required else 0)
+    required = sum(fam[k]["default"] for k in REQUIRED if k in fam)
+    print("done:", sum(f["rays"] for f in fam.values()), "rays; exact walk mismatches (must be 0):", exact_bad,
+          "; default walk mismatches where it must match:", required,
+          "; elsewhere:", sum(f["default"] for k, f in fam.items() if k not in REQUIRED))
+    sys.exit(1 if (required or exact_bad) else 0)
 
 
 if __name__ == "__main__":

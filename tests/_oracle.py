@@ -78,6 +78,7 @@ def lib():
     L.orc_triangle_normal.argtypes = [dp, dp, dp, dp]
     L.orc_triangle_normal.restype = None
     L.orc_scene_bbox.argtypes = [vp, dp, dp, dp, dp]
+    L.orc_object_boxes.argtypes = [vp, vp]
     L.orc_bvh_intersect.restype = C.c_int64
     L.orc_bvh_intersect.argtypes = [vp, dp, dp, C.c_double, C.c_double, C.c_int, dp]
     L.orc_material_evaluate.argtypes = [mp, dp, dp, dp, C.c_uint64, C.POINTER(C.c_uint32), dp, dp]
@@ -213,15 +214,17 @@ class OracleScene:
                 "root_box": list(i.root_box), "n_wide": i.n_wide, "wide_root_ref": i.wide_root_ref,
                 "wide_depth": i.wide_depth}
 
-    def use_walk_tree(self, product_scene):
+    def use_walk_tree(self, product_scene, gate=False):
         """Take the four-slot records the kernels walk from the product (a rayrs_amd.Scene, host-only
-        or on a device): traversal=2 then makes the kernel's walk on the kernel's data."""
+        or on a device): traversal=2 then makes the kernel's walk on the kernel's data.  gate=True: the
+        tree rayrs_render_params.exact_traversal walks (and the local-pool route's gates come from)."""
         info = product_scene.info()
-        box, ref = product_scene.export_wide()
+        box, ref = product_scene.export_gate_tree() if gate else product_scene.export_wide()
         box = np.ascontiguousarray(box)
         ref = np.ascontiguousarray(ref)
-        assert self._L.orc_set_wide(self._h, info["n_wide"], info["wide_root_ref"], info["wide_depth"],
-                                    box.ctypes.data, ref.ctypes.data) == 0
+        pre = "gate_" if gate else "wide_"
+        assert self._L.orc_set_wide(self._h, info["gate_n_wide" if gate else "n_wide"], info[pre + "root_ref"],
+                                    info[pre + "depth"], box.ctypes.data, ref.ctypes.data) == 0
         return self
 
     def export_wide(self):
@@ -306,6 +309,12 @@ class OracleScene:
         dr = C.c_uint32(draw)
         n = self._L.orc_radiance(self._h, d3(o), d3(d), int(max_bounces), int(key), C.byref(dr), int(traversal), rgb)
         return np.array(rgb), int(n), dr.value
+
+    def object_boxes(self, n_objects):
+        """Object::bbox of every object in insertion order: (n_objects, 6)."""
+        out = np.zeros((n_objects, 6), dtype=np.float64)
+        assert self._L.orc_object_boxes(self._h, out.ctypes.data) == 0
+        return out
 
     def bbox(self):
         box, cen = (C.c_double * 6)(), (C.c_double * 3)()

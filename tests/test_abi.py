@@ -198,7 +198,7 @@ def test_which_route_a_scene_takes_is_decided_at_scene_new_and_needs_no_gpu():
         sc = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
         info = sc.info()
         assert info["local_pool"] == want, fn
-        assert (info["n_wide"] <= 1 and info["n_prims"] <= 16) == bool(want)
+        assert (info["gate_n_wide"] <= 1 and info["n_prims"] <= 16) == bool(want)
         sc.set_tuning(local_pool=1)
         assert sc.info()["local_pool"] == 0
     # seventeen primitives under one record cannot happen (4 slots x 4), but seventeen primitives can: two records

@@ -29,9 +29,8 @@ def same_tree(objs, heur):
         assert pi["root_box"] == oi["root_box"]
         assert np.array_equal(pr, orf) and np.array_equal(pp, op)
         assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64))
-    # the four-slot records the kernels walk are the product's own tree over the reference's groups
-    pwb, pwr = prod.export_wide()
-    check_walk_tree(pb, pr, pwb, pwr, pi)
+    # the four-slot records the kernels walk are the product's own trees over the reference's groups / primitives
+    check_walk_trees(prod, orc, pi["n_prims"])
     return pi, pr, pp
 
 
@@ -59,18 +58,51 @@ def reference_groups(box, ref, info):
     return groups
 
 
-def check_walk_tree(box, ref, wbox, wref, info):
-    """What makes the walk tree legal (scene_host.cpp build_walk_tree), checked from the outside:
-    every group of the reference's tree sits in exactly one leaf slot behind exactly its gating
-    box; every interior slot's box is the union of the boxes below it (so a ray that misses it
-    misses every gating box inside); unused slots are marked; every record is reached once; the
-    stack bound holds."""
+LEAF_MARGIN = 2.0 ** -6  # scene_host.cpp
+
+
+def tight_box(prim_box, gate):
+    """scene_host.cpp tight_box, restated: the primitive's box widened by LEAF_MARGIN of its largest extent,
+    rounded outwards to f32, clipped to the gating box."""
+    ext = max(prim_box[1] - prim_box[0], prim_box[3] - prim_box[2], prim_box[5] - prim_box[4])
+    m = ext * LEAF_MARGIN
+    out = np.zeros(6)
+    for a in range(3):
+        lo, hi = prim_box[2 * a] - m, prim_box[2 * a + 1] + m
+        with np.errstate(over="ignore"):
+            lf, hf = np.float32(lo), np.float32(hi)
+        if float(lf) > lo:
+            lf = np.nextafter(lf, np.float32(-np.inf))
+        if float(hf) < hi:
+            hf = np.nextafter(hf, np.float32(np.inf))
+        out[2 * a] = float(lf) if float(lf) > gate[2 * a] else gate[2 * a]
+        out[2 * a + 1] = float(hf) if float(hf) < gate[2 * a + 1] else gate[2 * a + 1]
+    return out
+
+
+def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False):
+    """What makes a walk tree legal (scene_host.cpp build_walk_trees), checked from the outside: every interior
+    slot's box is the union of the boxes below it (so a ray that misses it misses every leaf box inside); unused
+    slots are marked; every record is reached once; the stack bound holds; and
+      gate=True (the tree exact_traversal walks): every group of the reference's tree sits in exactly one leaf slot
+        behind exactly its gating box -- the tree reaches what the reference reaches;
+      gate=False (the default tree): every primitive sits alone in exactly one leaf slot, behind its own bounding
+        box (prim_boxes[p]: Object::bbox of the object behind primitive p) widened by LEAF_MARGIN and clipped to its
+        group's gating box -- inside the gating box, so it reaches nothing the reference does not, and around the
+        primitive with the margin to spare."""
     groups = reference_groups(box, ref, info)
-    if info["n_interior"] == 0:
-        assert info["n_wide"] == 0 and info["wide_root_ref"] == info["root_ref"] and info["wide_depth"] == 0
+    pre = "gate_" if gate else "wide_"
+    n_wide = info["gate_n_wide" if gate else "n_wide"]
+    if info["n_interior"] == 0:  # one bottom Node: both trees are the root group behind the root box
+        assert n_wide == 0 and info[pre + "root_ref"] == info["root_ref"] and info[pre + "depth"] == 0
         return
-    assert info["wide_root_ref"] >> 30 == 0
-    seen_groups = set()
+    assert info[pre + "root_ref"] >> 30 == 0
+    gate_of = {}  # primitive -> its group's gating box
+    for g, bb in groups.items():
+        first, count = (g & 0x3fffffff) >> 2, (g & 3) + 1
+        for p in range(first, first + count):
+            gate_of[p] = np.frombuffer(bb, dtype=np.float64)
+    seen_leaves = set()
     seen_records = set()
 
     def visit(w):  # -> (union box of the record's slots, stack entries needed below)
@@ -86,10 +118,21 @@ def check_walk_tree(box, ref, wbox, wref, info):
                 break
             used += 1
             b = wbox[w, k]
-            if kind == 1:
-                assert r in groups and r not in seen_groups
-                seen_groups.add(r)
+            if kind == 1 and gate:
+                assert r in groups and r not in seen_leaves
+                seen_leaves.add(r)
                 assert b.tobytes() == groups[r]
+            elif kind == 1:
+                assert r & 3 == 0  # one primitive
+                p = (r & 0x3fffffff) >> 2
+                assert p in gate_of and p not in seen_leaves
+                seen_leaves.add(p)
+                g, pb = gate_of[p], prim_boxes[p]
+                assert b.tobytes() == tight_box(pb, g).tobytes()
+                # what the construction is for (boxes whose bounds are not numbers aside)
+                if np.isfinite(pb).all() and np.isfinite(g).all():
+                    assert (b[0::2] >= g[0::2]).all() and (b[1::2] <= g[1::2]).all()
+                    assert (b[0::2] <= np.maximum(pb[0::2], g[0::2])).all() and (b[1::2] >= np.minimum(pb[1::2], g[1::2])).all()
             else:
                 assert kind == 0
                 (clo, chi), need = visit(r & 0x3fffffff)
@@ -101,11 +144,21 @@ def check_walk_tree(box, ref, wbox, wref, info):
 
     import sys
     sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
-    (lo, hi), need = visit(info["wide_root_ref"] & 0x3fffffff)
-    assert seen_groups == set(groups) and len(seen_records) == info["n_wide"]
-    assert need == info["wide_depth"]
+    (lo, hi), need = visit(info[pre + "root_ref"] & 0x3fffffff)
+    assert seen_leaves == (set(groups) if gate else set(gate_of)) and len(seen_records) == n_wide
+    assert need == info[pre + "depth"]
     root = np.array(info["root_box"])
-    assert np.array_equal(lo, root[0::2]) and np.array_equal(hi, root[1::2])
+    if gate:
+        assert np.array_equal(lo, root[0::2]) and np.array_equal(hi, root[1::2])
+    else:
+        assert (lo >= root[0::2]).all() and (hi <= root[1::2]).all()
+
+
+def check_walk_trees(prod, orc, n_objects):
+    pb, pr, pp = prod.export_bvh()
+    info = prod.info()
+    check_walk_tree(pb, pr, *prod.export_gate_tree(), info, gate=True)
+    check_walk_tree(pb, pr, *prod.export_wide(), info, prim_boxes=orc.object_boxes(n_objects)[pp])
 
 
 SCENE_FNS = [scenes.diffuse_single_sphere, scenes.cook_torrance_spheres_metallic, scenes.material_test,
@@ -195,8 +248,7 @@ def test_large_mesh_builder_agreement():
     pb, pr, pp = prod.export_bvh()
     ob, orf, op = orc.export_bvh()
     assert np.array_equal(pr, orf) and np.array_equal(pp, op) and np.array_equal(pb, ob)
-    pwb, pwr = prod.export_wide()
-    check_walk_tree(pb, pr, pwb, pwr, prod.info())
+    check_walk_trees(prod, orc, prod.info()["n_prims"])
 
 
 def test_largest_boxes_lead_the_wide_records():

@@ -220,10 +220,11 @@ def _gpu_intersect(scene, o, d, exact):
     return t, obj
 
 
-def test_exact_traversal_returns_the_reference_hit_where_culling_loses_it():
-    """rayrs_render_params.exact_traversal / rayrs_test_intersect(exact = 1): the walk culls nothing (cull margin
-    +infinity), so it visits exactly the boxes BvhTree::intersect visits and returns the reference's closest hit BY
-    CONSTRUCTION -- also for the pinned ray of tests/test_walk_tree.py, within 1e-9 rad of a triangle's plane, whose
+def test_exact_traversal_returns_the_reference_hit_where_the_default_walk_loses_it():
+    """rayrs_render_params.exact_traversal / rayrs_test_intersect(exact = 1): the walk of the gate tree (the
+    reference's groups behind their gating boxes) culls nothing (cull margin +infinity), so it tests exactly the
+    primitives BvhTree::intersect tests and returns the reference's closest hit BY
+    CONSTRUCTION -- also for the pinned rays of tests/test_walk_tree.py: the one within 1e-9 rad of a triangle's plane, whose
     hit the default margin of 2^-10 loses (the default walk returns what the oracle's culled walk returns: the
     neighbour 2 % behind), and for grazing rays of ANY angle, which the default only gets right from 1e-7 rad up."""
     import os, sys
@@ -243,6 +244,21 @@ def test_exact_traversal_returns_the_reference_hit_where_culling_loses_it():
     assert obj[0] == wobj[0] and bits(t)[0] == bits(wt)[0]       # the heuristic's known failure, reproduced
     t, obj = _gpu_intersect(scene, o, d, exact=1)
     assert obj[0] == robj[0] and bits(t)[0] == bits(rt)[0]       # no culling: the reference's answer
+    # the other bet: a ray along a triangle's plane from 130 000 scene sizes away, on which the reference's own test
+    # accepts a neighbour the ray passes beside by more than the 1/64 the default tree's leaf boxes allow
+    objs, heur, scale, verts, idx = F.scene_for(2)
+    t0, t1 = 1e-6 * scale, 1e9 * scale
+    scene = Scene(objs, t0, t1, heur, hdri, device=0)
+    osc = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(scene)
+    o = np.array([[-2.8981278659447747, -633.8240400572021, 259665.5017321564]])
+    d = np.array([[0.0002220828721502402, 0.05051414085108857, -20.691401286965466]])
+    rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)
+    wt, wobj = osc.intersect_batch(o, d, t0, t1, traversal=2)
+    assert robj[0] >= 0 and wobj[0] >= 0 and wobj[0] != robj[0]
+    t, obj = _gpu_intersect(scene, o, d, exact=0)
+    assert obj[0] == wobj[0] and bits(t)[0] == bits(wt)[0]
+    t, obj = _gpu_intersect(scene, o, d, exact=1)
+    assert obj[0] == robj[0] and bits(t)[0] == bits(rt)[0]
     # rays aimed along triangles' own planes at every angle down to 1e-12 rad, and general rays, on sliver meshes and
     # nearly flat sheets: exact = 1 equals the recursion on all of them
     n_hits = 0

@@ -1,11 +1,13 @@
 """The two routes of the radiance integrator render the same bits.
 
-Scenes whose walk tree is at most one record (the reference's example scenes: a floor and one to
+Scenes whose gate tree is at most one record (the reference's example scenes: a floor and one to
 seven spheres, test_scenes.rs:14-256) are rendered by ONE launch that keeps every path in LDS from its
 first ray to its last (rayrs_amd/csrc/local_pool.hip); everything else -- and the same scenes with
 rayrs_tuning.local_pool = 1 -- streams its paths through the pool in HBM, three launches per bounce
 (wavefront.hip).  Both call device_path.h's functions, so both must reproduce the oracle's frame bit
-for bit, its ray / path / escaped-path counts, and each other's work counters."""
+for bit, its ray / path / escaped-path counts, and the work counters of the oracle's walk on the tree each
+walks (the local pool: the groups behind their gating boxes; the streaming kernels: the default tree of single
+primitives behind their own boxes)."""
 import numpy as np
 import pytest
 
@@ -32,6 +34,9 @@ def frames(cam_args, objs, heur, w, h, spp, mb, chunk=0, seed=0x5EED, count_work
     osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
     ocam = _oracle.OracleCamera(*cam_args)
     ref, ost = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)
+    if count_work:  # the oracle's walk on the records each route walks
+        _, ost["gate_walk"] = osc.use_walk_tree(scene, gate=True).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+        _, ost["default_walk"] = osc.use_walk_tree(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
     return (loc, lst), (stream, sst), (ref, ost)
 
 
@@ -66,8 +71,12 @@ def test_local_pool_streaming_and_oracle_agree(name, scene_fn, w, h, spp, mb, ch
     assert lst["kernel_launches"] == 1 and sst["kernel_launches"] > 1
     assert same_bits(loc, ref), f"local pool: {int((loc != ref).any(axis=2).sum())} pixels differ from the oracle"
     assert same_bits(stream, ref)
-    # the same work on either route: records entered, primitive tests by kind, hits per surface, direct rays
-    for k in ("interior_visits", "tri_tests", "sphere_tests", "plane_tests", "surface_hits", "direct_rays"):
+    # the work of each route: records entered and primitive tests by kind are the oracle's on the tree it walks;
+    # hits per surface and direct rays do not depend on the tree
+    for k in ("interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
+        assert lst[k] == ost["gate_walk"][k], k
+        assert sst[k] == ost["default_walk"][k], k
+    for k in ("surface_hits", "direct_rays"):
         assert lst[k] == sst[k], k
 
 
@@ -126,7 +135,7 @@ def test_selection_rule_on_both_sides_of_the_threshold():
         objs = [floor] + spheres(n)
         scene = rayrs_amd.Scene(objs, 1e-6, 1e6, BvhHeuristic.Sah(1000), HDRI, device=0)
         info = scene.info()
-        assert info["local_pool"] == (1 if info["n_wide"] <= 1 and info["n_prims"] <= 16 else 0)
+        assert info["local_pool"] == (1 if info["gate_n_wide"] <= 1 and info["n_prims"] <= 16 else 0)
         seen.add(info["local_pool"])
         cam = rayrs_amd.Camera(*cam_args)
         img, st = rayrs_amd.render(scene, cam, 4, 50, seed=5, out_f64=True)

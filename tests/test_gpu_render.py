@@ -237,9 +237,10 @@ def test_render_multi_runs_its_rccl_reduce_on_one_device(route):
 
 
 def test_exact_traversal_renders_the_same_frame_with_more_visits():
-    """rayrs_render_params.exact_traversal = 1: nothing is culled by the closest hit so far -- the reference's own
-    visit set (bvh.rs:391-415).  The frame is the oracle's and the default's; the walk visits more records and tests
-    more primitives (what the default saves), and equals the oracle's walk with its margin set to infinity."""
+    """rayrs_render_params.exact_traversal = 1: the reference's leaf groups behind their gating boxes, nothing culled
+    by the closest hit so far -- the reference's own visit set (bvh.rs:391-415).  The frame is the oracle's and the default's; the walk visits more records and tests
+    more primitives (what the default saves), and equals the oracle's walk of the gate tree with its margin set
+    to infinity."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 96, 64, 4)
     a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
     b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, exact_traversal=True)
@@ -250,7 +251,7 @@ def test_exact_traversal_renders_the_same_frame_with_more_visits():
     assert sb["interior_visits"] > sa["interior_visits"] and sb["tri_tests"] > sa["tri_tests"]
     try:
         _oracle.set_cull_margin(float("inf"))
-        _, wst = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
+        _, wst = osc.use_walk_tree(scene, gate=True).render(ocam, 4, traversal=2)
     finally:
         _oracle.set_cull_margin(2.0 ** -10)
     for k in ("interior_visits", "tri_tests", "plane_tests"):
