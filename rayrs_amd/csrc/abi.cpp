@@ -494,7 +494,7 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
-    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u)
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
@@ -579,8 +579,9 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
-    const WalkTree& t = s->tree(exact);
-    const rayrs_scene::Walk& w = s->trav[exact ? 1 : 0];
+    const bool gate = exact || s->lab.gate_tree != 0u;
+    const WalkTree& t = s->tree(gate);
+    const rayrs_scene::Walk& w = s->trav[gate ? 1 : 0];
     sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
     sc.surfaces = s->d_surfaces;
@@ -659,7 +660,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = lab.refill_min ? lab.refill_min : 52u;
-    rp.leaf_min = lab.leaf_min ? lab.leaf_min : 32u;
+    rp.leaf_min = lab.leaf_min ? lab.leaf_min : 24u;  // (32 while a leaf slot held a group of up to four primitives: 612 -> 604 ms of traversal on the headline frame)
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;
@@ -715,7 +716,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->trav[params->exact_traversal ? 1 : 0].blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[(params->exact_traversal || lab.gate_tree) ? 1 : 0].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;

@@ -19,7 +19,7 @@ extern "C" {
 
 typedef struct {
     uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
-    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (32) */
+    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (24) */
     uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
     uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
     uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
@@ -32,6 +32,9 @@ typedef struct {
                                as far as needed to keep a frame within 64 segments */
     uint32_t force_rccl;    /* rayrs_render_multi: run the RCCL reduce even when every handle sits on one device
                                (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
+    uint32_t gate_tree;     /* 1 = the default walk (with closest-hit culling) over the gate tree instead of the tree
+                               of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
+                               profiles/r04_tight_leaves.txt */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

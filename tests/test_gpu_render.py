@@ -258,6 +258,21 @@ def test_exact_traversal_renders_the_same_frame_with_more_visits():
         assert sb[k] == wst[k], k
 
 
+def test_the_culling_walk_on_the_gate_tree_is_still_there_for_comparisons():
+    """rayrs_lab.h gate_tree: rounds 2 and 3 walked the reference's groups behind their gating boxes with closest-hit
+    culling; scripts/ubench/exact_cost.py prices the default tree against it.  Same frame, the oracle's counters."""
+    scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 96, 64, 4)
+    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    scene.lab_set(gate_tree=1)
+    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    scene.lab_set()
+    assert_same_frame(a, b)
+    _, wst = osc.use_walk_tree(scene, gate=True).render(ocam, 4, traversal=2)
+    for k in ("rays", "interior_visits", "tri_tests", "plane_tests"):
+        assert sb[k] == wst[k], k
+    assert sa["tri_tests"] < sb["tri_tests"]  # what the leaf boxes are for
+
+
 def test_render_multi_rejects_bad_handles():
     from rayrs_amd import _ffi
     scene, cam, osc, ocam = both(scenes.diffuse_single_sphere, 16, 16, 1)
