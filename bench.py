@@ -215,6 +215,15 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the framebuffer reduce also with one rank (under "
                          "torch.distributed.run --nproc-per-node=1): the RCCL code path of an N-GPU run on a one-GPU box")
+    ap.add_argument("--no-stagger", action="store_true", help="development only: start all flights at once")
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="development only: render the tile share rank 0 of N would (what one GPU of N does), on one GPU")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered at a time, each by its own host thread on its own clone of the scene (own path "
+                         "pool) and HIP stream: the end of a frame -- a thinning pool, small launches -- overlaps the start "
+                         "of the next (and a rank's RCCL reduce the next frame's rendering).  1 = one frame after the other; "
+                         "0 = 2 when the frame is shared among GPUs (the end of a one-eighth share is 12 %% of it: 170 -> 158 ms "
+                         "per frame), 1 on one GPU (2 %% of a whole frame: measured +-0, for twice the pool memory)")
     ap.add_argument("--no-build", action="store_true",
                     help="do not run make: required under rocprofv3 (a profiled process must not spawn the compiler); "
                          "fails if the library is older than its sources")
@@ -257,6 +266,10 @@ def main():
     ply_path = os.path.join(tempfile.gettempdir(), f"rayrs_bench_mesh_rank{rank}.ply") if args.config in (3, 5) else None
     cam_args, objs, heur, spp, max_bounces = scenes.config(args.config, ply_path=ply_path)
     reduced = False
+    if args.share_of:
+        if world != 1:
+            raise SystemExit("--share-of is a one-GPU development option")
+        reduced = True
     if args.spp:
         spp, reduced = args.spp, True
     W0 = H0 = {1: 256, 2: 1024, 3: 1024, 4: 2048, 5: 2048}[args.config]
@@ -275,6 +288,15 @@ def main():
     info = scene.info()
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream(dev)
+    # frames in flight: flight 0 is the scene itself on the current stream; the others are clones (same records, own
+    # pool) on streams of their own
+    import threading
+    n_flights = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 or args.share_of) else 1)
+    n_flights = max(1, min(n_flights, args.steps))
+    # (with more than one flight none of them uses the null stream, whose launches order against every other stream's)
+    flights = [{"scene": scene, "stream": stream if n_flights == 1 else torch.cuda.Stream(dev)}]
+    for _ in range(n_flights - 1):
+        flights.append({"scene": scene.clone_to_device(local_rank), "stream": torch.cuda.Stream(dev)})
 
     def workload_key(W, H, chunk, camera=None):
         return f"config{args.config}_{camera or args.camera}_{W}x{H}_{spp}spp_chunk{chunk}_world{world}"
@@ -286,21 +308,69 @@ def main():
         # a pixel's samples are summed in chunks; the chunk comes from the WHOLE frame (rayrs_frame_sample_chunk:
         # at most 2^30 (pixel, chunk) items), never from the rank count, so every N renders the same bits
         chunk = rayrs_amd.frame_sample_chunk(W, H, spp, args.sample_chunk)
-        fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        F = max(1, min(n_flights, steps))
+        fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
         params = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
-                                       tile_ranks=world)
+                                       tile_ranks=args.share_of if args.share_of else world)
+        turn = {"n": 0, "failed": None}
+        cv = threading.Condition()
 
-        def step():
-            fb.zero_()
-            rayrs_amd.render_launch(scene, cam, params, fb.data_ptr(), stream.cuda_stream)
-            if use_dist and args.backend == "nccl":
-                tiles.reduce_framebuffer(fb, dst=0)       # RCCL over xGMI, ordered after the render on this stream
-            st = rayrs_amd.render_finish(scene)
-            if use_dist and args.backend != "nccl":       # rehearsal: reduce through host memory
-                host = fb.cpu()
-                tiles.reduce_framebuffer(host, dst=0)
-                fb.copy_(host)
-            return st
+        def my_turn(k):  # collectives are issued in frame order, whichever thread renders the frame
+            with cv:
+                while turn["n"] != k:
+                    if turn["failed"] is not None:
+                        raise RuntimeError("another flight failed")
+                    cv.wait(timeout=1.0)
+
+        def pass_turn():
+            with cv:
+                turn["n"] += 1
+                cv.notify_all()
+
+        def frames(n_frames, stagger_s=0.0):
+            """Renders n_frames frames, frame k on flight k % F; returns their stats in frame order.  Flight i starts
+            i * stagger_s late, so that the flights' frames end at different times."""
+            stats = [None] * n_frames
+            turn["n"], turn["failed"] = 0, None
+
+            def flight(i):
+                try:
+                    torch.cuda.set_device(dev)
+                    f, fb = flights[i], fbs[i]
+                    if i and stagger_s > 0.0:
+                        time.sleep(i * stagger_s)
+                    with torch.cuda.stream(f["stream"]):
+                        for k in range(i, n_frames, F):
+                            fb.zero_()
+                            rayrs_amd.render_launch(f["scene"], cam, params, fb.data_ptr(), f["stream"].cuda_stream)
+                            if use_dist and args.backend == "nccl":
+                                my_turn(k)
+                                tiles.reduce_framebuffer(fb, dst=0)   # RCCL over xGMI, ordered after the render on this stream
+                                pass_turn()
+                            st = rayrs_amd.render_finish(f["scene"])
+                            if use_dist and args.backend != "nccl":   # rehearsal: reduce through host memory
+                                my_turn(k)
+                                host = fb.cpu()
+                                tiles.reduce_framebuffer(host, dst=0)
+                                fb.copy_(host)
+                                pass_turn()
+                            stats[k] = st
+                except BaseException as e:  # noqa: BLE001 -- handed to the main thread below
+                    with cv:
+                        turn["failed"] = e
+                        cv.notify_all()
+
+            if F == 1:
+                flight(0)
+            else:
+                th = [threading.Thread(target=flight, args=(i,)) for i in range(F)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+            if turn["failed"] is not None:
+                raise turn["failed"]
+            return stats
 
         def fence():
             if use_dist:
@@ -308,18 +378,31 @@ def main():
             torch.cuda.synchronize(dev)
 
         st = None
-        for _ in range(warmup):
-            st = step()
+        if warmup:
+            st = frames(warmup)[-1]
         fence()
         t_begin = time.perf_counter()
-        rays = 0
-        kernel_ms, hit_ms, miss_ms = [], [], []
-        for _ in range(steps):
-            st = step()
-            rays += st["rays"]
-            kernel_ms.append(st["kernel_ms"]), hit_ms.append(st["hit_ms"]), miss_ms.append(st["miss_ms"])
+        timed = frames(steps, stagger_s=(st["trace_ms"] * 1e-3 / F) if (st is not None and F > 1 and not args.no_stagger) else 0.0)
         fence()
         elapsed = time.perf_counter() - t_begin
+        st = timed[-1]
+        fb = fbs[(steps - 1) % F]
+        rays = sum(t["rays"] for t in timed)
+        alone_ms = None
+        if F > 1 and want_roofline:
+            # the kernels' own durations: one more frame, rendered alone (with frames in flight the kernels of two
+            # frames share the GPU and a launch's duration is not its own)
+            fb_alone = torch.zeros_like(fbs[0])
+            rayrs_amd.render_launch(scene, cam, params, fb_alone.data_ptr(), stream.cuda_stream)
+            one = rayrs_amd.render_finish(scene)
+            del fb_alone
+            timed_for_kernels = [one]
+            alone_ms = one["trace_ms"]
+        else:
+            timed_for_kernels = timed
+        kernel_ms = [t["kernel_ms"] for t in timed_for_kernels]
+        hit_ms = [t["hit_ms"] for t in timed_for_kernels]
+        miss_ms = [t["miss_ms"] for t in timed_for_kernels]
 
         tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         if use_dist:
@@ -340,7 +423,7 @@ def main():
             # same launch once more with the work counters compiled in (untimed): the work of a launch is a
             # pure function of (scene, seed), so the counts apply to the timed launches exactly
             pc = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
-                                       tile_ranks=world, count_work=True)
+                                       tile_ranks=args.share_of if args.share_of else world, count_work=True)
             fb2 = torch.zeros_like(fb)
             rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
             cst = rayrs_amd.render_finish(scene)
@@ -348,6 +431,7 @@ def main():
             shares = ray_shares(cst, args.config, info["n_surfaces"])
             launches = st["kernel_launches"]                          # traversal launches = path rounds (local pool: segments)
             step_ms = max_elapsed / steps * 1e3
+            share_base_ms = alone_ms if alone_ms is not None else step_ms
             n_st = len(kernel_ms)
             units = surface_units(objs)
             ops_hit, ops_miss, ops_gen = shading_ops(cst, units)
@@ -363,7 +447,7 @@ def main():
                         "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)},
                         "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss}}
             for k in kern.values():
-                k["share_of_step"] = round(k["ms"] / step_ms, 3)
+                k["share_of_step"] = round(k["ms"] / share_base_ms, 3)
                 k["achieved_Tops"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9, 3)
                 k["frac"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9 / F64_PEAK_TOPS, 4)
                 k["ms"] = round(k["ms"], 3)
@@ -416,7 +500,10 @@ def main():
                 "frac_without_layout_conversions": round(frac_no_conv, 4),
                 "step": whole_step,
                 "kernel": dom, "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
-                "kernel_share_of_step": round(dom_ms / step_ms, 3),
+                "kernel_times_from": "the timed steps" if F == 1 else
+                                     "one more frame rendered alone behind the timed region (frames in flight share the GPU: "
+                                     "a launch's duration there is not its own); shares are of that frame's duration",
+                "kernel_share_of_step": round(dom_ms / share_base_ms, 3),
                 "definition": "the kernel with the largest share of the step: useful lane operations it is charged with / its "
                               "HIP-event time / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz = vector issue rate of f64-width "
                               "instructions; no FMA credit: the reference's arithmetic is unfused).  Traversal units (record, "
@@ -444,7 +531,8 @@ def main():
                 "fabric_frac_of_hbm_peak": None if fabric_gbs is None else round(fabric_gbs / HBM_PEAK_GBS, 4),
                 "fp64_valu_busy": valu_busy, "valu_wave_instructions_per_ray": valu_per_ray, "pmc_source": pmc_src,
             }
-        return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6,
+        return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6, "flights": F,
+                "frame_alone_ms": alone_ms,
                 "ms_per_step": max_elapsed / steps * 1e3, "rays_per_step": int(total_rays / steps),
                 "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares}
 
@@ -526,6 +614,11 @@ def main():
                 "resolution": [W, H], "spp": spp, "max_bounces": max_bounces, "primitives": n_prims,
                 "sample_chunk": chunk, "parallelism": f"8x8 image tiles interleaved over {world} GPU(s), "
                                                       f"scene replicated, one RCCL reduce of the f32x3 framebuffer",
+                # a step is one whole frame; with more than one in flight consecutive steps overlap (the end of a frame
+                # runs beside the start of the next), so ms_per_step = timed region / steps is a throughput figure and
+                # frame_alone_ms the latency of a frame rendered with the GPU to itself
+                "frames_in_flight": main_run["flights"],
+                "frame_alone_ms": None if main_run["frame_alone_ms"] is None else round(main_run["frame_alone_ms"], 2),
                 "layout": "compact f32 records" if info["compact"] else "f64 records",
                 "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"], "scene_bytes": info["device_bytes"],
                 "scene_build_s": round(build_s, 2), "source_hash": source_hash(),

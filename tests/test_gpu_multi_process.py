@@ -56,3 +56,38 @@ def test_bench_with_one_rank_runs_the_rccl_reduce():
     assert coll["librccl_mapped"] and "librccl" in coll["librccl_mapped"]
     assert forced["framebuffer_sha256"] == one["framebuffer_sha256"]
     assert forced["rays_per_step"] == one["rays_per_step"] and forced["n_gpus"] == 1
+
+
+def _with(args, **repl):
+    out = list(args)
+    for k, v in repl.items():
+        i = out.index("--" + k)
+        out[i + 1] = str(v)
+    return out
+
+
+def test_frames_in_flight_render_the_same_frames_in_frame_order():
+    """bench.py --frames-in-flight: with the frame shared among GPUs a rank keeps two frames in flight (own host
+    thread, own clone of the scene and path pool, own HIP stream each), so that the end of one overlaps the start of
+    the next; the framebuffer reduces are issued in frame order whichever thread rendered the frame.  Rehearsed with
+    two ranks on the one GPU (gloo), with the RCCL reduce of one rank (nccl), and on a one-eighth share alone: the
+    assembled frame stays the single-process frame, bit for bit."""
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
+    assert one["config"]["frames_in_flight"] == 1
+    five = _with(COMMON, steps=5, warmup=1)
+    port = 29800 + (os.getpid() % 1000)
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+               "--backend", "gloo", "--device", "0"] + five)
+    assert two["config"]["frames_in_flight"] == 2 and two["steps"] == 5
+    assert two["framebuffer_sha256"] == one["framebuffer_sha256"] and two["rays_per_step"] == one["rays_per_step"]
+    forced = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                  "--master-addr", "127.0.0.1", "--master-port", str(port + 1), "bench.py", "--gpus", "1",
+                  "--force-dist", "--backend", "nccl", "--frames-in-flight", "3"] + five)
+    assert forced["config"]["frames_in_flight"] == 3 and forced["config"]["collective"]["backend"] == "nccl"
+    assert forced["framebuffer_sha256"] == one["framebuffer_sha256"]
+    a = run([sys.executable, "bench.py", "--gpus", "1", "--share-of", "8", "--frames-in-flight", "1"] + five)
+    b = run([sys.executable, "bench.py", "--gpus", "1", "--share-of", "8"] + five)
+    assert a["config"]["frames_in_flight"] == 1 and b["config"]["frames_in_flight"] == 2
+    assert a["framebuffer_sha256"] == b["framebuffer_sha256"] != one["framebuffer_sha256"]
+    assert a["rays_per_step"] == b["rays_per_step"] < one["rays_per_step"]
