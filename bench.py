@@ -222,8 +222,9 @@ def main():
                     help="frames rendered at a time, each by its own host thread on its own clone of the scene (own path "
                          "pool) and HIP stream: the end of a frame -- a thinning pool, small launches -- overlaps the start "
                          "of the next (and a rank's RCCL reduce the next frame's rendering).  1 = one frame after the other; "
-                         "0 = 2 when the frame is shared among GPUs (the end of a one-eighth share is 12 %% of it: 170 -> 158 ms "
-                         "per frame), 1 on one GPU (2 %% of a whole frame: measured +-0, for twice the pool memory)")
+                         "0 = 3 when the frame is shared among GPUs (the end of a one-eighth share is 12 %% of it: 170 -> 158 -> 156 ms "
+                         "per frame with 2 and 3; a quarter 322 -> 310 -> 305; a half 617 -> 614 -> 612), 1 on one GPU (2 %% of a "
+                         "whole frame: measured +-0, for twice the pool memory)")
     ap.add_argument("--no-build", action="store_true",
                     help="do not run make: required under rocprofv3 (a profiled process must not spawn the compiler); "
                          "fails if the library is older than its sources")
@@ -291,7 +292,7 @@ def main():
     # frames in flight: flight 0 is the scene itself on the current stream; the others are clones (same records, own
     # pool) on streams of their own
     import threading
-    n_flights = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 or args.share_of) else 1)
+    n_flights = args.frames_in_flight if args.frames_in_flight > 0 else (3 if (world > 1 or args.share_of) else 1)
     n_flights = max(1, min(n_flights, args.steps))
     # (with more than one flight none of them uses the null stream, whose launches order against every other stream's)
     flights = [{"scene": scene, "stream": stream if n_flights == 1 else torch.cuda.Stream(dev)}]

@@ -67,10 +67,10 @@ def _with(args, **repl):
 
 
 def test_frames_in_flight_render_the_same_frames_in_frame_order():
-    """bench.py --frames-in-flight: with the frame shared among GPUs a rank keeps two frames in flight (own host
+    """bench.py --frames-in-flight: with the frame shared among GPUs a rank keeps three frames in flight (own host
     thread, own clone of the scene and path pool, own HIP stream each), so that the end of one overlaps the start of
     the next; the framebuffer reduces are issued in frame order whichever thread rendered the frame.  Rehearsed with
-    two ranks on the one GPU (gloo), with the RCCL reduce of one rank (nccl), and on a one-eighth share alone: the
+    two ranks on the one GPU (gloo), with the RCCL reduce of one rank from two threads (nccl), and on a one-eighth share alone: the
     assembled frame stays the single-process frame, bit for bit."""
     one = run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
     assert one["config"]["frames_in_flight"] == 1
@@ -79,15 +79,15 @@ def test_frames_in_flight_render_the_same_frames_in_frame_order():
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
                "--backend", "gloo", "--device", "0"] + five)
-    assert two["config"]["frames_in_flight"] == 2 and two["steps"] == 5
+    assert two["config"]["frames_in_flight"] == 3 and two["steps"] == 5
     assert two["framebuffer_sha256"] == one["framebuffer_sha256"] and two["rays_per_step"] == one["rays_per_step"]
     forced = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
                   "--master-addr", "127.0.0.1", "--master-port", str(port + 1), "bench.py", "--gpus", "1",
-                  "--force-dist", "--backend", "nccl", "--frames-in-flight", "3"] + five)
-    assert forced["config"]["frames_in_flight"] == 3 and forced["config"]["collective"]["backend"] == "nccl"
+                  "--force-dist", "--backend", "nccl", "--frames-in-flight", "2"] + five)
+    assert forced["config"]["frames_in_flight"] == 2 and forced["config"]["collective"]["backend"] == "nccl"
     assert forced["framebuffer_sha256"] == one["framebuffer_sha256"]
     a = run([sys.executable, "bench.py", "--gpus", "1", "--share-of", "8", "--frames-in-flight", "1"] + five)
     b = run([sys.executable, "bench.py", "--gpus", "1", "--share-of", "8"] + five)
-    assert a["config"]["frames_in_flight"] == 1 and b["config"]["frames_in_flight"] == 2
+    assert a["config"]["frames_in_flight"] == 1 and b["config"]["frames_in_flight"] == 3
     assert a["framebuffer_sha256"] == b["framebuffer_sha256"] != one["framebuffer_sha256"]
     assert a["rays_per_step"] == b["rays_per_step"] < one["rays_per_step"]
