@@ -1290,7 +1290,7 @@ static void flatten(orc_scene* s) {
 }
 
 /* The tree the HIP traversal kernel walks is NOT built here: it is the product's own
- * (rayrs_amd/csrc/scene_host.cpp build_walk_tree), handed over through
+ * (rayrs_amd/csrc/scene_host.cpp build_walk_trees), handed over through
  * rayrs_scene_export_wide and orc_set_wide so that isect_wide below makes the kernel's walk
  * on the kernel's data.  What makes that tree legal -- every group of the reference's tree
  * appears exactly once behind its exact gating box, every interior box contains what is

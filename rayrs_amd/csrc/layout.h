@@ -7,7 +7,7 @@
 //   primitive record triangle | sphere | plane + tag, DFS order  48 B (compact) /  80 B (full)
 //
 // The wide records are the product's own tree over the reference's leaf groups
-// (scene_host.cpp build_walk_tree); the two-child records of the reference's tree
+// (scene_host.cpp build_walk_trees); the two-child records of the reference's tree
 // exist on the host only (rayrs_scene_export_bvh).
 //
 // "compact" = every box bound and every triangle vertex is exactly

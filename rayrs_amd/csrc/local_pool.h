@@ -20,7 +20,7 @@ constexpr uint32_t LP_PATHS_PER_WAVE = LP_P;
 // The scene's gating boxes as kernel arguments: what is left of the BVH when the walk tree has at most one
 // record.  Gate g is one leaf group of the reference's tree (primitives first .. first + count - 1 in
 // depth-first order) behind exactly the box whose slab test gates the reference's access to it
-// (scene_host.cpp build_walk_tree); with no record at all the only gate is the root group behind the root box.
+// (scene_host.cpp build_walk_trees: the gate tree); with no record at all the only gate is the root group behind the root box.
 struct LocalScene {
     double box[LP_MAX_GATES][6];  // xmin xmax ymin ymax zmin zmax
     uint32_t first[LP_MAX_GATES], count[LP_MAX_GATES];

@@ -190,7 +190,7 @@ RR_DEV uint32_t lp_gen(const Pool& pl, bool valid, uint32_t p, const SceneDev& s
 }
 
 // ---- ISECT: Bvh::intersect (bvh.rs:391-415) on a walk tree of at most one record.  What decides whether the
-// reference reaches a primitive is one box, its gating box (scene_host.cpp build_walk_tree), after the root
+// reference reaches a primitive is one box, its gating box (scene_host.cpp build_walk_trees: the gate tree), after the root
 // Node's; the closest hit is the smallest accepted t, the first primitive in depth-first order on exact ties
 // (bvh.rs:62).  Gates and primitives are the same for every lane: the loops are wave-uniform and the records
 // arrive through the scalar cache.

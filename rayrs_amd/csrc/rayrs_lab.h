@@ -2,7 +2,7 @@
  * rayrs_lab.h -- PRIVATE scheduling knobs of librayrs_hip.so, for tests/ and scripts/ubench/ only.
  *
  * Not part of the boundary a rayrs-lib maintainer binds (include/rayrs_hip.h): nothing here has a
- * reference counterpart, none of it changes what is computed, and any of it may go away.  The public
+ * reference counterpart, none of it changes a frame, and any of it may go away.  The public
  * header keeps the two settings a caller may legitimately choose (rayrs_tuning: pool size, route).
  * 0 = the built-in default everywhere.
  */

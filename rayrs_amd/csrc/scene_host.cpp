@@ -337,7 +337,7 @@ void front_largest(WalkTree& f) {
     f.root_ref = (REF_INTERIOR << 30) | new_of[f.root_ref & 0x3fffffffu];
 }
 
-// ------------------------------------------------------------ the walk tree
+// ------------------------------------------------------------ the walk trees
 //
 // What decides the reference's answer is, per primitive, ONE box: a primitive is reached by
 // BvhTree::intersect (bvh.rs:391-415) iff every box on its root path passes the slab test,
@@ -347,13 +347,16 @@ void front_largest(WalkTree& f) {
 // implies passing all the others.  The closest hit is then the smallest accepted t, the
 // first primitive in depth-first order on exact ties (bvh.rs:62), whatever order the
 // primitives are visited in.  So the kernels need not walk the reference's topology: they
-// walk a tree built here for traversal speed whose leaf slots are the reference's *groups*
-// (the 1..4 leaves that share a parent Node, contiguous in depth-first order) behind their
-// exact gating boxes, and whose interior boxes are unions of those, i.e. supersets -- a ray
+// walk trees built here for traversal speed.  The GATE tree's leaf slots are the reference's
+// *groups* (the 1..4 leaves that share a parent Node, contiguous in depth-first order) behind
+// their exact gating boxes, and its interior boxes are unions of those, i.e. supersets -- a ray
 // that misses a superset misses every gating box inside it, so skipping the subtree skips
-// nothing the reference reaches.  On the benchmark scenes this removes the chain of sixteen
-// levels down which the reference carries the 50 x 50 floor (every query used to read all
-// eight folded records of it) and halves the records a query visits.
+// nothing the reference reaches: this tree reaches exactly what the reference reaches
+// (rayrs_render_params.exact_traversal, and the local-pool route's gates).  On the benchmark
+// scenes it removes the chain of sixteen levels down which the reference carries the 50 x 50
+// floor (every query used to read all eight folded records of it) and halves the records a
+// query visits.  The DEFAULT tree's leaf slots are single primitives behind boxes of their own
+// inside the gating box (tight_box below): a subset of what the reference reaches.
 
 struct WalkGroup {
     double box[6];
