@@ -234,7 +234,10 @@ typedef struct {
      * 1: the walk over the reference's leaf groups behind their exact gating boxes (rayrs_scene_export_gate_tree)
      *   with nothing culled: the reference's visit set by construction, bit-identical closest hits for every ray.
      *   Measured cost on the 1.3 M-triangle headline frame: profiles/r04_exact_traversal.txt.
-     * The local-pool route always takes the gate tree and never culls. */
+     * The local-pool route always takes the gate tree and never culls.  And the library sets 1 by itself for a frame
+     * whose camera stands farther from the scene's bounding box than 8 times that box's diagonal: the leaf boxes' bet
+     * was measured to hold for rays from nearby (bounce rays always are) and to fail for in-plane rays from thousands of
+     * scene sizes away, so it is not made from there (rayrs_render_stats.exact_walk reports the walk a frame took). */
     uint32_t exact_traversal;
 } rayrs_render_params;
 
@@ -271,7 +274,9 @@ typedef struct {
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
     uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
-    uint32_t pad;
+    uint32_t exact_walk;    /* 1 = this frame's queries made neither of the default walk's bets: exact_traversal was set, the
+                               camera stands farther than 8 scene diagonals from the scene (the library then takes the exact
+                               walk by itself, see rayrs_render_params.exact_traversal), or the local-pool route rendered it */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:

@@ -70,7 +70,7 @@ class RenderStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
-                ("local_pool", C.c_uint32), ("pad", C.c_uint32)]
+                ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

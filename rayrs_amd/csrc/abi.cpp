@@ -558,7 +558,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
-    RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, pad);
+    RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, exact_walk);
     RAYRS_STRUCT(rayrs_tuning, 2);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
 #undef RAYRS_STRUCT
@@ -600,6 +600,26 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.t1 = s->flat.t1;
     sc.exact = exact ? 1u : 0u;
     return sc;
+}
+
+// The default walk's leaf boxes are a bet on the reference's arithmetic that was measured to hold for rays from within
+// ten scene sizes of the scene and to fail, a few times in 10^4, for rays aimed along a primitive's plane from thousands
+// of scene sizes away (include/rayrs_hip.h exact_traversal; profiles/r04_tight_leaves.txt).  Bounce rays start on the
+// scene's surfaces; only a camera can stand that far out.  So the bet is only made where it was measured: a frame whose
+// camera is farther from the root Node's box than RAYRS_EXACT_CAMERA_DISTANCE times that box's diagonal takes the exact
+// walk without being asked (rayrs_render_stats.exact_walk says which walk a frame took).
+constexpr double RAYRS_EXACT_CAMERA_DISTANCE = 8.0;
+static bool camera_is_far(const rayrs_scene* s, const rayrs_camera* c) {
+    const double* b = s->flat.root_box;
+    double d2 = 0.0, e2 = 0.0;
+    for (int a = 0; a < 3; a++) {
+        const double lo = b[2 * a], hi = b[2 * a + 1], o = c->origin[a];
+        const double out = o < lo ? lo - o : (o > hi ? o - hi : 0.0);
+        d2 += out * out;
+        e2 += (hi - lo) * (hi - lo);
+    }
+    // (a box or an origin that is not a number compares false: the default walk, as for any other frame)
+    return d2 > RAYRS_EXACT_CAMERA_DISTANCE * RAYRS_EXACT_CAMERA_DISTANCE * e2;
 }
 
 static CameraDev make_camera_dev(const rayrs_camera* c) {
@@ -689,7 +709,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.partial = scene->d_partial;
     rp.partial_item0 = 0;
 
-    const SceneDev sc = make_scene_dev(scene, params->exact_traversal != 0u);
+    const bool exact = params->exact_traversal != 0u || camera_is_far(scene, camera);
+    scene->last_exact = exact;
+    const SceneDev sc = make_scene_dev(scene, exact);
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
@@ -716,7 +738,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->trav[(params->exact_traversal || lab.gate_tree) ? 1 : 0].blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[(exact || lab.gate_tree) ? 1 : 0].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;
@@ -947,6 +969,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->kernel_ms = t;
         stats->hit_ms = h, stats->miss_ms = m;
         stats->local_pool = scene->last_local ? 1u : 0u;
+        stats->exact_walk = (scene->last_exact || scene->last_local) ? 1u : 0u;
         stats->kernel_launches = (uint64_t)scene->rounds;
     }
     return RAYRS_OK;

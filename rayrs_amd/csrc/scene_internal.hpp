@@ -64,6 +64,7 @@ struct rayrs_scene {
     // Scenes whose walk tree is at most one record are rendered by local_pool.hip: every path resident in LDS.
     bool local_ok = false;
     bool last_local = false;          // the render in flight took that route
+    bool last_exact = false;          // ... with the exact walk (asked for, or a far camera: abi.cpp camera_is_far)
     rayrs::LocalScene local = {};
     int local_blocks_per_cu = 1;      // local-pool kernel, from the occupancy query with the scene's LDS size
     double* d_local_light = nullptr;  // 4 doubles per resident path

@@ -5,15 +5,17 @@ on the product's own trees (host-only scene, device = -1), walked by the oracle 
             construction -- REQUIRED to match on every ray of every family;
   default   the tree of single primitives behind their widened boxes, slots entered beyond closest_t * (1 + 2^-10)
             culled: two bets on the reference's arithmetic (include/rayrs_hip.h exact_traversal).  REQUIRED to match on
-            the general family and on grazing rays 1e-7 rad and more off the plane from origins within 10 scene
-            sizes; counted and reported elsewhere;
+            the general family and on grazing rays 1e-7 rad and more off the plane from origins within 8 root-box
+            diagonals of the scene -- beyond that a frame's camera gets the exact walk without asking (abi.cpp
+            camera_is_far), and bounce rays start on the scene; counted and reported elsewhere;
   leaves    the default tree with no culling: which of the default's mismatches are the leaf boxes' alone.
 The geometry is where Moeller-Trumbore is least accurate: sliver triangles, nearly coplanar tessellated sheets whose
 group boxes are almost flat (hits sit on box faces), scene scales 1e-3 .. 1e3, origins up to 1e6 scene sizes away, and
 two families of directions:
   general   elevations 1e-7 .. 1 rad over the sheet's mean plane, axis-aligned directions (0 * inf in the slab test)
   grazing   IN the plane of a chosen triangle plus 1e-13 .. 1e-3 of its normal, aimed at a point inside it
-            (near: the origin within 10 scene sizes -- where a camera stands and every bounce ray starts; far: beyond)
+            (near: the origin within 8 root-box diagonals of the root box -- where the product makes its bets; far: beyond,
+            where the product takes the exact walk)
 Culling loses a hit when a primitive's computed t lies more than the margin in front of a box around it (the error of
 t grows like eps * distance / triangle size / angle: at 1e-9 rad and 5000 triangle sizes it reaches 2^-10).  A leaf box
 loses one when the reference's own test accepts a hit on a primitive the ray passes beside by more than 1/64 of its
@@ -105,16 +107,23 @@ def rays_for(rng, verts, scale, n):
     return o, d
 
 
-NEAR = 10.0  # scene sizes
+NEAR = 8.0  # abi.cpp RAYRS_EXACT_CAMERA_DISTANCE: diagonals of the root box between it and the origin
 
 
-def families(seed, verts, idx, scale, per_scene):
+def is_near(o, root_box):
+    """abi.cpp camera_is_far, negated: the origins from which a frame's camera gets the default walk."""
+    b = np.asarray(root_box, dtype=np.float64)
+    lo, hi = b[0::2], b[1::2]
+    out = np.maximum(np.maximum(lo - o, o - hi), 0.0)
+    return (out * out).sum(axis=1) <= NEAR * NEAR * ((hi - lo) ** 2).sum()
+
+
+def families(seed, verts, idx, scale, per_scene, root_box):
     """[(family name, origins, directions)] for one scene."""
     rr = np.random.default_rng(seed * 7919 + 1)
     og, dg = rays_for(rr, verts, scale, per_scene // 2)
     oz, dz, eps = grazing_rays(rr, verts, idx, scale, per_scene - per_scene // 2)
-    centre = 0.5 * (verts.min(axis=0).astype(np.float64) + verts.max(axis=0).astype(np.float64))
-    near = np.linalg.norm(oz - centre, axis=1) <= NEAR * 2.0 * scale  # (a sheet spans 2 * scale)
+    near = is_near(oz, root_box)
     out = [("general", og, dg)]
     for name, sel in (("grazing >= 1e-7", eps >= 1e-7), ("grazing 1e-9..1e-7", (eps < 1e-7) & (eps >= 1e-9)), ("grazing < 1e-9", eps < 1e-9)):
         out.append((name + " near", oz[sel & near], dz[sel & near]))
@@ -140,7 +149,7 @@ def main():
         prod = rayrs_amd.Scene(objs, tmin, tmax, heur, hdri, device=-1)
         osc = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod)
         osg = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod, gate=True)
-        for name, o, d in families(seed, verts, idx, scale, per_scene):
+        for name, o, d in families(seed, verts, idx, scale, per_scene, prod.info()["root_box"]):
             f = fam.setdefault(name, dict(rays=0, hits=0, default=0, leaves=0, exact=0, worst=-1.0, in_front=0, beyond=0))
             ta, oa = osc.intersect_batch(o, d, tmin, tmax, traversal=0)
             tb, ob = osc.intersect_batch(o, d, tmin, tmax, traversal=2)

@@ -258,6 +258,47 @@ def test_exact_traversal_renders_the_same_frame_with_more_visits():
         assert sb[k] == wst[k], k
 
 
+def test_a_camera_far_from_the_scene_gets_the_exact_walk_without_asking():
+    """The leaf boxes' bet fails, a few times in 10^4, for rays aimed along a triangle's plane from thousands of scene
+    sizes away (profiles/r04_tight_leaves.txt) and was never seen to fail from nearby.  Bounce rays start on the scene;
+    only a camera can stand far out -- and a frame whose camera is more than 8 root-box diagonals from the root box takes
+    the exact walk by itself (abi.cpp camera_is_far).  rayrs_render_stats.exact_walk reports the walk; the far frame's
+    counters are the oracle's for the gate tree with nothing culled."""
+    mesh = lambda: scenes.mesh_scene(3)
+    scene, cam, osc, ocam = both(mesh, 64, 48, 4)
+    box = np.array(scene.info()["root_box"])
+    diag = float(np.linalg.norm(box[1::2] - box[0::2]))
+    _, st = rayrs_amd.render(scene, cam, 4, out_f64=True)
+    assert st["exact_walk"] == 0 and st["local_pool"] == 0           # the reference's own camera: the default walk
+    _, st = rayrs_amd.render(scene, cam, 4, out_f64=True, exact_traversal=True)
+    assert st["exact_walk"] == 1
+    # the same mesh through a long lens from 12 diagonals above the floor's corner
+    far_o = (box[1] + 12.0 * diag * 0.6, 12.0 * diag * 0.8, 0.3)
+    far = (far_o, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.45, 64 / 254.0, 48 / 254.0, 100)
+    near_o = tuple(0.5 * c for c in far_o)                             # 6 diagonals: still the default walk
+    near = (near_o, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.9, 64 / 254.0, 48 / 254.0, 100)
+    for cam_args, want in ((far, 1), (near, 0)):
+        cam = rayrs_amd.Camera(*cam_args)
+        ocam = _oracle.OracleCamera(*cam_args)
+        img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True)
+        ref, ost = osc.render(ocam, 6, traversal=0)
+        assert st["exact_walk"] == want
+        assert_same_frame(img, ref)
+        assert st["rays"] == ost["rays"] and st["tri_tests"] > 0      # the lens does see the mesh
+        try:
+            if want:
+                _oracle.set_cull_margin(float("inf"))
+            _, wst = osc.use_walk_tree(scene, gate=bool(want)).render(ocam, 6, traversal=2)
+        finally:
+            _oracle.set_cull_margin(2.0 ** -10)
+        for k in ("interior_visits", "tri_tests", "plane_tests"):
+            assert st[k] == wst[k], (want, k)
+    # the local-pool route makes neither bet whatever the camera
+    scene, cam, osc, ocam = both(scenes.cook_torrance_spheres_metallic, 48, 32, 2)
+    _, st = rayrs_amd.render(scene, cam, 2)
+    assert st["local_pool"] == 1 and st["exact_walk"] == 1
+
+
 def test_the_culling_walk_on_the_gate_tree_is_still_there_for_comparisons():
     """rayrs_lab.h gate_tree: rounds 2 and 3 walked the reference's groups behind their gating boxes with closest-hit
     culling; scripts/ubench/exact_cost.py prices the default tree against it.  Same frame, the oracle's counters."""

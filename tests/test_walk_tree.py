@@ -161,7 +161,8 @@ def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
     Moeller-Trumbore is least accurate: sliver triangles, nearly flat sheets, origins up to 1e6 scene sizes away,
     general directions down to 1e-7 rad over the sheet and rays aimed along a triangle's own plane.
     The default walk must match on the general family and on grazing rays 1e-7 rad and more off the plane from
-    within 10 scene sizes; the exact walk (gate tree, nothing culled) on every ray of every family, by construction.
+    within 8 root-box diagonals of the scene (from farther out a frame takes the exact walk by itself: abi.cpp
+    camera_is_far); the exact walk (gate tree, nothing culled) on every ray of every family, by construction.
     scripts/fuzz_traversal.py is the same over 1e8 rays; this is 1.6 M.  The probe measures the cull margin itself:
     how far in front of a box around it a hit's t can lie."""
     import sys, os
@@ -175,7 +176,7 @@ def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
         prod = rayrs_amd.Scene(objs, t0, t1, heur, hdri, device=-1)
         osc = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(prod)
         osg = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(prod, gate=True)
-        for name, o, d in F.families(seed, verts, idx, scale, 200_000):
+        for name, o, d in F.families(seed, verts, idx, scale, 200_000, prod.info()["root_box"]):
             rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)
             wt, wobj = osc.intersect_batch(o, d, t0, t1, traversal=2)
             same = (wobj == robj) & (wt.view(np.uint64) == rt.view(np.uint64))
