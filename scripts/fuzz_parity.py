@@ -18,6 +18,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 HDRI = procedural.make_hdri(256, 128)
 bad = 0
 n_both = 0
+n_far = 0
 t0 = time.time()
 for seed in range(first, first + count):
     r = np.random.default_rng(seed ^ 0xABCDEF)
@@ -32,8 +33,17 @@ for seed in range(first, first + count):
         from rayrs_amd.api import Emission, Object
         for o in objs:
             o.emission = Emission.Dark()
-    cam_args = scenes.camera_for_resolution(cam_args, w, h)
     scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    if seed % 7 == 3:  # the same view through a long lens from 9 .. 40 scene diagonals away: such a frame takes the exact walk
+        box = np.array(scene.info()["root_box"])
+        diag = float(np.linalg.norm(box[1::2] - box[0::2]))
+        o, up, look, fov = np.array(cam_args[0], dtype=float), cam_args[1], np.array(cam_args[2], dtype=float), cam_args[3]
+        back = o - look
+        dist = float(np.linalg.norm(back))
+        if np.isfinite(diag) and diag > 0 and dist > 0:
+            new = float(r.uniform(9.0, 40.0)) * diag + dist
+            cam_args = (tuple(look + back / dist * new), up, tuple(look), fov * dist / new) + tuple(cam_args[4:])
+    cam_args = scenes.camera_for_resolution(cam_args, w, h)
     cam = rayrs_amd.Camera(*cam_args)
     osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
     ocam = _oracle.OracleCamera(*cam_args)
@@ -49,8 +59,16 @@ for seed in range(first, first + count):
     ok = np.array_equal(img.view(np.uint64), ref0.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths"):
         ok = ok and st[k] == ost0[k]
-    # (the local-pool route walks the gate tree: the groups behind their gating boxes)
-    ref, ost = osc.use_walk_tree(scene, gate=bool(scene.info()["local_pool"])).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+    # the oracle's walk on the records the frame's queries walked: the local-pool route and a frame that took the exact
+    # walk (a camera far from the scene: abi.cpp camera_is_far) the gate tree -- the latter with nothing culled
+    far = bool(st["exact_walk"]) and not st["local_pool"]
+    n_far += far
+    try:
+        if far:
+            _oracle.set_cull_margin(float("inf"))
+        ref, ost = osc.use_walk_tree(scene, gate=bool(st["exact_walk"])).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+    finally:
+        _oracle.set_cull_margin(2.0 ** -10)
     ok = ok and np.array_equal(img.view(np.uint64), ref.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
         ok = ok and st[k] == ost[k]
@@ -64,5 +82,5 @@ for seed in range(first, first + count):
         print("MISMATCH seed", seed, w, h, spp, chunk, mb, {k: (st[k], ost[k]) for k in ("rays", "interior_visits")}, flush=True)
     if (seed - first) % 20 == 19:
         print(f"{seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print("done:", count, "scenes,", bad, "mismatches;", n_both, "scenes rendered on both routes")
+print("done:", count, "scenes,", bad, "mismatches;", n_both, "scenes rendered on both routes;", n_far, "frames took the exact walk for their camera's distance")
 sys.exit(1 if bad else 0)
