@@ -452,14 +452,21 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         return;
     }
     // rank of a hit slot = number of hit slots visited before it (nearer entry, then lower slot);
-    // for a < b, slot a goes first unless e_b < e_a
-    const unsigned long long c01 = __builtin_amdgcn_ballot_w64(e1 < e0), c02 = __builtin_amdgcn_ballot_w64(e2 < e0);
-    const unsigned long long c03 = __builtin_amdgcn_ballot_w64(e3 < e0), c12 = __builtin_amdgcn_ballot_w64(e2 < e1);
-    const unsigned long long c13 = __builtin_amdgcn_ballot_w64(e3 < e1), c23 = __builtin_amdgcn_ballot_w64(e3 < e2);
-    const int k_0 = (int)RR_LANE_BIT(m1 & c01) + (int)RR_LANE_BIT(m2 & c02) + (int)RR_LANE_BIT(m3 & c03);
-    const int k_1 = (int)RR_LANE_BIT(m0 & ~c01) + (int)RR_LANE_BIT(m2 & c12) + (int)RR_LANE_BIT(m3 & c13);
-    const int k_2 = (int)RR_LANE_BIT(m0 & ~c02) + (int)RR_LANE_BIT(m1 & ~c12) + (int)RR_LANE_BIT(m3 & c23);
-    const int k_3 = (int)RR_LANE_BIT(m0 & ~c03) + (int)RR_LANE_BIT(m1 & ~c13) + (int)RR_LANE_BIT(m2 & ~c23);
+    // for a < b, slot a goes first unless e_b < e_a.  (EXACT: every slot the ray enters is visited whatever the
+    // closest hit, so the order buys nothing -- the closest hit is the smallest accepted t, ties by primitive
+    // index, in any order: slot order, and the six comparisons are not made.)
+    int k_0, k_1, k_2, k_3;
+    if (EXACT) {
+        k_0 = 0, k_1 = (int)h0, k_2 = (int)h0 + (int)h1, k_3 = (int)h0 + (int)h1 + (int)h2;
+    } else {
+        const unsigned long long c01 = __builtin_amdgcn_ballot_w64(e1 < e0), c02 = __builtin_amdgcn_ballot_w64(e2 < e0);
+        const unsigned long long c03 = __builtin_amdgcn_ballot_w64(e3 < e0), c12 = __builtin_amdgcn_ballot_w64(e2 < e1);
+        const unsigned long long c13 = __builtin_amdgcn_ballot_w64(e3 < e1), c23 = __builtin_amdgcn_ballot_w64(e3 < e2);
+        k_0 = (int)RR_LANE_BIT(m1 & c01) + (int)RR_LANE_BIT(m2 & c02) + (int)RR_LANE_BIT(m3 & c03);
+        k_1 = (int)RR_LANE_BIT(m0 & ~c01) + (int)RR_LANE_BIT(m2 & c12) + (int)RR_LANE_BIT(m3 & c13);
+        k_2 = (int)RR_LANE_BIT(m0 & ~c02) + (int)RR_LANE_BIT(m1 & ~c12) + (int)RR_LANE_BIT(m3 & c23);
+        k_3 = (int)RR_LANE_BIT(m0 & ~c03) + (int)RR_LANE_BIT(m1 & ~c13) + (int)RR_LANE_BIT(m2 & ~c23);
+    }
 #undef RR_LANE_BIT
     tv.cur = (h0 && k_0 == 0) ? r0 : (h1 && k_1 == 0) ? r1 : (h2 && k_2 == 0) ? r2 : r3;
     // rank k >= 1 goes to stack entry top - k; everything else to the lane's spare entry
