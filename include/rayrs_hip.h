@@ -227,10 +227,11 @@ typedef struct {
      *     box widened by 1/64 of its size (inside the reference's gating box, so nothing extra is ever tested) --
      *     the reference's answer unless its own test accepts a hit on a primitive the ray passes beside by more
      *     than that.
-     *   Both fail only for rays within about 1e-7 rad of a primitive's plane seen from many thousand primitive sizes
-     *   away, where Moeller-Trumbore's own result is rounding noise (scripts/fuzz_traversal.py counts them:
-     *   profiles/r04_tight_leaves.txt; tests/test_walk_tree.py pins one failing ray of each kind); no rendered
-     *   frame, of any size, has differed in a bit.
+     *   Both fail only for rays aimed nearly IN a primitive's plane, where Moeller-Trumbore's own result is rounding
+     *   noise: culling within about 1e-7 rad of it (one such ray in 10^6 from nearby), the leaf boxes only from
+     *   thousands of scene sizes away (a few in 10^4 of such rays, up to 1e-5 rad off the plane; none from within 8
+     *   scene diagonals at 1e-7 rad and more) -- scripts/fuzz_traversal.py counts them, profiles/r04_tight_leaves.txt;
+     *   tests/test_walk_tree.py pins one failing ray of each kind; no rendered frame, of any size, has differed in a bit.
      * 1: the walk over the reference's leaf groups behind their exact gating boxes (rayrs_scene_export_gate_tree)
      *   with nothing culled: the reference's visit set by construction, bit-identical closest hits for every ray.
      *   Measured cost on the 1.3 M-triangle headline frame: profiles/r04_exact_traversal.txt.
@@ -318,12 +319,13 @@ int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camer
                        const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats);
 
 /* ---- tuning: the two scheduling choices a caller may legitimately make.  0 = the built-in default.  Neither changes
- * what is computed.  (Round 1 read such settings from RAYRS_* environment variables; a library must not.  The kernels'
+ * the arithmetic (the streaming route's default walk makes the two bets described at rayrs_render_params.exact_traversal,
+ * the local-pool route makes neither; no frame has differed between them).  (Round 1 read such settings from RAYRS_* environment variables; a library must not.  The kernels'
  * development knobs -- thresholds, LDS budgets, test switches -- are not part of this boundary: rayrs_amd/csrc/rayrs_lab.h.) */
 typedef struct {
     uint32_t pool_slots;    /* streaming route: paths in flight = slots of the pool in HBM, 128 + 33 bytes each
                                (default: min(items, 112 Mi, samples / 12)); ignored on the local-pool route */
-    uint32_t local_pool;    /* a scene whose walk tree is at most one record (n_wide <= 1: the reference's sphere
+    uint32_t local_pool;    /* a scene whose gate tree is at most one record (gate_n_wide <= 1: the reference's sphere
                                scenes) is rendered by ONE launch that keeps every path in LDS from its first ray
                                to its last (local_pool.hip) instead of three launches per bounce over a pool in
                                HBM; same arithmetic, same bits.  0 = do so, 1 = never (the streaming kernels) */

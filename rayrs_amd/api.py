@@ -305,7 +305,7 @@ class Scene:
 
     def set_tuning(self, **kw):
         """The two scheduling choices of include/rayrs_hip.h rayrs_tuning (pool_slots, local_pool); 0 = default.
-        They never change what is computed."""
+        They do not change the arithmetic (the routes differ in which primitives a query tests: include/rayrs_hip.h)."""
         t = _ffi.Tuning()
         for k, v in kw.items():
             if k not in dict(_ffi.Tuning._fields_):

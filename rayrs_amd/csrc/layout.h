@@ -6,9 +6,10 @@
 //   wide record      four boxes + four references              128 B (compact) / 256 B (full)
 //   primitive record triangle | sphere | plane + tag, DFS order  48 B (compact) /  80 B (full)
 //
-// The wide records are the product's own tree over the reference's leaf groups
-// (scene_host.cpp build_walk_trees); the two-child records of the reference's tree
-// exist on the host only (rayrs_scene_export_bvh).
+// The wide records are the product's own trees (scene_host.cpp build_walk_trees): the default
+// tree over the reference's primitives, each behind a box of its own inside its gating box, and
+// the gate tree over the reference's leaf groups behind exactly their gating boxes; the two-child
+// records of the reference's tree exist on the host only (rayrs_scene_export_bvh).
 //
 // "compact" = every box bound and every triangle vertex is exactly
 // representable in f32 (true for PLY meshes, whose vertices are f32), so the
@@ -21,9 +22,9 @@ namespace rayrs {
 
 // child reference: kind << 30 | payload
 constexpr uint32_t REF_INTERIOR = 0u;  // payload = interior record index
-constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1): 1..4 primitives behind their gating box
+constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1): 1..4 primitives behind the slot's box
 constexpr uint32_t REF_SINGLE = 2u;    // two-child export only: payload = prim << 2, a direct leaf (no box of its own,
-                                       // bvh.rs:297, :302); the walk tree holds it as a one-primitive REF_RANGE behind
+                                       // bvh.rs:297, :302); the gate tree holds it as a one-primitive REF_RANGE behind
                                        // the box of the Node it hangs under
 constexpr uint32_t REF_NONE = 3u;
 
