@@ -272,3 +272,45 @@ def test_largest_boxes_lead_the_wide_records():
     owner = np.repeat(np.arange(256, len(ref)), 4).reshape(-1, 4)[(ref[256:] >> 30) == 0]
     later = kids >= 256
     assert np.all(kids[later] > owner[later])
+
+
+def degenerate_objects():
+    """Primitives whose own boxes are points, flat, huge or beyond f32, beside a floor and forty slivers."""
+    r = np.random.default_rng(12)
+    objs = [Object.plane(Axis.Y, -25.0, 25.0, -25.0, 25.0, 0.0, NR, DARK)]
+    p = np.array([0.5, 1.0, -0.25])
+    objs.append(Object.triangle(p, p, p, NR, DARK))                                  # a point
+    objs.append(Object.triangle(p, p + (1.0, 0.0, 0.0), p + (2.0, 0.0, 0.0), NR, DARK))  # a segment
+    objs.append(Object.triangle((0.0, 2.0, 0.0), (1.0, 2.0, 0.0), (0.0, 2.0, 1.0), NR, DARK))  # flat in y
+    objs.append(Object.sphere(1e-300, (-1.0, 1.0, 1.0), NR, DARK))
+    objs.append(Object.sphere(1e30, (0.0, 2e30, 0.0), NR, DARK))                     # far beyond everything else
+    objs.append(Object.triangle((1e39, 0.0, 0.0), (1e39, 1e39, 0.0), (1e39, 0.0, 1e39), NR, DARK))  # beyond f32's range
+    for i in range(40):
+        c = r.uniform(-3, 3, 3)
+        objs.append(Object.triangle(c, c + r.uniform(-1, 1, 3) * 1e-9, c + r.uniform(-1, 1, 3), NR, DARK))  # slivers
+    return objs
+
+
+def test_leaf_boxes_of_degenerate_and_extreme_primitives():
+    """The default tree's leaf boxes (scene_host.cpp tight_box) for primitives whose own boxes are points, flat, huge or
+    beyond f32: every one must still lie inside its gating box and around the primitive's box, bit for bit as restated
+    here -- and the oracle's walk over both trees must return the recursion's hits."""
+    r = np.random.default_rng(13)
+    objs = degenerate_objects()
+    for heur in (BvhHeuristic.Sah(1000), BvhHeuristic.Midpoint):
+        prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+        orc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+        check_walk_trees(prod, orc, prod.info()["n_prims"])
+        o = r.uniform(-4, 4, (4000, 3))
+        d = r.normal(size=(4000, 3))
+        d[:500] = (0.5, 1.0, -0.25) - o[:500]   # at the point and the segment
+        rt, robj = orc.intersect_many(o, d, 1e-6, 1e6, traversal=0)
+        wt, wobj = orc.use_walk_tree(prod).intersect_many(o, d, 1e-6, 1e6, traversal=2)
+        assert np.array_equal(wobj, robj) and np.array_equal(wt.view(np.uint64), rt.view(np.uint64))
+        try:
+            _oracle.set_cull_margin(float("inf"))
+            xt, xobj = orc.use_walk_tree(prod, gate=True).intersect_many(o, d, 1e-6, 1e6, traversal=2)
+        finally:
+            _oracle.set_cull_margin(2.0 ** -10)
+        assert np.array_equal(xobj, robj) and np.array_equal(xt.view(np.uint64), rt.view(np.uint64))
+        assert (robj >= 0).sum() > 1000

@@ -299,6 +299,36 @@ def test_a_camera_far_from_the_scene_gets_the_exact_walk_without_asking():
     assert st["local_pool"] == 1 and st["exact_walk"] == 1
 
 
+def test_degenerate_and_extreme_primitives_render_the_oracles_frame():
+    """Points, segments, flat and sliver triangles, a sphere of radius 1e-300, one of 1e30 and a triangle beyond f32's range
+    (tests/test_bvh_builder.py degenerate_objects; f64 records): the default walk, the exact walk and the oracle's recursion
+    render the same frame, with the oracle's counters for the tree each walks."""
+    from test_bvh_builder import degenerate_objects
+    from rayrs_amd.api import BvhHeuristic, Material, Emission
+    objs = degenerate_objects()
+    for o in objs[::3]:
+        o.mat = Material.LambertianDiffuse((0.7, 0.6, 0.5))
+    cam_args = ((3.0, 2.5, 5.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 55.0, 56 / 254.0, 40 / 254.0, 100)
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, BvhHeuristic.Sah(1000), HDRI, device=0)
+    assert not scene.info()["compact"]
+    cam = rayrs_amd.Camera(*cam_args)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, BvhHeuristic.Sah(1000), HDRI)
+    ocam = _oracle.OracleCamera(*cam_args)
+    ref, ost = osc.render(ocam, 6, traversal=0)
+    for exact in (False, True):
+        img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True, exact_traversal=exact)
+        assert st["exact_walk"] == int(exact) and st["rays"] == ost["rays"]
+        assert_same_frame(img, ref)
+        try:
+            if exact:
+                _oracle.set_cull_margin(float("inf"))
+            _, wst = osc.use_walk_tree(scene, gate=exact).render(ocam, 6, traversal=2)
+        finally:
+            _oracle.set_cull_margin(2.0 ** -10)
+        for k in ("interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
+            assert st[k] == wst[k], (exact, k)
+
+
 def test_the_culling_walk_on_the_gate_tree_is_still_there_for_comparisons():
     """rayrs_lab.h gate_tree: rounds 2 and 3 walked the reference's groups behind their gating boxes with closest-hit
     culling; scripts/ubench/exact_cost.py prices the default tree against it.  Same frame, the oracle's counters."""
