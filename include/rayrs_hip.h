@@ -123,7 +123,7 @@ typedef struct rayrs_scene rayrs_scene;
  * Consumes nothing: `objs` stays owned by the caller and may be destroyed
  * right after.  Builds the BVH exactly as Bvh::build does (bvh.rs:199-389,
  * same splits, same child order), derives the tree the kernels walk from it
- * (rayrs_scene_export_wide) and uploads that to HIP device `device`.  device = -1 builds a host-only scene (no GPU needed) that can
+ * (rayrs_scene_export_cert_tree; also rayrs_scene_export_gate_tree, rayrs_scene_export_wide) and uploads them to HIP device `device`.  device = -1 builds a host-only scene (no GPU needed) that can
  * be inspected with rayrs_scene_info / rayrs_scene_export_bvh but not
  * rendered.  hdri_rgb: hdri_w*hdri_h RGB f32 texels, row-major, image origin
  * upper left; values are clipped to [0, 3] as main.rs:43 does. */
@@ -150,8 +150,14 @@ typedef struct {
     uint32_t local_pool;    /* 1 = the gate tree is at most one record: renders keep every path in LDS
                                (rayrs_tuning.local_pool, local_pool.hip) */
     uint32_t gate_n_wide;   /* the same three for the gate tree (rayrs_scene_export_gate_tree), which */
-    uint32_t gate_root_ref; /* rayrs_render_params.exact_traversal walks */
+    uint32_t gate_root_ref; /* RAYRS_WALK_REFERENCE walks */
     uint32_t gate_depth;
+    uint32_t cert_n_wide;   /* the same three for the certified tree (rayrs_scene_export_cert_tree), which */
+    uint32_t cert_root_ref; /* RAYRS_WALK_CERTIFIED, the default, walks */
+    uint32_t cert_depth;
+    uint32_t pad0;
+    double cert_center[3];  /* rays whose origin lies within cert_radius (max norm) of cert_center are inside the */
+    double cert_radius;     /* certified walk's theorem; for the others every certificate reads "in doubt" */
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -174,14 +180,23 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
  * 1..4 leaves that share a parent Node, contiguous in depth-first order -- behind exactly its gating box; an
  * interior slot (kind 0) carries the union of the boxes below it, so a ray that misses it misses every gating box
  * inside.  Every group appears exactly once: the primitives this tree reaches are the primitives the reference
- * reaches.  Walked by rayrs_render_params.exact_traversal and the source of the local-pool route's gates.
+ * reaches.  Walked by RAYRS_WALK_REFERENCE and the source of the local-pool route's gates.
  *   rayrs_scene_export_wide (n = n_wide), the default: a leaf slot is ONE primitive behind its own bounding box
  * (Bvh::build's, geometry.rs bbox) widened on every side by 1/64 of its largest extent, rounded outwards to f32 and
- * clipped to its gating box.  It reaches a subset of what the reference reaches (see exact_traversal for what the
- * subset leaves out and why that is the reference's answer all the same).
+ * clipped to its gating box.  It reaches a subset of what the reference reaches (RAYRS_WALK_FAST: what the subset
+ * leaves out is a bet).
  * tests/test_bvh_builder.py checks all of this from the exports alone. */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
+/*   rayrs_scene_export_cert_tree (n = cert_n_wide), what the default walk reads: the gate tree's records, in which
+ * every group of three or four primitives is opened into a record of its own (the group's slot keeps its exact
+ * gating box and becomes kind 0): its slots are the group's primitives one by one (kind 1, count 1), each behind
+ * its own bounding box widened by 1/64 of its largest extent and rounded outwards to f32 (not clipped), with one
+ * certificate word per slot in wide_cert (n*4 u32; four signed bytes nx, ny, nz, bias): a triangle's normal
+ * scaled to largest component +-127, or (0,0,0,127) "the box test decides" for every other kind of slot, or 0
+ * "always test" for a primitive nothing is proved about.  rayrs_amd/csrc/scene_host.cpp build_cert_tree states
+ * the theorem; tests/test_bvh_builder.py re-derives every word and box from the objects. */
+int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* wide_cert);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -203,6 +218,7 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 /* ---- render: the block loop of rayrs/src/main.rs:57-101 ---- */
 
 enum { RAYRS_OUT_F32 = 0, RAYRS_OUT_F64 = 1 };
+enum { RAYRS_WALK_CERTIFIED = 0, RAYRS_WALK_REFERENCE = 1, RAYRS_WALK_FAST = 2 }; /* rayrs_render_params.walk */
 
 typedef struct {
     uint32_t spp;          /* main.rs:68 */
@@ -218,28 +234,32 @@ typedef struct {
     uint32_t tile_rank, tile_ranks;
     uint32_t out_format;   /* RAYRS_OUT_F32: f32x3 (image.rs:224-229), RAYRS_OUT_F64: f64x3 */
     uint32_t count_work;   /* 1 = also count traversal work (slower; for the roofline figure) */
-    /* BvhTree::intersect tests every primitive whose enclosing Node boxes the ray enters and never compares a box
-     * with the closest hit so far (bvh.rs:391-415).
-     * 0 (default): the walk makes two bets on the reference's arithmetic, each measured, neither a construction:
-     *   - closest-hit culling: a box entered beyond best_t * (1 + 2^-10) is skipped -- the reference's answer
-     *     unless a primitive's COMPUTED t lies more than that in front of a box around it;
-     *   - tight leaf boxes (rayrs_scene_export_wide): a primitive is tested only if the ray enters its own bounding
-     *     box widened by 1/64 of its size (inside the reference's gating box, so nothing extra is ever tested) --
-     *     the reference's answer unless its own test accepts a hit on a primitive the ray passes beside by more
-     *     than that.
-     *   Both fail only for rays aimed nearly IN a primitive's plane, where Moeller-Trumbore's own result is rounding
-     *   noise: culling within about 1e-7 rad of it (one such ray in 10^6 from nearby), the leaf boxes only from
-     *   thousands of scene sizes away (a few in 10^4 of such rays, up to 1e-5 rad off the plane; none from within 8
-     *   scene diagonals at 1e-7 rad and more) -- scripts/fuzz_traversal.py counts them, profiles/r04_tight_leaves.txt;
-     *   tests/test_walk_tree.py pins one failing ray of each kind; no rendered frame, of any size, has differed in a bit.
-     * 1: the walk over the reference's leaf groups behind their exact gating boxes (rayrs_scene_export_gate_tree)
-     *   with nothing culled: the reference's visit set by construction, bit-identical closest hits for every ray.
-     *   Measured cost on the 1.3 M-triangle headline frame: profiles/r04_exact_traversal.txt.
-     * The local-pool route always takes the gate tree and never culls.  And the library sets 1 by itself for a frame
-     * whose camera stands farther from the scene's bounding box than 8 times that box's diagonal: the leaf boxes' bet
-     * was measured to hold for rays from nearby (bounce rays always are) and to fail for in-plane rays from thousands of
-     * scene sizes away, so it is not made from there (rayrs_render_stats.exact_walk reports the walk a frame took). */
-    uint32_t exact_traversal;
+    /* Which walk answers the BVH queries (RAYRS_WALK_*).  BvhTree::intersect tests every primitive whose enclosing
+     * Node boxes the ray enters and never compares a box with the closest hit so far (bvh.rs:391-415); all three walks
+     * return its closest hit (smallest accepted t, first primitive in depth-first order on ties, bvh.rs:62), they
+     * differ in what that claim rests on:
+     * RAYRS_WALK_CERTIFIED (0, the default): the reference's leaf groups behind exactly their gating boxes, nothing
+     *   culled by the closest hit; inside an entered group of three or four, a primitive is tested iff the ray enters
+     *   its own bounding box widened by 1/64 of its size OR the ray lies within about 2 % (cosine) of the triangle's
+     *   plane.  For every other ray "the widened box is missed" implies "the reference's own Moeller-Trumbore rejects
+     *   it" by a forward error bound (rayrs_amd/csrc/scene_host.cpp build_cert_tree): the reference's answer for
+     *   EVERY ray, by theorem.  Rays from farther than 4 half extents of the scene's bounding box from its centre,
+     *   or with non-finite / extreme directions, are outside the theorem and test every primitive of an entered group.
+     * RAYRS_WALK_REFERENCE (1): the same groups and boxes, every primitive of an entered group tested: the
+     *   reference's visit set BY CONSTRUCTION, no theorem involved (rayrs_scene_export_gate_tree).  The local-pool
+     *   route always walks this way.  Cost on the headline frame: profiles/r05_walks.txt.
+     * RAYRS_WALK_FAST (2): two bets on the reference's arithmetic, each measured, neither proved (rounds 2-4's
+     *   default): closest-hit culling -- a box entered beyond best_t * (1 + 2^-10) is skipped -- and single
+     *   primitives behind their own widened boxes CLIPPED to the gating box in one tree of their own
+     *   (rayrs_scene_export_wide).  Both fail only for rays aimed nearly IN a primitive's plane, where
+     *   Moeller-Trumbore's result is rounding noise: culling within about 1e-7 rad of it (one such ray in 10^6), the
+     *   leaf boxes from thousands of scene sizes away (scripts/fuzz_traversal.py, profiles/r04_tight_leaves.txt;
+     *   tests/test_walk_tree.py pins one failing ray of each kind, on which the other two walks return the
+     *   reference's primitive); no rendered frame has differed in a bit.  For a camera farther from the scene's
+     *   bounding box than 8 of its diagonals the library walks RAYRS_WALK_REFERENCE instead.
+     * rayrs_render_stats.walk reports the walk a frame took.  (Until round 5 this field was `exact_traversal`, 0 =
+     * what is now RAYRS_WALK_FAST; 1 keeps its meaning.  Zero-initialise the struct: values above 2 are refused.) */
+    uint32_t walk;
 } rayrs_render_params;
 
 typedef struct {
@@ -275,9 +295,9 @@ typedef struct {
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
     uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
-    uint32_t exact_walk;    /* 1 = this frame's queries made neither of the default walk's bets: exact_traversal was set, the
-                               camera stands farther than 8 scene diagonals from the scene (the library then takes the exact
-                               walk by itself, see rayrs_render_params.exact_traversal), or the local-pool route rendered it */
+    uint32_t walk;          /* the RAYRS_WALK_* this frame's queries were answered by: the one asked for; RAYRS_WALK_REFERENCE
+                               when the local-pool route rendered the frame, or in place of RAYRS_WALK_FAST for a camera
+                               farther than 8 scene diagonals from the scene */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:
@@ -319,8 +339,7 @@ int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camer
                        const rayrs_render_params* params, void* out_host, rayrs_render_stats* stats);
 
 /* ---- tuning: the two scheduling choices a caller may legitimately make.  0 = the built-in default.  Neither changes
- * the arithmetic (the streaming route's default walk makes the two bets described at rayrs_render_params.exact_traversal,
- * the local-pool route makes neither; no frame has differed between them).  (Round 1 read such settings from RAYRS_* environment variables; a library must not.  The kernels'
+ * the arithmetic or the answer.  (Round 1 read such settings from RAYRS_* environment variables; a library must not.  The kernels'
  * development knobs -- thresholds, LDS budgets, test switches -- are not part of this boundary: rayrs_amd/csrc/rayrs_lab.h.) */
 typedef struct {
     uint32_t pool_slots;    /* streaming route: paths in flight = slots of the pool in HBM, 128 + 33 bytes each
@@ -349,8 +368,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);
 int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out);
 int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
                    uint64_t n, uint64_t* out_bits);
-/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  exact: rayrs_render_params.exact_traversal */
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
+/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  walk: RAYRS_WALK_* */
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int walk, double* t,
                          int64_t* object);
 /* Material::evaluate for n (normal, view, key) tuples with one material:
  * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */

@@ -863,6 +863,8 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
+    uint32_t* wide_cert; /* n_wide * 4 certificate words (orc_set_wide_cert), or NULL */
+    double cert_center[3], cert_radius;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -879,6 +881,7 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->prim_object);
     free(s->wide_box);
     free(s->wide_ref);
+    free(s->wide_cert);
     free(s);
 }
 
@@ -1311,6 +1314,22 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
+    free(s->wide_cert);
+    s->wide_cert = NULL;
+    return 0;
+}
+
+/* The product's certified tree (rayrs_scene_export_cert_tree) carries one certificate word per slot; handing
+ * them over after orc_set_wide makes traversal 2 the product's CERTIFIED walk (rayrs_amd/csrc/device_path.h
+ * trav_interior_step<..., WALK_CERT>, restated in isect_wide below): nothing culled, and a slot whose box
+ * the segment misses entered all the same when its certificate reads "in doubt" for the ray. */
+int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double center[3], double radius) {
+    if (!s || !s->have_wide || !cert) return -1;
+    free(s->wide_cert);
+    s->wide_cert = (uint32_t*)malloc(((size_t)s->finfo.n_wide * 4 + 1) * sizeof(uint32_t));
+    memcpy(s->wide_cert, cert, (size_t)s->finfo.n_wide * 4 * sizeof(uint32_t));
+    for (int k = 0; k < 3; k++) s->cert_center[k] = center[k];
+    s->cert_radius = radius;
     return 0;
 }
 
@@ -1541,6 +1560,34 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
     return best;
 }
 
+/* The certified walk's view of a ray (rayrs_amd/csrc/layout.h, device_path.h cert_ray_word): its direction as
+ * four signed bytes (dx, dy, dz, 127), largest component +-127, rounded to nearest even; (0, 0, 0, 127) for a
+ * ray outside the theorem's premises (scene_host.cpp build_cert_tree (5)). */
+static uint32_t cert_ray_word(const orc_scene* s, ray_t ray) {
+    const uint32_t outside = 127u << 24;
+    const double o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    double m = 0.0;
+    for (int k = 0; k < 3; k++) {
+        if (!(rr_fabs(o[k] - s->cert_center[k]) <= s->cert_radius)) return outside; /* NaN: outside */
+        if (!(rr_fabs(d[k]) <= 0x1p400)) return outside;
+        if (rr_fabs(d[k]) > m) m = rr_fabs(d[k]);
+    }
+    if (!(m >= 0x1p-400)) return outside;
+    const double sc = 127.0 / m;
+    uint32_t w = outside;
+    for (int k = 0; k < 3; k++) {
+        const int q = (int)nearbyint(d[k] * sc);
+        w |= ((uint32_t)q & 0xffu) << (8 * k);
+    }
+    return w;
+}
+static int cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
+    int sum = 0;
+    for (int k = 0; k < 4; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(slot_word >> (8 * k));
+    if (sum < 0) sum = -sum;
+    return sum < 512; /* layout.h CERT_THRESHOLD */
+}
+
 /* Diagnostics: when set, isect_wide adds one to hist[record] per visit and to
  * hist[n_wide + min(sp, 63)] the stack height seen at each visit (single-threaded use). */
 static uint64_t* g_visit_hist = NULL;
@@ -1567,6 +1614,8 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
     int sp = 0;
     uint32_t cur = s->finfo.wide_root_ref;
+    const int certified = s->wide_cert != NULL; /* the certified walk: no culling, certificates consulted */
+    const uint32_t ray_word = certified ? cert_ray_word(s, ray) : 0u;
     for (;;) {
         if ((cur >> 30) == REF_KIND_INTERIOR) {
             uint32_t rec = cur & 0x3fffffffu;
@@ -1587,7 +1636,11 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                     ent[c] = tmin;
                 } else if (kind != REF_KIND_NONE) {
                     hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
-                    if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) hit[c] = 0;
+                    if (certified) {
+                        if (!hit[c] && cert_in_doubt(ray_word, s->wide_cert[(size_t)rec * 4 + c])) hit[c] = 1, ent[c] = tmin;
+                    } else if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) {
+                        hit[c] = 0;
+                    }
                 }
                 n += hit[c];
             }

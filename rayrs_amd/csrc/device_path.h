@@ -317,6 +317,7 @@ struct Trav {
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
     int sp;
+    uint32_t dq;         // WALK_CERT: the ray's direction as four signed bytes (cert_ray_word)
 };
 
 // What BvhTree::intersect does first (bvh.rs:394): the box of the root Node.  A ray that misses it
@@ -330,11 +331,40 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
+// The ray as the certified walk's certificates see it (layout.h): (dx, dy, dz, 127) with the direction scaled to
+// largest component +-127 and rounded to nearest even, or (0, 0, 0, 127) for a ray outside the theorem's premises
+// -- origin farther than cert_radius (max norm) from cert_center, a component of the direction that is not finite
+// or beyond 2^400, or a largest component below 2^-400 -- for which every triangle's certificate then reads
+// "in doubt".  The CPU checker restates the same arithmetic (one IEEE division, three products,
+// round to nearest even), so both sides see the same word.
+RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
+    const double ax = rr_fabs(d.x), ay = rr_fabs(d.y), az = rr_fabs(d.z);
+    double m = ax;
+    if (ay > m) m = ay;
+    if (az > m) m = az;
+    const bool inside = rr_fabs(o.x - sc.cert_center[0]) <= sc.cert_radius && rr_fabs(o.y - sc.cert_center[1]) <= sc.cert_radius &&
+                        rr_fabs(o.z - sc.cert_center[2]) <= sc.cert_radius && ax <= 0x1p400 && ay <= 0x1p400 && az <= 0x1p400 &&
+                        m >= 0x1p-400;  // (NaN compares false everywhere)
+    const double s = 127.0 / m;
+    const int qx = (int)__builtin_rint(d.x * s), qy = (int)__builtin_rint(d.y * s), qz = (int)__builtin_rint(d.z * s);
+    const uint32_t w = ((uint32_t)qx & 0xffu) | (((uint32_t)qy & 0xffu) << 8) | (((uint32_t)qz & 0xffu) << 16) | CERT_RAY_OUTSIDE;
+    return inside ? w : CERT_RAY_OUTSIDE;
+}
+
+// |dx nx + dy ny + dz nz + 127 bias| < CERT_THRESHOLD: one v_dot4_i32_i8 with the threshold folded into its
+// accumulator and one unsigned compare.
+RR_DEV bool cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
+    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)slot_word, CERT_THRESHOLD - 1, false);
+    return (uint32_t)sum < (uint32_t)(2 * CERT_THRESHOLD - 1);
+}
+
+template <int WALK = WALK_FAST>
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
+    tv.dq = WALK == WALK_CERT ? cert_ray_word(sc, o, d) : 0u;
     tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
@@ -377,9 +407,10 @@ struct HotNodes {
     RR_DEV static constexpr uint32_t stride() { return COMPACT ? 9u : 17u; }  // granules
 };
 
-template <bool COMPACT, bool COUNT, bool EXACT = false>
+template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
                                WorkCount& wc) {
+    constexpr bool EXACT = WALK != WALK_FAST;  // nothing culled by the closest hit, slots entered in slot order
     const double tmin = sc.t0, tmax = sc.t1;
     const V3 inv = tv.inv;
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
@@ -388,14 +419,17 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     double e0, e1, e2, e3;
     bool h0, h1, h2, h3;
     uint32_t r0, r1, r2, r3;
+    uint4 ct = make_uint4(0u, 0u, 0u, 0u);  // WALK_CERT: the slots' certificate words (the record's last granule)
     if (COMPACT) {
         uint4 a, b, c, d, f, g, r;
         if (rec < hot.count) {
             const uint4* src = hot.lds + rec * HotNodes::stride<true>();
             a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+            if (WALK == WALK_CERT) ct = src[7];
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
             a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+            if (WALK == WALK_CERT) ct = src[7];
         }
         r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
         // slot k = dwords 6k .. 6k+5 (xmin xmax ymin ymax zmin zmax)
@@ -412,6 +446,7 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         uint4 x, y, z, r;
         if (in_lds) x = lsrc[0], y = lsrc[1], z = lsrc[2], r = lsrc[12];
         else x = gsrc[0], y = gsrc[1], z = gsrc[2], r = gsrc[12];
+        if (WALK == WALK_CERT) ct = in_lds ? lsrc[13] : gsrc[13];
         r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
         h0 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e0);
         if (in_lds) x = lsrc[3], y = lsrc[4], z = lsrc[5];
@@ -440,10 +475,19 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // (a compile-time choice: the margin as a kernel argument is one more scalar pair alive across the walk, which the
     // traversal kernel answers by re-loading arguments from memory inside its loop -- +27 % kernel time, measured)
     const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
-    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
-    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
-    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
+    unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
+    unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
+    unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
+    unsigned long long m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
+    if (WALK == WALK_CERT) {
+        // a slot the segment misses is entered all the same when its certificate is in doubt for this ray: only a
+        // triangle of a group record can be (every other slot carries CERT_NEVER), and the walk stands in that record
+        // because the group's gating box was passed -- the reference tests this triangle, so may the walk
+        m0 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.x));
+        m1 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.y));
+        m2 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.z));
+        m3 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.w));
+    }
 #define RR_LANE_BIT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
     h0 = RR_LANE_BIT(m0), h1 = RR_LANE_BIT(m1), h2 = RR_LANE_BIT(m2), h3 = RR_LANE_BIT(m3);
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
@@ -517,15 +561,15 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
-template <bool COMPACT, bool COUNT, bool EXACT = false>
+template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
-    trav_init(sc, o, d, tv);
+    trav_init<WALK>(sc, o, d, tv);
     const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
-            trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
+            trav_interior_step<COMPACT, COUNT, WALK>(sc, o, stack, hot, tv, wc);
         else
             trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }

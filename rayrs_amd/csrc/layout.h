@@ -53,13 +53,34 @@ static_assert(sizeof(NodeF64) == 128, "NodeF64");
 struct Node4F32 {  // 128 B
     float box[4][6];
     uint32_t ref[4];
-    uint32_t pad[4];
+    uint32_t cert[4];  // one certificate word per slot (below); read by the certified walk only
 };
 struct Node4F64 {  // 256 B
     double box[4][6];
     uint32_t ref[4];
-    uint32_t pad[12];
+    uint32_t cert[4];
+    uint32_t pad[8];
 };
+
+// Certificate word of a slot: four signed bytes (nx, ny, nz, bias).  The certified walk (device_path.h
+// trav_interior_step<..., WALK_CERT>) carries the ray's direction as four signed bytes (dx, dy, dz, 127) -- the
+// direction scaled so that its largest component is +-127, each component rounded to nearest -- and takes a slot
+// whose box the ray misses as "entered" all the same when |dx nx + dy ny + dz nz + 127 bias| < CERT_THRESHOLD:
+// the ray may then lie so close to the plane of the slot's triangle that the reference's own test is rounding
+// noise, and only running that test says what the reference answers (scene_host.cpp build_cert_tree has the
+// theorem and the arithmetic behind the threshold).
+//   CERT_NEVER  (0, 0, 0, 127): the sum is 127 * 127 whatever the ray -- a slot whose box test decides by
+//               construction (interior slots, groups behind their exact gating box, unused slots);
+//   CERT_ALWAYS (0, 0, 0, 0): the sum is 0 -- a primitive for which nothing is proved (not a triangle, degenerate,
+//               too thin or too small for the scene): tested whenever its group's gating box is entered, as the
+//               reference does;
+//   otherwise   (nx, ny, nz, 0): the triangle's normal scaled so that its largest component is +-127, rounded.
+// A ray outside the theorem's premises (origin too far out, direction not finite or of extreme magnitude) carries
+// (0, 0, 0, 127): every triangle slot then reads "in doubt", CERT_NEVER slots still read "never".
+constexpr uint32_t CERT_NEVER = 127u << 24;
+constexpr uint32_t CERT_ALWAYS = 0u;
+constexpr int32_t CERT_THRESHOLD = 512;
+constexpr uint32_t CERT_RAY_OUTSIDE = 127u << 24;
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
@@ -72,6 +93,15 @@ static_assert(sizeof(Node4F64) == 256, "Node4F64");
 //   plane   : umin, umax, vmin, vmax, pos as 5 f64 (axis in the tag)
 constexpr uint32_t PRIM_DWORDS_COMPACT = 12;  // 48 B
 constexpr uint32_t PRIM_DWORDS_FULL = 20;     // 80 B
+
+// Which walk a traversal kernel instance makes (SceneDev::walk; rayrs_render_params.walk, include/rayrs_hip.h):
+//   WALK_FAST       the tree of single primitives behind clipped boxes, closest-hit culling: two bets
+//                   (device_path.h TRAV_CULL_MARGIN, scene_host.cpp LEAF_MARGIN);
+//   WALK_REFERENCE  the gate tree, nothing culled: the primitives BvhTree::intersect tests, by construction;
+//   WALK_CERT       the certified tree, nothing culled: a primitive of an entered group is skipped only where
+//                   "its widened box is missed" provably means "the reference rejects it" (scene_host.cpp
+//                   build_cert_tree), which the slot's certificate word decides against the ray's (Trav::dq).
+enum : int { WALK_FAST = 0, WALK_REFERENCE = 1, WALK_CERT = 2 };
 
 // One row per distinct (Material, Emission) pair; material.rs:148-238, :1056-1060.
 struct SurfaceDev {
@@ -104,9 +134,10 @@ struct SceneDev {
     double t0, t1;  // Scene::t_range, lib.rs:218
     double hdri_wm1, hdri_hm1;  // (hdri_w - 1) as f64 and (hdri_h - 1) as f64, lib.rs:262-263 (converted on the host: a kernel
                                 // that converts them hoists the results into vector registers for its whole run)
-    // rayrs_render_params.exact_traversal: the walk culls nothing by the closest hit so far, as BvhTree::intersect
-    // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
-    uint32_t exact, pad1;
+    // rayrs_render_params.walk as the kernels take it: device_path.h WALK_FAST / WALK_REFERENCE / WALK_CERT (which
+    // instance of the traversal kernel runs, on which of the scene's three trees `nodes` points to)
+    uint32_t walk, pad1;
+    double cert_center[3], cert_radius;  // WALK_CERT: the per-ray guard (device_path.h cert_ray_word)
 };
 
 struct CameraDev {

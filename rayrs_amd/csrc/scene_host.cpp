@@ -623,6 +623,10 @@ void tight_box(const Aabb& b, const double* gate, double* out) {
         if ((double)lf > lo) lf = std::nextafterf(lf, -std::numeric_limits<float>::infinity());
         if ((double)hf < hi) hf = std::nextafterf(hf, std::numeric_limits<float>::infinity());
         lo = (double)lf, hi = (double)hf;
+        if (!gate) {  // the certified tree: its group records sit BEHIND the gating box, nothing is clipped
+            out[2 * a] = lo, out[2 * a + 1] = hi;
+            continue;
+        }
         // (a bound that is not a number, from an object whose own box is not, leaves the gating box's bound)
         out[2 * a] = lo > gate[2 * a] ? lo : gate[2 * a];
         out[2 * a + 1] = hi < gate[2 * a + 1] ? hi : gate[2 * a + 1];
@@ -652,12 +656,161 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
     front_largest(t);
 }
 
+// ------------------------------------------------------------ the certified tree
+//
+// What the default walk leaves out, and why that is the reference's answer BY THEOREM, not by measurement.
+//
+// The tree is the gate tree -- groups behind exactly their gating boxes, interior boxes the unions of those, so
+// that "the segment misses the box" means "the reference does not get there" by the monotony of the slab test --
+// with every group of CERT_MIN_GROUP or more primitives opened into a record of its own ("group record"): the
+// group's slot keeps the exact gating box and refers to that record, whose slots are the group's primitives one
+// by one, each behind its own bounding box widened by LEAF_MARGIN of its largest extent (rounded outwards to
+// f32, NOT clipped) and each with a certificate word (layout.h).  A walk that stands in a group record has
+// passed the group's gating box exactly as BvhTree::intersect does (bvh.rs:391-415), so the reference tests
+// every primitive of that record; the walk tests a primitive iff the segment enters its widened box OR its
+// certificate reads "in doubt" for this ray, and skips it otherwise.  The claim: whenever it skips a triangle,
+// the reference's own test (geometry.rs:359-375, then bvh.rs:406) rejects it.
+//
+// Notation.  u = 2^-53.  Triangle p1, p2, p3; ray o + s d, s in (t0, t1); all finite doubles.  The reference
+// computes, in this order and without fused operations (device_path.h triangle_intersect is the same list):
+//     a = fl(p2 - p1), b = fl(p3 - p1), c = fl(o - p1)              (Triangle::new :342-343, intersect :360)
+//     p = fl(d x b), q = fl(c x a)
+//     den = fl(p . a), Nu = fl(p . c), Nv = fl(q . d), Nt = fl(q . b)
+//     t = fl(Nt / den), uu = fl(Nu / den), vv = fl(Nv / den)
+//     reject if t < 0 or uu < 0 or vv < 0 or fl(uu + vv) > 1; accept iff also t0 < t < t1   (bvh.rs:406)
+// Take a, b, c as the data of a perturbed problem: triangle Q' = (p1, p1 + a, p1 + b), origin o' = p1 + c.  Each
+// component of a, b, c carries one rounding, so Q' and o' lie within u * (their distance from p1) of Q and o.
+// Write P = d x b, Qx = c x a, DEN = P . a = -d . (a x b), NU = P . c, NV = Qx . d, NT = Qx . b for the exact
+// values on that data; U = NU / DEN, V = NV / DEN, TT = NT / DEN are the barycentric coordinates and the ray
+// parameter of the point X' = o' + TT d = p1 + U a + V b where the perturbed line meets the perturbed plane.
+//
+// (1) Rounding.  A cross product's component is fl(fl(xy) - fl(zw)): |p - P| <= sqrt2 g2 |d||b| with
+//     g2 = 2u / (1 - 2u) (sum of squares of |x y| + |z w| over the components is at most 2 |d|^2 |b|^2); a
+//     three-term dot product adds at most g3 |p||a|.  So
+//         |den - DEN| <= E |d||a||b|,  |Nu - NU| <= E |d||b||c|,  |Nv - NV| <= E |c||a||d|,  |Nt - NT| <= E |c||a||b|
+//     with E = (3 + 2 sqrt2) u (1 + 8u) < 6 u.  (Underflow adds at most 2^-1070 absolutely, below every
+//     quantity compared here once magnitudes are within the ranges checked in (5).)
+// (2) Conditioning.  Let kappa = |DEN| / (|d||a||b|) = |cos(d, n')| sin(gamma'), n' the normal of Q' and gamma'
+//     its corner angle at p1, and L = max(1, |c| / min(|a|, |b|)).  PREMISE:  kappa >= 2^-36 L.
+//     Then den = DEN (1 + eta) with |eta| <= 6u / kappa <= 2^-14: den is finite, not zero and has DEN's sign, and
+//     (a quotient adds one rounding; Nu / den = U / (1 + eta) + (Nu - NU) / den with |Nu - NU| / |DEN| <=
+//     (6u / kappa) |c| / |a|, likewise Nv with |c| / |b| and Nt with |c| / |d|)
+//         |uu - U| <= (|U| + 1) lam,  |vv - V| <= (|V| + 1) lam,  |t - TT| <= (|TT| + |c| / |d|) lam / L,
+//     lam = 8u L / kappa <= 2^-14.
+// (3) Acceptance puts X' next to the triangle.  If the reference accepts, uu >= 0, vv >= 0, uu + vv <= 1 + 2u,
+//     so U >= -2 lam, V >= -2 lam, U + V <= 1 + 6 lam: every barycentric weight of X' in Q' is at least
+//     -6 lam.  Two of three weights summing to 1 can be negative, so along every axis k X' lies within
+//     12 lam ext_k(Q') < 2^-10 ext_k of the bounding box of Q' -- within 2^-9 ext_max of the bounding box of Q
+//     (the perturbations of Q' and o' are at most u |a|, u |b|, u |c|, and u |c| <= u L min(|a|,|b|) <= 2^-21 ext_max
+//     with L <= 2^31, checked in (5)) -- that is, inside the widened box W, whose margin is
+//     m = LEAF_MARGIN ext_max = 2^-6 ext_max, with (7/8) m to spare on every side.
+// (4) ... so the slab test on W passes.  Along the line a step ds moves no coordinate by more than ds |d|_inf,
+//     so the exact parameter interval [A, B] of the line inside W contains TT with (7/8) m / |d|_inf to spare on
+//     both sides.  The slab test computes each axis' parameters as fl(fl(bound - o_k) fl(1 / d_k)): relative
+//     error below 4u each, and the parameters that decide are at most |TT| + m / |d|_inf in magnitude with
+//     |TT||d| <= |c| + |X' - p1| <= |c| + 4 ext_max, so the computed interval [A~, B~] still contains TT with
+//     (3/4) m / |d|_inf to spare (4u |c| <= 2^-19 ext_max).  A zero component d_k makes that axis' slab
+//     (-inf, +inf), o_k lying strictly inside W's slab (X'_k = o'_k there): never a NaN.  Acceptance also says
+//     t0 < t < t1, and |t - TT||d| <= (|TT||d| + |c|) lam / L <= (2 |c| / L + 4 ext_max) lam <= (2 sqrt3 + 4) lam ext_max
+//     < 2^-11 ext_max = m / 32  (|c| / L <= min(|a|,|b|) <= sqrt3 ext_max).  So A~ < t < B~ and t0 < t < t1:
+//     max(t0, A~) < min(t1, B~), and the test the walk makes (device_path.h slab: !(tmax <= tmin)) passes.
+//     Contrapositive: the segment misses W and the premise holds  ==>  the reference does not accept this triangle.
+// (5) The certificate makes the premise checkable from one dword.  At build time, per triangle, with D the bound on
+//     |o - p1| that the walk's per-ray guard enforces (FlatScene::cert_radius: |o - centre|_inf <= R, so
+//     D = sqrt3 (R + the root box's largest half extent)):  tau = 2^-36 max(1, 1.01 D / min(|a|,|b|)) / sin(gamma).
+//     If tau <= 2^-10, and the triangle's sizes are sane (edges and D within 2^+-200, L <= 2^31), the word holds
+//     the normal N = a x b scaled to largest component +-127 and rounded to nearest; else CERT_ALWAYS.  The walk
+//     scales d the same way (largest component +-127, round to nearest: exact division 127 / max|d_k|, one
+//     multiply, v_rndne).  With r, s the two rounding vectors (components at most 1/2 + 2^-40),
+//         dq . nq = (127 / |d|_inf)(127 / |N|_inf) d . N + (127 / |d|_inf) d . r + (127 / |N|_inf) N . s + s . r,
+//     and the last three are at most 190.5 + 190.5 + 0.76 < 382 in magnitude.  "Not in doubt" means
+//     |dq . nq| >= CERT_THRESHOLD = 512, hence |d . N| / (|d||N|) >= (512 - 382) / (127^2 * 3) > 2^-8.6
+//     (|d|_inf >= |d| / sqrt3, likewise N): four times tau, which swallows the difference between N computed here
+//     in f64 and the exact normal of Q' (relative 4u / sin(gamma)) -- kappa >= 2^-8.6 sin(gamma') >= 2^-36 L.
+//     A ray whose origin fails the guard, or whose direction has a largest component outside [2^-400, 2^400] or a
+//     component that is not finite, carries (0, 0, 0, 127): every triangle reads "in doubt" and is tested.
+// What is in doubt is tested with the reference's own arithmetic, what is not in doubt and missed is rejected
+// by the reference: the certified walk returns BvhTree::intersect's closest hit for every ray.  Nothing is
+// culled by the closest hit so far (no certificate exists for that: device_path.h TRAV_CULL_MARGIN), so the
+// order of the visits does not matter and slots are entered in slot order.
+// About 2 % of (ray, triangle slot) pairs read "in doubt" (|cos| below 0.01 ... 0.03 depending on how the two
+// vectors quantise): they cost a primitive test each, the same test the reference makes.
+constexpr uint32_t CERT_MIN_GROUP = 3;  // smaller groups stay behind their gating box (a record visit costs about a primitive test)
+constexpr double CERT_GUARD_RADII = 4.0;  // rays from within this many root-box half extents of its centre are certified
+
+static uint32_t cert_word_for(const Shape& s, double D) {
+    if (s.kind != PRIM_TRIANGLE) return CERT_ALWAYS;
+    const double a[3] = {s.p2.x - s.p1.x, s.p2.y - s.p1.y, s.p2.z - s.p1.z};
+    const double b[3] = {s.p3.x - s.p1.x, s.p3.y - s.p1.y, s.p3.z - s.p1.z};
+    const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const double lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const double lo = 0x1p-200, hi = 0x1p200;
+    if (!(la >= lo && la <= hi && lb >= lo && lb <= hi && ln >= lo * lo && D >= lo && D <= hi)) return CERT_ALWAYS;  // NaN: false
+    const double emin = la < lb ? la : lb;
+    const double L = std::max(1.0, 1.01 * D / emin);
+    if (!(L <= 0x1p31)) return CERT_ALWAYS;
+    const double sin_gamma = ln / (la * lb);
+    const double tau = 0x1p-36 * L / sin_gamma;
+    if (!(tau <= 0x1p-10)) return CERT_ALWAYS;
+    const double m = std::max(std::fabs(n[0]), std::max(std::fabs(n[1]), std::fabs(n[2])));
+    const double sc = 127.0 / m;
+    uint32_t w = 0;
+    for (int k = 0; k < 3; k++) {
+        const int q = (int)std::nearbyint(n[k] * sc);  // in [-127, 127]
+        w |= ((uint32_t)q & 0xffu) << (8 * k);
+    }
+    return w;
+}
+
+// f.gate must be built.  objs / prim_object give the shapes behind the primitive records.
+void build_cert_tree(FlatScene& f, const ObjectList& objs, const std::vector<Aabb>& prim_box) {
+    WalkTree& t = f.cert;
+    t = f.gate;
+    t.node_bytes.clear();
+    // the guard: rays from within CERT_GUARD_RADII half extents of the root box's centre (max norm)
+    double half = 0.0;
+    for (int a = 0; a < 3; a++) {
+        f.cert_center[a] = 0.5 * f.root_box[2 * a] + 0.5 * f.root_box[2 * a + 1];
+        half = std::max(half, 0.5 * (f.root_box[2 * a + 1] - f.root_box[2 * a]));
+    }
+    f.cert_radius = CERT_GUARD_RADII * half;
+    if (!(f.cert_radius > 0.0) || !std::isfinite(f.cert_radius)) f.cert_radius = 0.0;  // nothing is certified
+    const double D = std::sqrt(3.0) * (f.cert_radius + half);
+    const uint32_t n_gate = t.n();
+    t.cert.assign((size_t)n_gate * 4, CERT_NEVER);
+    bool opened = false;
+    for (uint32_t r = 0; r < n_gate; r++)
+        for (int c = 0; c < 4; c++) {
+            const uint32_t ref = t.ref[(size_t)r * 4 + c];
+            if ((ref >> 30) != REF_RANGE) continue;
+            const uint32_t first = (ref & 0x3fffffffu) >> 2, count = (ref & 3u) + 1u;
+            if (count < CERT_MIN_GROUP) continue;
+            const uint32_t rec = t.n();
+            t.ref.resize(t.ref.size() + 4, REF_NONE << 30);
+            t.box.resize(t.box.size() + 24, 0.0);
+            t.cert.resize(t.cert.size() + 4, CERT_NEVER);
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t p = first + i;
+                tight_box(prim_box[p], nullptr, &t.box[((size_t)rec * 4 + i) * 6]);
+                t.ref[(size_t)rec * 4 + i] = (REF_RANGE << 30) | (p << 2);
+                t.cert[(size_t)rec * 4 + i] = f.cert_radius > 0.0 ? cert_word_for(objs.objs[f.prim_object[p]].geom, D) : CERT_ALWAYS;
+            }
+            t.ref[(size_t)r * 4 + c] = (REF_INTERIOR << 30) | rec;
+            opened = true;
+        }
+    // a group record's first slot replaces the group's reference, its others are pushed: three more pending entries at most
+    if (opened) t.depth += 3;
+}
+
 // prim_box[p]: the reference's bounding box of the object behind primitive record p
-void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
+void build_walk_trees(FlatScene& f, const ObjectList& objs, const std::vector<Aabb>& prim_box) {
     f.walk = WalkTree();
     f.gate = WalkTree();
+    f.cert = WalkTree();
     if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
-        f.walk.root_ref = f.gate.root_ref = f.root_ref;
+        f.walk.root_ref = f.gate.root_ref = f.cert.root_ref = f.root_ref;
         return;
     }
     std::vector<WalkGroup> groups;
@@ -666,6 +819,7 @@ void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
     std::vector<WalkGroup> singles;
     split_groups(groups, prim_box, singles);
     build_tree_over(singles, f.walk);
+    build_cert_tree(f, objs, prim_box);
 }
 
 inline bool boxes_f32_exact(const WalkTree& t) {
@@ -689,6 +843,7 @@ void fill_nodes(WalkTree& t) {
         for (int ch = 0; ch < 4; ch++) {
             const uint32_t ref = t.ref[(size_t)r * 4 + ch];
             nodes[r].ref[ch] = ref;
+            nodes[r].cert[ch] = t.cert.empty() ? CERT_NEVER : t.cert[(size_t)r * 4 + ch];
             for (int k = 0; k < 6; k++)
                 nodes[r].box[ch][k] = (ref >> 30) == REF_NONE ? ((k & 1) ? (F)-inf : (F)inf) : (F)t.box[((size_t)r * 4 + ch) * 6 + k];
         }
@@ -733,11 +888,11 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     {
         std::vector<Aabb> prim_box(n);
         for (size_t p = 0; p < n; p++) prim_box[p] = b.boxes[f.prim_object[p]];
-        build_walk_trees(f, prim_box);
+        build_walk_trees(f, objs, prim_box);
     }
 
     // ---- choose the layout
-    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk);
+    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk) && boxes_f32_exact(f.cert);
     for (size_t i = 0; i < n && compact; i++) {
         const Shape& s = objs.objs[i].geom;
         if (s.kind != PRIM_TRIANGLE) continue;
@@ -749,7 +904,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
             }
     }
     f.compact = compact;
-    for (WalkTree* t : {&f.gate, &f.walk}) {
+    for (WalkTree* t : {&f.gate, &f.walk, &f.cert}) {
         if (compact) fill_nodes<Node4F32, float>(*t);
         else fill_nodes<Node4F64, double>(*t);
     }

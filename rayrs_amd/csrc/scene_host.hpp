@@ -50,6 +50,7 @@ struct WalkTree {
     std::vector<uint32_t> ref;  // n * 4
     uint32_t root_ref = 0;
     uint32_t depth = 0;         // stack entries the traversal can need
+    std::vector<uint32_t> cert;  // n * 4: the slots' certificate words (layout.h CERT_*); empty = CERT_NEVER everywhere
     std::vector<uint8_t> node_bytes;  // the records as the kernels read them (Node4F32 / Node4F64)
     uint32_t n() const { return (uint32_t)(ref.size() / 4); }
 };
@@ -64,8 +65,14 @@ struct FlatScene {
     // The trees the kernels traverse (scene_host.cpp "the walk trees"): four-slot records whose leaf slots are
     //   gate  the reference's leaf groups behind their exact gating boxes -- reaches exactly what the reference
     //         reaches; walked when rayrs_render_params.exact_traversal is set, and by the local-pool route;
-    //   walk  single primitives behind their own widened boxes inside the gating box -- the default.
-    WalkTree walk, gate;
+    //   walk  single primitives behind their own widened boxes inside the gating box, closest-hit culling: two bets
+    //         on the reference's arithmetic (RAYRS_WALK_FAST);
+    //   cert  the gate tree with every group of three or four primitives opened into a record of its own: single
+    //         primitives behind their widened boxes, each with a quantised normal, so that "box missed" is only
+    //         taken for "the reference rejects" where that is a theorem (scene_host.cpp build_cert_tree) -- the default.
+    WalkTree walk, gate, cert;
+    double cert_center[3] = {0, 0, 0};  // rays whose origin lies farther than cert_radius (max norm) from here are
+    double cert_radius = 0;             // outside the theorem's premises: every certificate reads "in doubt" for them
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)
