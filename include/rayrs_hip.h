@@ -158,6 +158,7 @@ typedef struct {
     uint32_t pad0;
     double cert_center[3];  /* rays whose origin lies within cert_radius (max norm) of cert_center are inside the */
     double cert_radius;     /* certified walk's theorem; for the others every certificate reads "in doubt" */
+    double cert_ext;        /* largest extent along an axis of a triangle that carries a certificate (the walk's culling margin) */
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -196,7 +197,8 @@ int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uin
  * scaled to largest component +-127, or (0,0,0,127) "the box test decides" for every other kind of slot, or 0
  * "always test" for a primitive nothing is proved about.  rayrs_amd/csrc/scene_host.cpp build_cert_tree states
  * the theorem; tests/test_bvh_builder.py re-derives every word and box from the objects. */
-int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* wide_cert);
+int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* wide_cert,
+                                 double* prim_gate /* n_prims * 6: every primitive's gating box */);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 

@@ -864,7 +864,8 @@ struct orc_scene {
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
     uint32_t* wide_cert; /* n_wide * 4 certificate words (orc_set_wide_cert), or NULL */
-    double cert_center[3], cert_radius;
+    double* prim_gate;   /* n_prims * 6: every primitive's gating box, as the product exports it */
+    double cert_center[3], cert_radius, cert_ext;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -882,6 +883,7 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->wide_box);
     free(s->wide_ref);
     free(s->wide_cert);
+    free(s->prim_gate);
     free(s);
 }
 
@@ -1323,13 +1325,18 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
  * them over after orc_set_wide makes traversal 2 the product's CERTIFIED walk (rayrs_amd/csrc/device_path.h
  * trav_interior_step<..., WALK_CERT>, restated in isect_wide below): nothing culled, and a slot whose box
  * the segment misses entered all the same when its certificate reads "in doubt" for the ray. */
-int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double center[3], double radius) {
-    if (!s || !s->have_wide || !cert) return -1;
+int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double* prim_gate, const double center[3], double radius,
+                      double ext) {
+    if (!s || !s->have_wide || !cert || !prim_gate) return -1;
     free(s->wide_cert);
+    free(s->prim_gate);
+    s->prim_gate = (double*)malloc(((size_t)s->finfo.n_prims * 6 + 1) * sizeof(double));
+    memcpy(s->prim_gate, prim_gate, (size_t)s->finfo.n_prims * 6 * sizeof(double));
     s->wide_cert = (uint32_t*)malloc(((size_t)s->finfo.n_wide * 4 + 1) * sizeof(uint32_t));
     memcpy(s->wide_cert, cert, (size_t)s->finfo.n_wide * 4 * sizeof(uint32_t));
     for (int k = 0; k < 3; k++) s->cert_center[k] = center[k];
     s->cert_radius = radius;
+    s->cert_ext = ext;
     return 0;
 }
 
@@ -1561,31 +1568,40 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
 }
 
 /* The certified walk's view of a ray (rayrs_amd/csrc/layout.h, device_path.h cert_ray_word): its direction as
- * four signed bytes (dx, dy, dz, 127), largest component +-127, rounded to nearest even; (0, 0, 0, 127) for a
- * ray outside the theorem's premises (scene_host.cpp build_cert_tree (5)). */
+ * three signed bytes (dx, dy, dz), scaled to length 127, rounded to nearest even; (0, 0, 0) for a ray
+ * outside the theorem's premises (scene_host.cpp build_cert_tree (5)). */
 static uint32_t cert_ray_word(const orc_scene* s, ray_t ray) {
-    const uint32_t outside = 127u << 24;
     const double o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
     double m = 0.0;
     for (int k = 0; k < 3; k++) {
-        if (!(rr_fabs(o[k] - s->cert_center[k]) <= s->cert_radius)) return outside; /* NaN: outside */
-        if (!(rr_fabs(d[k]) <= 0x1p400)) return outside;
+        if (!(rr_fabs(o[k] - s->cert_center[k]) <= s->cert_radius)) return 0u; /* NaN: outside */
+        if (!(rr_fabs(d[k]) <= 0x1p400)) return 0u;
         if (rr_fabs(d[k]) > m) m = rr_fabs(d[k]);
     }
-    if (!(m >= 0x1p-400)) return outside;
-    const double sc = 127.0 / m;
-    uint32_t w = outside;
+    if (!(m >= 0x1p-400)) return 0u;
+    const double sc = 127.0 / rr_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    uint32_t w = 0u;
     for (int k = 0; k < 3; k++) {
         const int q = (int)nearbyint(d[k] * sc);
         w |= ((uint32_t)q & 0xffu) << (8 * k);
     }
     return w;
 }
+/* in doubt: |dx ax + dy ay + dz az| < 130 w, w = bits 24..30 (layout.h) */
 static int cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
     int sum = 0;
-    for (int k = 0; k < 4; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(slot_word >> (8 * k));
+    for (int k = 0; k < 3; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(slot_word >> (8 * k));
     if (sum < 0) sum = -sum;
-    return sum < 512; /* layout.h CERT_THRESHOLD */
+    return (uint32_t)sum < ((slot_word >> 24) & 127u) * 130u;
+}
+/* A slot that is not in doubt is culled when its box is entered beyond the closest hit so far -- by the usual
+ * relative margin and by 2^-8 of the largest extent of a certified triangle, taken along the ray's slowest axis
+ * (device_path.h cert_penalty and trav_interior_step<..., WALK_CERT>: the same expressions). */
+static double cert_penalty(const orc_scene* s, v3 inv) {
+    double im = rr_fabs(inv.x);
+    if (rr_fabs(inv.y) > im) im = rr_fabs(inv.y);
+    if (rr_fabs(inv.z) > im) im = rr_fabs(inv.z);
+    return s->cert_ext * (0x1p-8 * im);
 }
 
 /* Diagnostics: when set, isect_wide adds one to hist[record] per visit and to
@@ -1616,6 +1632,7 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     uint32_t cur = s->finfo.wide_root_ref;
     const int certified = s->wide_cert != NULL; /* the certified walk: no culling, certificates consulted */
     const uint32_t ray_word = certified ? cert_ray_word(s, ray) : 0u;
+    const double pen = certified ? cert_penalty(s, inv) : 0.0;
     for (;;) {
         if ((cur >> 30) == REF_KIND_INTERIOR) {
             uint32_t rec = cur & 0x3fffffffu;
@@ -1631,16 +1648,24 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                 uint32_t kind = refs[c] >> 30;
                 hit[c] = 0;
                 ent[c] = 0.0;
-                if (kind == REF_KIND_SINGLE) {
+                if (certified) {
+                    if (kind != REF_KIND_NONE) {
+                        const double* bx = s->wide_box + ((size_t)rec * 4 + c) * 6;
+                        /* (a ray outside the theorem's premises -- word 0 -- is in doubt everywhere) */
+                        const int doubt = ray_word == 0u || cert_in_doubt(ray_word, s->wide_cert[(size_t)rec * 4 + c]);
+                        hit[c] = aabb_intersect_entry(bx, ray, inv, tmin, tmax, &ent[c]);
+                        if (hit[c]) {
+                            if (!doubt && ent[c] > best_t * (1.0 + 0x1p-10) + pen) hit[c] = 0;
+                        } else if (doubt && (s->wide_cert[(size_t)rec * 4 + c] >> 31)) {
+                            hit[c] = 1; /* a triangle-side box missed, the ray near a plane below: only the tests themselves know */
+                        }
+                    }
+                } else if (kind == REF_KIND_SINGLE) {
                     hit[c] = 1;
                     ent[c] = tmin;
                 } else if (kind != REF_KIND_NONE) {
                     hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
-                    if (certified) {
-                        if (!hit[c] && cert_in_doubt(ray_word, s->wide_cert[(size_t)rec * 4 + c])) hit[c] = 1, ent[c] = tmin;
-                    } else if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) {
-                        hit[c] = 0;
-                    }
+                    if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) hit[c] = 0;
                 }
                 n += hit[c];
             }
@@ -1663,7 +1688,12 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
             }
         } else {
             uint32_t first = (cur & 0x3fffffffu) >> 2;
-            uint32_t count = (cur & 3u) + 1u;
+            uint32_t count = (cur >> 30) == REF_KIND_SINGLE ? 1u : (cur & 3u) + 1u;
+            if (certified && (cur >> 30) == REF_KIND_SINGLE) {
+                /* a single triangle of the certified tree: the reference only gets to it through its gating box (bvh.rs:399) */
+                double e_unused;
+                if (!aabb_intersect_entry(s->prim_gate + (size_t)first * 6, ray, inv, tmin, tmax, &e_unused)) count = 0;
+            }
             for (uint32_t k = 0; k < count; k++) {
                 uint32_t p = first + k;
                 int obj = (int)s->prim_object[p];

@@ -202,7 +202,8 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
 /* The certificate words of the product's certified tree (rayrs_scene_export_cert_tree), after orc_set_wide with
  * that tree's records: traversal 2 then makes the product's certified walk (nothing culled; a missed slot whose
  * certificate reads "in doubt" for the ray is entered all the same). */
-int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double center[3], double radius);
+int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double* prim_gate /* n_prims * 6 */, const double center[3], double radius,
+                      double ext);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

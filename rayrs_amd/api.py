@@ -360,16 +360,16 @@ class Scene:
 
     def export_cert_tree(self):
         """The records the default (certified) walk reads: (box[cert_n_wide,4,6], ref[cert_n_wide,4],
-        cert[cert_n_wide,4]) -- the gate tree with groups of three or four opened into records of single
-        primitives behind their own widened boxes, one certificate word per slot."""
+        cert[cert_n_wide,4], prim_gate[n_prims,6]) -- one certificate word per slot, and every primitive's gating box."""
         i = self.info()
         n = i["cert_n_wide"]
         box = np.zeros((max(n, 1), 4, 6), dtype=np.float64)
         ref = np.zeros((max(n, 1), 4), dtype=np.uint32)
         cert = np.zeros((max(n, 1), 4), dtype=np.uint32)
-        _ffi.check(self._L.rayrs_scene_export_cert_tree(self._h, box.ctypes.data, ref.ctypes.data, cert.ctypes.data),
-                   "rayrs_scene_export_cert_tree")
-        return box[:n], ref[:n], cert[:n]
+        gate = np.zeros((max(i["n_prims"], 1), 6), dtype=np.float64)
+        _ffi.check(self._L.rayrs_scene_export_cert_tree(self._h, box.ctypes.data, ref.ctypes.data, cert.ctypes.data,
+                                                        gate.ctypes.data), "rayrs_scene_export_cert_tree")
+        return box[:n], ref[:n], cert[:n], gate[:i["n_prims"]]
 
     def close(self):
         if self._h is not None:

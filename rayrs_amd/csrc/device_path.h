@@ -318,6 +318,7 @@ struct Trav {
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
     int sp;
     uint32_t dq;         // WALK_CERT: the ray's direction as four signed bytes (cert_ray_word)
+    double pen;          // WALK_CERT: cert_penalty
 };
 
 // What BvhTree::intersect does first (bvh.rs:394): the box of the root Node.  A ray that misses it
@@ -331,12 +332,12 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// The ray as the certified walk's certificates see it (layout.h): (dx, dy, dz, 127) with the direction scaled to
-// largest component +-127 and rounded to nearest even, or (0, 0, 0, 127) for a ray outside the theorem's premises
-// -- origin farther than cert_radius (max norm) from cert_center, a component of the direction that is not finite
-// or beyond 2^400, or a largest component below 2^-400 -- for which every triangle's certificate then reads
-// "in doubt".  The CPU checker restates the same arithmetic (one IEEE division, three products,
-// round to nearest even), so both sides see the same word.
+// The ray as the certified walk's certificates see it (layout.h): (dx, dy, dz), the direction scaled to length
+// 127 and rounded to nearest even, or (0, 0, 0) for a ray outside the theorem's premises -- origin farther than
+// cert_radius (max norm) from cert_center, a component of the direction that is not finite or beyond 2^400, or a
+// largest component below 2^-400 -- for which every slot that can be in doubt then is.  The CPU checker restates
+// the same arithmetic (a dot product, an IEEE square root and division, three products, round to nearest even), so
+// both sides see the same word.
 RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
     const double ax = rr_fabs(d.x), ay = rr_fabs(d.y), az = rr_fabs(d.z);
     double m = ax;
@@ -345,17 +346,30 @@ RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
     const bool inside = rr_fabs(o.x - sc.cert_center[0]) <= sc.cert_radius && rr_fabs(o.y - sc.cert_center[1]) <= sc.cert_radius &&
                         rr_fabs(o.z - sc.cert_center[2]) <= sc.cert_radius && ax <= 0x1p400 && ay <= 0x1p400 && az <= 0x1p400 &&
                         m >= 0x1p-400;  // (NaN compares false everywhere)
-    const double s = 127.0 / m;
+    const double s = 127.0 / rr_sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
     const int qx = (int)__builtin_rint(d.x * s), qy = (int)__builtin_rint(d.y * s), qz = (int)__builtin_rint(d.z * s);
-    const uint32_t w = ((uint32_t)qx & 0xffu) | (((uint32_t)qy & 0xffu) << 8) | (((uint32_t)qz & 0xffu) << 16) | CERT_RAY_OUTSIDE;
+    const uint32_t w = ((uint32_t)qx & 0xffu) | (((uint32_t)qy & 0xffu) << 8) | (((uint32_t)qz & 0xffu) << 16);
     return inside ? w : CERT_RAY_OUTSIDE;
 }
 
-// |dx nx + dy ny + dz nz + 127 bias| < CERT_THRESHOLD: one v_dot4_i32_i8 with the threshold folded into its
-// accumulator and one unsigned compare.
+// |dx ax + dy ay + dz az| < CERT_UNIT w: one v_dot4_i32_i8 (the ray word's fourth byte is zero), its absolute value,
+// w (bits 24..30) * CERT_UNIT and a compare.
 RR_DEV bool cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
-    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)slot_word, CERT_THRESHOLD - 1, false);
-    return (uint32_t)sum < (uint32_t)(2 * CERT_THRESHOLD - 1);
+    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)slot_word, 0, false);
+    const uint32_t mag = (uint32_t)(sum < 0 ? -sum : sum);
+    return mag < ((slot_word >> 24) & 127u) * CERT_UNIT;
+}
+
+// The certified walk's closest-hit culling (scene_host.cpp build_cert_tree (6)): a slot that is not in doubt is
+// skipped when its box is entered beyond the closest hit so far by the usual relative margin AND by 2^-8 of the largest
+// extent of any certified triangle of the scene, taken along the ray's slowest axis -- a hit accepted below the slot
+// lies within 2^-9 of its triangle's extent of the slot's box, which moves its parameter by no more than that.  The
+// ray's share of that, cert_ext * 2^-8 * max |1 / d_k|, is computed once per ray (Trav::pen).
+RR_DEV double cert_penalty(const SceneDev& sc, V3 inv) {
+    double im = rr_fabs(inv.x);
+    if (rr_fabs(inv.y) > im) im = rr_fabs(inv.y);
+    if (rr_fabs(inv.z) > im) im = rr_fabs(inv.z);
+    return sc.cert_ext * (0x1p-8 * im);
 }
 
 template <int WALK = WALK_FAST>
@@ -365,6 +379,7 @@ RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
     tv.dq = WALK == WALK_CERT ? cert_ray_word(sc, o, d) : 0u;
+    tv.pen = WALK == WALK_CERT ? cert_penalty(sc, tv.inv) : 0.0;
     tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
@@ -410,7 +425,8 @@ struct HotNodes {
 template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
                                WorkCount& wc) {
-    constexpr bool EXACT = WALK != WALK_FAST;  // nothing culled by the closest hit, slots entered in slot order
+    constexpr bool EXACT = WALK == WALK_REFERENCE;  // nothing culled by the closest hit, slots entered in slot order
+    constexpr bool CERT = WALK == WALK_CERT;        // culled only with a certificate (cert_culled), entered when in doubt
     const double tmin = sc.t0, tmax = sc.t1;
     const V3 inv = tv.inv;
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
@@ -474,19 +490,29 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // compare for every complement.
     // (a compile-time choice: the margin as a kernel argument is one more scalar pair alive across the walk, which the
     // traversal kernel answers by re-loading arguments from memory inside its loop -- +27 % kernel time, measured)
-    const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
-    unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
-    unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
-    unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
-    unsigned long long m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
-    if (WALK == WALK_CERT) {
-        // a slot the segment misses is entered all the same when its certificate is in doubt for this ray: only a
-        // triangle of a group record can be (every other slot carries CERT_NEVER), and the walk stands in that record
-        // because the group's gating box was passed -- the reference tests this triangle, so may the walk
-        m0 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.x));
-        m1 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.y));
-        m2 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.z));
-        m3 |= __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.w));
+    unsigned long long m0, m1, m2, m3;
+    if (CERT) {
+        // in doubt: entered if the segment enters the box or the box is a triangle-side one (CERT_TIGHT: only the
+        // tests below can tell); not in doubt: entered if the segment enters the box and the box is not culled
+        // (a ray outside the theorem's premises -- word 0 -- is in doubt everywhere)
+        const unsigned long long out = __builtin_amdgcn_ballot_w64(tv.dq == CERT_RAY_OUTSIDE);
+        const unsigned long long d0 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.x));
+        const unsigned long long d1 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.y));
+        const unsigned long long d2 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.z));
+        const unsigned long long d3 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.w));
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(h2), b3 = __builtin_amdgcn_ballot_w64(h3);
+        const double cull = tv.best_t * TRAV_CULL_MARGIN + tv.pen;
+        m0 = (d0 & (b0 | __builtin_amdgcn_ballot_w64((int)ct.x < 0))) | (~d0 & b0 & __builtin_amdgcn_ballot_w64(!(e0 > cull)));
+        m1 = (d1 & (b1 | __builtin_amdgcn_ballot_w64((int)ct.y < 0))) | (~d1 & b1 & __builtin_amdgcn_ballot_w64(!(e1 > cull)));
+        m2 = (d2 & (b2 | __builtin_amdgcn_ballot_w64((int)ct.z < 0))) | (~d2 & b2 & __builtin_amdgcn_ballot_w64(!(e2 > cull)));
+        m3 = (d3 & (b3 | __builtin_amdgcn_ballot_w64((int)ct.w < 0))) | (~d3 & b3 & __builtin_amdgcn_ballot_w64(!(e3 > cull)));
+    } else {
+        const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
+        m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
+        m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
+        m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
+        m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
     }
 #define RR_LANE_BIT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
     h0 = RR_LANE_BIT(m0), h1 = RR_LANE_BIT(m1), h2 = RR_LANE_BIT(m2), h3 = RR_LANE_BIT(m3);
@@ -532,12 +558,30 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// One leaf reference: its 1..4 primitives in DFS order, then pop.
-template <bool COMPACT, bool COUNT>
+// One leaf reference: its 1..4 primitives in DFS order, then pop.  A REF_SINGLE reference (the certified tree: one
+// triangle behind its own widened box) carries no box of the reference's; BvhTree::intersect gets to the triangle
+// through its gating box (bvh.rs:399), so that box -- SceneDev::gates, one per primitive -- is tested first, with
+// the arithmetic every other box is tested with.
+template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
     const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
-    const uint32_t count = (tv.cur & 3u) + 1u;
+    uint32_t count = (tv.cur & 3u) + 1u;
+    if (WALK == WALK_CERT && (tv.cur >> 30) == REF_SINGLE) {
+        const V3 inv = tv.inv;
+        const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+        double entry;
+        bool pass;
+        if (COMPACT) {
+            const uint4* g = reinterpret_cast<const uint4*>(sc.gates) + (size_t)first * 2;
+            const uint4 a = g[0], b = g[1];
+            pass = slab_f32(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, o, inv, tmin, tmax, entry);
+        } else {
+            const uint4* g = reinterpret_cast<const uint4*>(sc.gates) + (size_t)first * 3;
+            pass = slab_f64(g[0], g[1], g[2], nx, ny, nz, o, inv, tmin, tmax, entry);
+        }
+        count = pass ? 1u : 0u;
+    }
     if (COUNT) wc.leaf_prims = count;
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t p = first + k;
@@ -571,7 +615,7 @@ RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack
         if (trav_at_interior(tv))
             trav_interior_step<COMPACT, COUNT, WALK>(sc, o, stack, hot, tv, wc);
         else
-            trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+            trav_leaf_step<COMPACT, COUNT, WALK>(sc, o, d, stack, tv, wc);
     }
     t_hit = tv.best_t;
     prim_hit = tv.best_prim;

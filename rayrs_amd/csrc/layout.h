@@ -23,9 +23,11 @@ namespace rayrs {
 // child reference: kind << 30 | payload
 constexpr uint32_t REF_INTERIOR = 0u;  // payload = interior record index
 constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1): 1..4 primitives behind the slot's box
-constexpr uint32_t REF_SINGLE = 2u;    // two-child export only: payload = prim << 2, a direct leaf (no box of its own,
-                                       // bvh.rs:297, :302); the gate tree holds it as a one-primitive REF_RANGE behind
-                                       // the box of the Node it hangs under
+constexpr uint32_t REF_SINGLE = 2u;    // payload = prim << 2.  In the two-child export: a direct leaf (no box of its own,
+                                       // bvh.rs:297, :302; the gate tree holds it as a one-primitive REF_RANGE behind
+                                       // the box of the Node it hangs under).  In the certified tree: one primitive of a
+                                       // group record behind its OWN widened box (the only slots a walk may enter
+                                       // without having passed their box: "in doubt", below)
 constexpr uint32_t REF_NONE = 3u;
 
 // primitive tag: kind | axis << 2 | surface << 8
@@ -62,25 +64,26 @@ struct Node4F64 {  // 256 B
     uint32_t pad[8];
 };
 
-// Certificate word of a slot: four signed bytes (nx, ny, nz, bias).  The certified walk (device_path.h
-// trav_interior_step<..., WALK_CERT>) carries the ray's direction as four signed bytes (dx, dy, dz, 127) -- the
-// direction scaled so that its largest component is +-127, each component rounded to nearest -- and takes a slot
-// whose box the ray misses as "entered" all the same when |dx nx + dy ny + dz nz + 127 bias| < CERT_THRESHOLD:
-// the ray may then lie so close to the plane of the slot's triangle that the reference's own test is rounding
-// noise, and only running that test says what the reference answers (scene_host.cpp build_cert_tree has the
-// theorem and the arithmetic behind the threshold).
-//   CERT_NEVER  (0, 0, 0, 127): the sum is 127 * 127 whatever the ray -- a slot whose box test decides by
-//               construction (interior slots, groups behind their exact gating box, unused slots);
-//   CERT_ALWAYS (0, 0, 0, 0): the sum is 0 -- a primitive for which nothing is proved (not a triangle, degenerate,
-//               too thin or too small for the scene): tested whenever its group's gating box is entered, as the
-//               reference does;
-//   otherwise   (nx, ny, nz, 0): the triangle's normal scaled so that its largest component is +-127, rounded.
+// Certificate word of a slot: (ax, ay, az) signed bytes, then w in bits 24..30 and CERT_TIGHT in bit 31.  The
+// certified walk (device_path.h trav_interior_step<..., WALK_CERT>) carries the ray's direction as three signed bytes
+// (dx, dy, dz) -- the direction scaled to length 127, each component rounded to nearest -- and calls the slot IN
+// DOUBT for the ray when |dx ax + dy ay + dz az| < CERT_UNIT * w: the ray may then lie so close to the plane of a
+// triangle below the slot that the reference's own test of it is rounding noise (scene_host.cpp build_cert_tree
+// has the theorem and the arithmetic behind the thresholds).  A slot in doubt is never culled by the closest hit so
+// far, and a CERT_TIGHT slot -- one whose box is built from the triangles' own widened boxes instead of the
+// reference's gating boxes -- is entered when in doubt even if the segment misses its box.
+//   w = 0       never in doubt: nothing below the slot whose computed t can be far off (rectangles only; unused slots);
+//   w = 3       one triangle: (ax, ay, az) is its unit normal times 127, rounded (|cos| below 2.4 %: in doubt);
+//   w = 4..126  several triangles: the axis of a cone around their normals, w grows with the cone's half angle;
+//   w = 127     always in doubt (130 * 127 exceeds every possible sum): spheres, degenerate or needle-thin triangles,
+//               triangles too small for the scene, cones too wide -- nothing is proved about what is below.
 // A ray outside the theorem's premises (origin too far out, direction not finite or of extreme magnitude) carries
-// (0, 0, 0, 127): every triangle slot then reads "in doubt", CERT_NEVER slots still read "never".
-constexpr uint32_t CERT_NEVER = 127u << 24;
-constexpr uint32_t CERT_ALWAYS = 0u;
-constexpr int32_t CERT_THRESHOLD = 512;
-constexpr uint32_t CERT_RAY_OUTSIDE = 127u << 24;
+// (0, 0, 0): every slot with w > 0 is in doubt for it.
+constexpr uint32_t CERT_NEVER = 0u;
+constexpr uint32_t CERT_ALWAYS = 127u << 24;
+constexpr uint32_t CERT_UNIT = 130;      // the threshold per unit of w (7 bits)
+constexpr uint32_t CERT_TIGHT = 1u << 31; // the slot's box is a triangle-side box: a ray in doubt enters it even when the segment misses it
+constexpr uint32_t CERT_RAY_OUTSIDE = 0u;
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
@@ -138,6 +141,8 @@ struct SceneDev {
     // instance of the traversal kernel runs, on which of the scene's three trees `nodes` points to)
     uint32_t walk, pad1;
     double cert_center[3], cert_radius;  // WALK_CERT: the per-ray guard (device_path.h cert_ray_word)
+    double cert_ext;                     // WALK_CERT: largest extent of a certified triangle (device_path.h cert_penalty)
+    const void* gates;  // WALK_CERT: every primitive's gating box: 6 f32 + 2 pad (compact) / 6 f64 (full), by primitive record
 };
 
 struct CameraDev {

@@ -71,12 +71,15 @@ struct FlatScene {
     //         primitives behind their widened boxes, each with a quantised normal, so that "box missed" is only
     //         taken for "the reference rejects" where that is a theorem (scene_host.cpp build_cert_tree) -- the default.
     WalkTree walk, gate, cert;
+    std::vector<double> prim_gate;      // n_prims * 6: every primitive's gating box (the certified walk tests it before a single triangle)
     double cert_center[3] = {0, 0, 0};  // rays whose origin lies farther than cert_radius (max norm) from here are
     double cert_radius = 0;             // outside the theorem's premises: every certificate reads "in doubt" for them
+    double cert_ext = 0;                // the largest extent (along an axis) of a triangle that carries a certificate
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)
     std::vector<uint8_t> prim_bytes;
+    std::vector<uint8_t> gate_bytes;  // per primitive record: its gating box, 6 f32 + 2 pad (compact) / 6 f64
     std::vector<float> hdri_quads;  // 16 floats per texel: the 2x2 footprint of a lookup at (i, j), RGBA each
     uint32_t hdri_w = 0, hdri_h = 0;
     double t0 = 0, t1 = 0;
@@ -84,6 +87,8 @@ struct FlatScene {
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }
 };
+
+extern uint32_t g_cert_tight_max_w, g_cert_whole_groups;  // development knobs of build_cert_tree (rayrs_lab.h rayrs_lab_build)
 
 // Scene::new (lib.rs:227-245) minus the upload.  Returns RAYRS_* status.
 int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int heuristic, uint32_t splits,

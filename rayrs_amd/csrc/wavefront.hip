@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // none is on an interior record).
 
 template <bool COMPACT, bool COUNT, int WALK>
-__global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+__global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     uint32_t slot = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     Trav tv;
-    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0, tv.dq = 0;
+    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0, tv.dq = 0, tv.pen = 0;
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                trav_leaf_step<COMPACT, COUNT, WALK>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -901,17 +901,21 @@ static hipError_t trav_set_lds(uint32_t lds) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+hipError_t wf_trav_occupancy(bool compact, int walk, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
     const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_CERT>, 256, lds);
+        if (walk == WALK_CERT) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_CERT>, 256, lds);
+        if (walk == WALK_REFERENCE) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_REFERENCE>, 256, lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_FAST>, 256, lds);
     }
     if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
     if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_CERT>, 256, lds);
+    if (walk == WALK_CERT) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_CERT>, 256, lds);
+    if (walk == WALK_REFERENCE) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_REFERENCE>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_FAST>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,

@@ -7,6 +7,8 @@ import numpy as np
 import rayrs_amd, _oracle
 from rayrs_amd import scenes, procedural, _ffi
 hdri = procedural.make_hdri(64, 32)
+if os.environ.get("BUILD"):
+    _ffi.lib().rayrs_lab_build(*[int(x) for x in os.environ["BUILD"].split(",")])
 for level in (3, 5):
     cam_args, objs, heur = scenes.mesh_scene(level, area_light=True)
     cam_args = scenes.camera_for_resolution(cam_args, 96, 64)

@@ -14,6 +14,9 @@ cam_args, objs, heur, _, mb = scenes.config(cfg)
 if os.environ.get("CAMERA") == "close":
     cam_args = scenes.MESH_CLOSE_CAM
 cam_args = scenes.camera_for_resolution(cam_args, res, res)
+if os.environ.get("BUILD"):  # "w,whole": rayrs_lab.h rayrs_lab_build
+    from rayrs_amd import _ffi
+    _ffi.lib().rayrs_lab_build(*[int(x) for x in os.environ["BUILD"].split(",")])
 scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, procedural.make_hdri(1024, 512), device=0)
 print({k: v for k, v in scene.info().items() if "n_wide" in k or "depth" in k or k == "build_seconds"}, flush=True)
 cam = rayrs_amd.Camera(*cam_args)
@@ -22,6 +25,8 @@ rayrs_amd.render(scene, cam, 4, mb)
 ref = None
 WALKS = [("certified", dict(), "certified"), ("reference", dict(), "reference"), ("fast", dict(), "fast"),
          ("fast on the gate tree", dict(gate_tree=1), "fast")]
+if os.environ.get("ONLY"):
+    WALKS = [w for w in WALKS if w[0] in os.environ["ONLY"].split(",")]
 for name, lab, walk in WALKS + WALKS[::-1]:
     scene.lab_set(**dict(extra, **lab))
     img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, walk=walk)
