@@ -155,10 +155,9 @@ typedef struct {
     uint32_t cert_n_wide;   /* the same three for the certified tree (rayrs_scene_export_cert_tree), which */
     uint32_t cert_root_ref; /* RAYRS_WALK_CERTIFIED, the default, walks */
     uint32_t cert_depth;
-    uint32_t pad0;
+    uint32_t n_filtered;    /* group members that carry a certificate (0: the certified walk is the reference walk) */
     double cert_center[3];  /* rays whose origin lies within cert_radius (max norm) of cert_center are inside the */
-    double cert_radius;     /* certified walk's theorem; for the others every certificate reads "in doubt" */
-    double cert_ext;        /* largest extent along an axis of a triangle that carries a certificate (the walk's culling margin) */
+    double cert_radius;     /* certified walk's theorem; the others are in doubt for every member */
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -189,16 +188,14 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
  * tests/test_bvh_builder.py checks all of this from the exports alone. */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
-/*   rayrs_scene_export_cert_tree (n = cert_n_wide), what the default walk reads: the gate tree's records, in which
- * every group of three or four primitives is opened into a record of its own (the group's slot keeps its exact
- * gating box and becomes kind 0): its slots are the group's primitives one by one (kind 1, count 1), each behind
- * its own bounding box widened by 1/64 of its largest extent and rounded outwards to f32 (not clipped), with one
- * certificate word per slot in wide_cert (n*4 u32; four signed bytes nx, ny, nz, bias): a triangle's normal
- * scaled to largest component +-127, or (0,0,0,127) "the box test decides" for every other kind of slot, or 0
- * "always test" for a primitive nothing is proved about.  rayrs_amd/csrc/scene_host.cpp build_cert_tree states
- * the theorem; tests/test_bvh_builder.py re-derives every word and box from the objects. */
-int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* wide_cert,
-                                 double* prim_gate /* n_prims * 6: every primitive's gating box */);
+/*   rayrs_scene_export_cert_tree (n = cert_n_wide = gate_n_wide), what the default walk reads: the gate tree's
+ * records once more, a group some of whose members carry a certificate marked kind 2 instead of 1 (payload
+ * unchanged), and per primitive record (n_prims of them, depth-first order) its certificate word member_cert: 0 =
+ * none (tested whenever the group is entered), else bit 31 | the triangle's unit normal times 127 as three signed
+ * bytes.  A member gets a certificate when it is a sane triangle (rayrs_amd/csrc/scene_host.cpp build_cert_tree,
+ * which states the theorem) whose bounding box, widened by 1/64 of its largest extent, has less than an eighth of
+ * its gating box's area.  tests/test_bvh_builder.py re-derives every word from the objects. */
+int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* member_cert);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -241,15 +238,16 @@ typedef struct {
      * return its closest hit (smallest accepted t, first primitive in depth-first order on ties, bvh.rs:62), they
      * differ in what that claim rests on:
      * RAYRS_WALK_CERTIFIED (0, the default): the reference's leaf groups behind exactly their gating boxes, nothing
-     *   culled by the closest hit; inside an entered group of three or four, a primitive is tested iff the ray enters
-     *   its own bounding box widened by 1/64 of its size OR the ray lies within about 2 % (cosine) of the triangle's
-     *   plane.  For every other ray "the widened box is missed" implies "the reference's own Moeller-Trumbore rejects
-     *   it" by a forward error bound (rayrs_amd/csrc/scene_host.cpp build_cert_tree): the reference's answer for
-     *   EVERY ray, by theorem.  Rays from farther than 4 half extents of the scene's bounding box from its centre,
-     *   or with non-finite / extreme directions, are outside the theorem and test every primitive of an entered group.
-     * RAYRS_WALK_REFERENCE (1): the same groups and boxes, every primitive of an entered group tested: the
-     *   reference's visit set BY CONSTRUCTION, no theorem involved (rayrs_scene_export_gate_tree).  The local-pool
-     *   route always walks this way.  Cost on the headline frame: profiles/r05_walks.txt.
+     *   culled by the closest hit, every member of an entered group tested -- except a member far smaller than its
+     *   gating box (a mesh triangle that shares a bottom Node with the 50 x 50 floor) whose own bounding box, widened by
+     *   1/64 of its size, the ray misses while lying more than about 2 % (cosine) off the triangle's plane: for such a
+     *   ray "the widened box is missed" implies "the reference's own Moeller-Trumbore rejects it" by a forward error
+     *   bound (rayrs_amd/csrc/scene_host.cpp build_cert_tree; rayrs_scene_export_cert_tree): the reference's answer
+     *   for EVERY ray, by construction plus that theorem.  Rays from farther than 4 half extents of the scene's bounding
+     *   box from its centre, or with non-finite / extreme directions, are outside the theorem and test every member.
+     * RAYRS_WALK_REFERENCE (1): the same with every member of an entered group tested: the reference's visit set BY
+     *   CONSTRUCTION, no theorem involved (rayrs_scene_export_gate_tree).  The local-pool route always walks this
+     *   way.  Cost on the headline frame: profiles/r05_walks.txt.
      * RAYRS_WALK_FAST (2): two bets on the reference's arithmetic, each measured, neither proved (rounds 2-4's
      *   default): closest-hit culling -- a box entered beyond best_t * (1 + 2^-10) is skipped -- and single
      *   primitives behind their own widened boxes CLIPPED to the gating box in one tree of their own

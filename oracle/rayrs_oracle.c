@@ -863,9 +863,8 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
-    uint32_t* wide_cert; /* n_wide * 4 certificate words (orc_set_wide_cert), or NULL */
-    double* prim_gate;   /* n_prims * 6: every primitive's gating box, as the product exports it */
-    double cert_center[3], cert_radius, cert_ext;
+    uint32_t* member_cert; /* n_prims: the product's certificate words (orc_set_member_certs), or NULL */
+    double cert_center[3], cert_radius;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -882,8 +881,7 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->prim_object);
     free(s->wide_box);
     free(s->wide_ref);
-    free(s->wide_cert);
-    free(s->prim_gate);
+    free(s->member_cert);
     free(s);
 }
 
@@ -1316,27 +1314,23 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
-    free(s->wide_cert);
-    s->wide_cert = NULL;
+    free(s->member_cert);
+    s->member_cert = NULL;
     return 0;
 }
 
-/* The product's certified tree (rayrs_scene_export_cert_tree) carries one certificate word per slot; handing
- * them over after orc_set_wide makes traversal 2 the product's CERTIFIED walk (rayrs_amd/csrc/device_path.h
- * trav_interior_step<..., WALK_CERT>, restated in isect_wide below): nothing culled, and a slot whose box
- * the segment misses entered all the same when its certificate reads "in doubt" for the ray. */
-int orc_set_wide_cert(orc_scene* s, const uint32_t* cert, const double* prim_gate, const double center[3], double radius,
-                      double ext) {
-    if (!s || !s->have_wide || !cert || !prim_gate) return -1;
-    free(s->wide_cert);
-    free(s->prim_gate);
-    s->prim_gate = (double*)malloc(((size_t)s->finfo.n_prims * 6 + 1) * sizeof(double));
-    memcpy(s->prim_gate, prim_gate, (size_t)s->finfo.n_prims * 6 * sizeof(double));
-    s->wide_cert = (uint32_t*)malloc(((size_t)s->finfo.n_wide * 4 + 1) * sizeof(uint32_t));
-    memcpy(s->wide_cert, cert, (size_t)s->finfo.n_wide * 4 * sizeof(uint32_t));
+/* The product's certified tree (rayrs_scene_export_cert_tree) is its gate tree with some groups marked kind 2
+ * ("filtered") plus one certificate word per primitive; handing the words over after orc_set_wide makes traversal 2
+ * the product's CERTIFIED walk (rayrs_amd/csrc/device_path.h trav_leaf_step<..., WALK_CERT>, restated in isect_wide
+ * below): nothing culled, and a member of a filtered group that carries a certificate skipped when the segment
+ * misses its bounding box widened by 1/64 of its largest extent and the ray is not in doubt for it. */
+int orc_set_member_certs(orc_scene* s, const uint32_t* member_cert, const double center[3], double radius) {
+    if (!s || !s->have_wide || !member_cert) return -1;
+    free(s->member_cert);
+    s->member_cert = (uint32_t*)malloc(((size_t)s->finfo.n_prims + 1) * sizeof(uint32_t));
+    memcpy(s->member_cert, member_cert, (size_t)s->finfo.n_prims * sizeof(uint32_t));
     for (int k = 0; k < 3; k++) s->cert_center[k] = center[k];
     s->cert_radius = radius;
-    s->cert_ext = ext;
     return 0;
 }
 
@@ -1587,21 +1581,12 @@ static uint32_t cert_ray_word(const orc_scene* s, ray_t ray) {
     }
     return w;
 }
-/* in doubt: |dx ax + dy ay + dz az| < 130 w, w = bits 24..30 (layout.h) */
-static int cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
+/* in doubt: |dx nx + dy ny + dz nz| < 320 (layout.h CERT_THRESHOLD); a ray outside the premises (word 0) always is */
+static int cert_in_doubt(uint32_t ray_word, uint32_t member_word) {
     int sum = 0;
-    for (int k = 0; k < 3; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(slot_word >> (8 * k));
+    for (int k = 0; k < 3; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(member_word >> (8 * k));
     if (sum < 0) sum = -sum;
-    return (uint32_t)sum < ((slot_word >> 24) & 127u) * 130u;
-}
-/* A slot that is not in doubt is culled when its box is entered beyond the closest hit so far -- by the usual
- * relative margin and by 2^-8 of the largest extent of a certified triangle, taken along the ray's slowest axis
- * (device_path.h cert_penalty and trav_interior_step<..., WALK_CERT>: the same expressions). */
-static double cert_penalty(const orc_scene* s, v3 inv) {
-    double im = rr_fabs(inv.x);
-    if (rr_fabs(inv.y) > im) im = rr_fabs(inv.y);
-    if (rr_fabs(inv.z) > im) im = rr_fabs(inv.z);
-    return s->cert_ext * (0x1p-8 * im);
+    return sum < 320;
 }
 
 /* Diagnostics: when set, isect_wide adds one to hist[record] per visit and to
@@ -1630,9 +1615,8 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
     int sp = 0;
     uint32_t cur = s->finfo.wide_root_ref;
-    const int certified = s->wide_cert != NULL; /* the certified walk: no culling, certificates consulted */
+    const int certified = s->member_cert != NULL; /* the certified walk: nothing culled, member filters consulted */
     const uint32_t ray_word = certified ? cert_ray_word(s, ray) : 0u;
-    const double pen = certified ? cert_penalty(s, inv) : 0.0;
     for (;;) {
         if ((cur >> 30) == REF_KIND_INTERIOR) {
             uint32_t rec = cur & 0x3fffffffu;
@@ -1649,17 +1633,8 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                 hit[c] = 0;
                 ent[c] = 0.0;
                 if (certified) {
-                    if (kind != REF_KIND_NONE) {
-                        const double* bx = s->wide_box + ((size_t)rec * 4 + c) * 6;
-                        /* (a ray outside the theorem's premises -- word 0 -- is in doubt everywhere) */
-                        const int doubt = ray_word == 0u || cert_in_doubt(ray_word, s->wide_cert[(size_t)rec * 4 + c]);
-                        hit[c] = aabb_intersect_entry(bx, ray, inv, tmin, tmax, &ent[c]);
-                        if (hit[c]) {
-                            if (!doubt && ent[c] > best_t * (1.0 + 0x1p-10) + pen) hit[c] = 0;
-                        } else if (doubt && (s->wide_cert[(size_t)rec * 4 + c] >> 31)) {
-                            hit[c] = 1; /* a triangle-side box missed, the ray near a plane below: only the tests themselves know */
-                        }
-                    }
+                    if (kind != REF_KIND_NONE)
+                        hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
                 } else if (kind == REF_KIND_SINGLE) {
                     hit[c] = 1;
                     ent[c] = tmin;
@@ -1688,16 +1663,32 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
             }
         } else {
             uint32_t first = (cur & 0x3fffffffu) >> 2;
-            uint32_t count = (cur >> 30) == REF_KIND_SINGLE ? 1u : (cur & 3u) + 1u;
-            if (certified && (cur >> 30) == REF_KIND_SINGLE) {
-                /* a single triangle of the certified tree: the reference only gets to it through its gating box (bvh.rs:399) */
-                double e_unused;
-                if (!aabb_intersect_entry(s->prim_gate + (size_t)first * 6, ray, inv, tmin, tmax, &e_unused)) count = 0;
-            }
+            uint32_t count = (cur & 3u) + 1u;
+            const int filtered = certified && (cur >> 30) == 2u; /* REF_FILTERED */
             for (uint32_t k = 0; k < count; k++) {
                 uint32_t p = first + k;
                 int obj = (int)s->prim_object[p];
                 const shape_t* g = &s->objs[obj].geom;
+                if (filtered && g->kind == ORC_SHAPE_TRIANGLE && (s->member_cert[p] >> 31) &&
+                    !cert_in_doubt(ray_word, s->member_cert[p])) {
+                    /* the member's bounding box widened by 2^-6 of its largest extent (device_path.h member_box_missed) */
+                    const double c[3][3] = {{g->p1.x, g->p2.x, g->p3.x}, {g->p1.y, g->p2.y, g->p3.y}, {g->p1.z, g->p2.z, g->p3.z}};
+                    double lo[3], hi[3], bx[6], e_unused;
+                    for (int a = 0; a < 3; a++) {
+                        double l = c[a][0], h = c[a][0];
+                        if (c[a][1] < l) l = c[a][1];
+                        if (c[a][2] < l) l = c[a][2];
+                        if (c[a][1] > h) h = c[a][1];
+                        if (c[a][2] > h) h = c[a][2];
+                        lo[a] = l, hi[a] = h;
+                    }
+                    double ext = hi[0] - lo[0];
+                    if (hi[1] - lo[1] > ext) ext = hi[1] - lo[1];
+                    if (hi[2] - lo[2] > ext) ext = hi[2] - lo[2];
+                    const double m = ext * 0x1p-6;
+                    for (int a = 0; a < 3; a++) bx[2 * a] = lo[a] - m, bx[2 * a + 1] = hi[a] + m;
+                    if (!aabb_intersect_entry(bx, ray, inv, tmin, tmax, &e_unused)) continue; /* the reference rejects it: theorem */
+                }
                 if (cnt) {
                     if (g->kind == ORC_SHAPE_TRIANGLE) cnt->tri_tests++;
                     else if (g->kind == ORC_SHAPE_SPHERE) cnt->sphere_tests++;

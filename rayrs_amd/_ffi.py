@@ -53,8 +53,8 @@ class SceneInfo(C.Structure):
                 ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
                 ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32), ("gate_n_wide", C.c_uint32),
                 ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32), ("cert_n_wide", C.c_uint32),
-                ("cert_root_ref", C.c_uint32), ("cert_depth", C.c_uint32), ("pad0", C.c_uint32),
-                ("cert_center", C.c_double * 3), ("cert_radius", C.c_double), ("cert_ext", C.c_double)]
+                ("cert_root_ref", C.c_uint32), ("cert_depth", C.c_uint32), ("n_filtered", C.c_uint32),
+                ("cert_center", C.c_double * 3), ("cert_radius", C.c_double)]
 
 
 class RenderParams(C.Structure):
@@ -135,14 +135,12 @@ def lib():
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
     L.rayrs_scene_export_gate_tree.argtypes = [vp, vp, vp]
-    L.rayrs_scene_export_cert_tree.argtypes = [vp, vp, vp, vp, vp]
+    L.rayrs_scene_export_cert_tree.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     L.rayrs_lab_set.argtypes = [vp, C.POINTER(LabTuning)]  # private: rayrs_amd/csrc/rayrs_lab.h
     L.rayrs_lab_set.restype = C.c_int
-    L.rayrs_lab_build.argtypes = [C.c_uint32, C.c_uint32]
-    L.rayrs_lab_build.restype = None
     L.rayrs_frame_sample_chunk.argtypes = [C.c_uint32] * 4
     L.rayrs_frame_sample_chunk.restype = C.c_uint32
     L.rayrs_abi_layout.argtypes = [vp, C.c_uint32]

@@ -325,7 +325,7 @@ class Scene:
     def info(self) -> dict:
         i = _ffi.SceneInfo()
         _ffi.check(self._L.rayrs_scene_info(self._h, C.byref(i)), "rayrs_scene_info")
-        d = {n: getattr(i, n) for n, _ in i._fields_ if n not in ("root_box", "cert_center", "pad0")}
+        d = {n: getattr(i, n) for n, _ in i._fields_ if n not in ("root_box", "cert_center")}
         d["root_box"] = list(i.root_box)
         d["cert_center"] = list(i.cert_center)
         return d
@@ -359,17 +359,16 @@ class Scene:
         return box[:i["gate_n_wide"]], ref[:i["gate_n_wide"]]
 
     def export_cert_tree(self):
-        """The records the default (certified) walk reads: (box[cert_n_wide,4,6], ref[cert_n_wide,4],
-        cert[cert_n_wide,4], prim_gate[n_prims,6]) -- one certificate word per slot, and every primitive's gating box."""
+        """What the default (certified) walk reads: (box[cert_n_wide,4,6], ref[cert_n_wide,4], member_cert[n_prims])
+        -- the gate tree's records with the filtered groups marked kind 2, and every primitive's certificate word."""
         i = self.info()
         n = i["cert_n_wide"]
         box = np.zeros((max(n, 1), 4, 6), dtype=np.float64)
         ref = np.zeros((max(n, 1), 4), dtype=np.uint32)
-        cert = np.zeros((max(n, 1), 4), dtype=np.uint32)
-        gate = np.zeros((max(i["n_prims"], 1), 6), dtype=np.float64)
-        _ffi.check(self._L.rayrs_scene_export_cert_tree(self._h, box.ctypes.data, ref.ctypes.data, cert.ctypes.data,
-                                                        gate.ctypes.data), "rayrs_scene_export_cert_tree")
-        return box[:n], ref[:n], cert[:n], gate[:i["n_prims"]]
+        mcert = np.zeros(max(i["n_prims"], 1), dtype=np.uint32)
+        _ffi.check(self._L.rayrs_scene_export_cert_tree(self._h, box.ctypes.data, ref.ctypes.data, mcert.ctypes.data),
+                   "rayrs_scene_export_cert_tree")
+        return box[:n], ref[:n], mcert[:i["n_prims"]]
 
     def close(self):
         if self._h is not None:

@@ -196,7 +196,6 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     for (auto& w : s->trav)
         if (w.d_nodes) (void)hipFree(w.d_nodes);
     if (s->d_prims) (void)hipFree(s->d_prims);
-    if (s->d_gates) (void)hipFree(s->d_gates);
     if (s->d_surfaces) (void)hipFree(s->d_surfaces);
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -302,8 +301,6 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     }
     HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
     HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&s->d_gates, f.gate_bytes.size()));
-    HIP_TRY(hipMemcpy(s->d_gates, f.gate_bytes.data(), f.gate_bytes.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
     HIP_TRY(hipMemcpy(s->d_surfaces, s->surfaces.data(), s->surfaces.size() * sizeof(SurfaceDev),
                       hipMemcpyHostToDevice));
@@ -311,7 +308,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.cert.node_bytes.size() + f.prim_bytes.size() + f.gate_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.cert.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -389,7 +386,7 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->cert_depth = f.cert.depth;
     for (int i = 0; i < 3; i++) info->cert_center[i] = f.cert_center[i];
     info->cert_radius = f.cert_radius;
-    info->cert_ext = f.cert_ext;
+    info->n_filtered = f.n_filtered;
     info->local_pool = (scene->local_ok && scene->tuning.local_pool != 1u) ? 1u : 0u;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
@@ -424,14 +421,12 @@ int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uin
     return RAYRS_OK;
 }
 
-int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* wide_cert,
-                                 double* prim_gate) {
+int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* member_cert) {
     if (!scene) return RAYRS_INVALID_ARG;
     const WalkTree& t = scene->flat.cert;
     if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
     if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
-    if (wide_cert && !t.cert.empty()) std::memcpy(wide_cert, t.cert.data(), t.cert.size() * 4);
-    if (prim_gate && !scene->flat.prim_gate.empty()) std::memcpy(prim_gate, scene->flat.prim_gate.data(), scene->flat.prim_gate.size() * 8);
+    if (member_cert && scene->flat.n_prims()) std::memcpy(member_cert, scene->flat.member_cert.data(), (size_t)scene->flat.n_prims() * 4);
     return RAYRS_OK;
 }
 
@@ -510,11 +505,6 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
     return (int)pl.timed_rounds;
 }
 
-void rayrs_lab_build(uint32_t cert_tight_max_w, uint32_t cert_whole_groups) {
-    rayrs::g_cert_tight_max_w = cert_tight_max_w;
-    rayrs::g_cert_whole_groups = cert_whole_groups;
-}
-
 // rayrs_lab.h: the kernels' development knobs (tests/ and scripts/ubench/ only)
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
@@ -553,7 +543,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_camera, origin), RAYRS_FIELD(rayrs_camera, e_x), RAYRS_FIELD(rayrs_camera, e_y);
     RAYRS_FIELD(rayrs_camera, z), RAYRS_FIELD(rayrs_camera, width), RAYRS_FIELD(rayrs_camera, height);
     RAYRS_FIELD(rayrs_camera, ppc), RAYRS_FIELD(rayrs_camera, x_pixels), RAYRS_FIELD(rayrs_camera, y_pixels);
-    RAYRS_STRUCT(rayrs_scene_info_t, 26);
+    RAYRS_STRUCT(rayrs_scene_info_t, 25);
     RAYRS_FIELD(rayrs_scene_info_t, n_objects), RAYRS_FIELD(rayrs_scene_info_t, n_interior);
     RAYRS_FIELD(rayrs_scene_info_t, n_prims), RAYRS_FIELD(rayrs_scene_info_t, root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, depth), RAYRS_FIELD(rayrs_scene_info_t, compact);
@@ -565,8 +555,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, gate_n_wide), RAYRS_FIELD(rayrs_scene_info_t, gate_root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, gate_depth);
     RAYRS_FIELD(rayrs_scene_info_t, cert_n_wide), RAYRS_FIELD(rayrs_scene_info_t, cert_root_ref);
-    RAYRS_FIELD(rayrs_scene_info_t, cert_depth), RAYRS_FIELD(rayrs_scene_info_t, pad0), RAYRS_FIELD(rayrs_scene_info_t, cert_center);
-    RAYRS_FIELD(rayrs_scene_info_t, cert_radius), RAYRS_FIELD(rayrs_scene_info_t, cert_ext);
+    RAYRS_FIELD(rayrs_scene_info_t, cert_depth), RAYRS_FIELD(rayrs_scene_info_t, n_filtered), RAYRS_FIELD(rayrs_scene_info_t, cert_center);
+    RAYRS_FIELD(rayrs_scene_info_t, cert_radius);
     RAYRS_STRUCT(rayrs_render_params, 9);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
@@ -619,7 +609,7 @@ static SceneDev make_scene_dev(const rayrs_scene* s, uint32_t walk) {
     const rayrs_scene::Walk& w = s->trav[x];
     sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
-    sc.gates = s->d_gates;
+    sc.n_filtered = s->flat.n_filtered;
     sc.surfaces = s->d_surfaces;
     sc.hdri = s->d_hdri;
     sc.hdri_w = s->flat.hdri_w;
@@ -637,7 +627,6 @@ static SceneDev make_scene_dev(const rayrs_scene* s, uint32_t walk) {
     sc.walk = walk == RAYRS_WALK_CERTIFIED ? (uint32_t)WALK_CERT : walk == RAYRS_WALK_REFERENCE ? (uint32_t)WALK_REFERENCE : (uint32_t)WALK_FAST;
     for (int i = 0; i < 3; i++) sc.cert_center[i] = s->flat.cert_center[i];
     sc.cert_radius = s->flat.cert_radius;
-    sc.cert_ext = s->flat.cert_ext;
     return sc;
 }
 

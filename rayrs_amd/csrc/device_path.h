@@ -317,8 +317,7 @@ struct Trav {
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
     int sp;
-    uint32_t dq;         // WALK_CERT: the ray's direction as four signed bytes (cert_ray_word)
-    double pen;          // WALK_CERT: cert_penalty
+    uint32_t dq;         // WALK_CERT: the ray's direction as three signed bytes (cert_ray_word)
 };
 
 // What BvhTree::intersect does first (bvh.rs:394): the box of the root Node.  A ray that misses it
@@ -332,12 +331,12 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// The ray as the certified walk's certificates see it (layout.h): (dx, dy, dz), the direction scaled to length
-// 127 and rounded to nearest even, or (0, 0, 0) for a ray outside the theorem's premises -- origin farther than
+// The ray as the certified walk's certificates see it (layout.h MemberFilter): (dx, dy, dz), the direction scaled to
+// length 127 and rounded to nearest even, or (0, 0, 0) for a ray outside the theorem's premises -- origin farther than
 // cert_radius (max norm) from cert_center, a component of the direction that is not finite or beyond 2^400, or a
-// largest component below 2^-400 -- for which every slot that can be in doubt then is.  The CPU checker restates
-// the same arithmetic (a dot product, an IEEE square root and division, three products, round to nearest even), so
-// both sides see the same word.
+// largest component below 2^-400 -- which is then in doubt for every member.  The CPU checker restates the same
+// arithmetic (a dot product, an IEEE square root and division, three products, round to nearest even), so both
+// sides see the same word.
 RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
     const double ax = rr_fabs(d.x), ay = rr_fabs(d.y), az = rr_fabs(d.z);
     double m = ax;
@@ -352,24 +351,11 @@ RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
     return inside ? w : CERT_RAY_OUTSIDE;
 }
 
-// |dx ax + dy ay + dz az| < CERT_UNIT w: one v_dot4_i32_i8 (the ray word's fourth byte is zero), its absolute value,
-// w (bits 24..30) * CERT_UNIT and a compare.
-RR_DEV bool cert_in_doubt(uint32_t ray_word, uint32_t slot_word) {
-    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)slot_word, 0, false);
-    const uint32_t mag = (uint32_t)(sum < 0 ? -sum : sum);
-    return mag < ((slot_word >> 24) & 127u) * CERT_UNIT;
-}
-
-// The certified walk's closest-hit culling (scene_host.cpp build_cert_tree (6)): a slot that is not in doubt is
-// skipped when its box is entered beyond the closest hit so far by the usual relative margin AND by 2^-8 of the largest
-// extent of any certified triangle of the scene, taken along the ray's slowest axis -- a hit accepted below the slot
-// lies within 2^-9 of its triangle's extent of the slot's box, which moves its parameter by no more than that.  The
-// ray's share of that, cert_ext * 2^-8 * max |1 / d_k|, is computed once per ray (Trav::pen).
-RR_DEV double cert_penalty(const SceneDev& sc, V3 inv) {
-    double im = rr_fabs(inv.x);
-    if (rr_fabs(inv.y) > im) im = rr_fabs(inv.y);
-    if (rr_fabs(inv.z) > im) im = rr_fabs(inv.z);
-    return sc.cert_ext * (0x1p-8 * im);
+// |dx nx + dy ny + dz nz| < CERT_THRESHOLD: one v_dot4_i32_i8 (the ray word's fourth byte is zero) with the threshold
+// folded into its accumulator, and one unsigned compare.
+RR_DEV bool cert_in_doubt(uint32_t ray_word, uint32_t member_word) {
+    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)member_word, CERT_THRESHOLD - 1, false);
+    return (uint32_t)sum < (uint32_t)(2 * CERT_THRESHOLD - 1);
 }
 
 template <int WALK = WALK_FAST>
@@ -378,8 +364,7 @@ RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
-    tv.dq = WALK == WALK_CERT ? cert_ray_word(sc, o, d) : 0u;
-    tv.pen = WALK == WALK_CERT ? cert_penalty(sc, tv.inv) : 0.0;
+    tv.dq = (WALK == WALK_CERT && sc.n_filtered != 0u) ? cert_ray_word(sc, o, d) : 0u;  // (a scalar branch)
     tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
@@ -425,8 +410,7 @@ struct HotNodes {
 template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
                                WorkCount& wc) {
-    constexpr bool EXACT = WALK == WALK_REFERENCE;  // nothing culled by the closest hit, slots entered in slot order
-    constexpr bool CERT = WALK == WALK_CERT;        // culled only with a certificate (cert_culled), entered when in doubt
+    constexpr bool EXACT = WALK != WALK_FAST;  // nothing culled by the closest hit, slots entered in slot order
     const double tmin = sc.t0, tmax = sc.t1;
     const V3 inv = tv.inv;
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
@@ -435,17 +419,14 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     double e0, e1, e2, e3;
     bool h0, h1, h2, h3;
     uint32_t r0, r1, r2, r3;
-    uint4 ct = make_uint4(0u, 0u, 0u, 0u);  // WALK_CERT: the slots' certificate words (the record's last granule)
     if (COMPACT) {
         uint4 a, b, c, d, f, g, r;
         if (rec < hot.count) {
             const uint4* src = hot.lds + rec * HotNodes::stride<true>();
             a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
-            if (WALK == WALK_CERT) ct = src[7];
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
             a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
-            if (WALK == WALK_CERT) ct = src[7];
         }
         r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
         // slot k = dwords 6k .. 6k+5 (xmin xmax ymin ymax zmin zmax)
@@ -462,7 +443,6 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
         uint4 x, y, z, r;
         if (in_lds) x = lsrc[0], y = lsrc[1], z = lsrc[2], r = lsrc[12];
         else x = gsrc[0], y = gsrc[1], z = gsrc[2], r = gsrc[12];
-        if (WALK == WALK_CERT) ct = in_lds ? lsrc[13] : gsrc[13];
         r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
         h0 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e0);
         if (in_lds) x = lsrc[3], y = lsrc[4], z = lsrc[5];
@@ -490,30 +470,11 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     // compare for every complement.
     // (a compile-time choice: the margin as a kernel argument is one more scalar pair alive across the walk, which the
     // traversal kernel answers by re-loading arguments from memory inside its loop -- +27 % kernel time, measured)
-    unsigned long long m0, m1, m2, m3;
-    if (CERT) {
-        // in doubt: entered if the segment enters the box or the box is a triangle-side one (CERT_TIGHT: only the
-        // tests below can tell); not in doubt: entered if the segment enters the box and the box is not culled
-        // (a ray outside the theorem's premises -- word 0 -- is in doubt everywhere)
-        const unsigned long long out = __builtin_amdgcn_ballot_w64(tv.dq == CERT_RAY_OUTSIDE);
-        const unsigned long long d0 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.x));
-        const unsigned long long d1 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.y));
-        const unsigned long long d2 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.z));
-        const unsigned long long d3 = out | __builtin_amdgcn_ballot_w64(cert_in_doubt(tv.dq, ct.w));
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
-        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(h2), b3 = __builtin_amdgcn_ballot_w64(h3);
-        const double cull = tv.best_t * TRAV_CULL_MARGIN + tv.pen;
-        m0 = (d0 & (b0 | __builtin_amdgcn_ballot_w64((int)ct.x < 0))) | (~d0 & b0 & __builtin_amdgcn_ballot_w64(!(e0 > cull)));
-        m1 = (d1 & (b1 | __builtin_amdgcn_ballot_w64((int)ct.y < 0))) | (~d1 & b1 & __builtin_amdgcn_ballot_w64(!(e1 > cull)));
-        m2 = (d2 & (b2 | __builtin_amdgcn_ballot_w64((int)ct.z < 0))) | (~d2 & b2 & __builtin_amdgcn_ballot_w64(!(e2 > cull)));
-        m3 = (d3 & (b3 | __builtin_amdgcn_ballot_w64((int)ct.w < 0))) | (~d3 & b3 & __builtin_amdgcn_ballot_w64(!(e3 > cull)));
-    } else {
-        const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
-        m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
-        m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
-        m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
-        m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
-    }
+    const double cull = EXACT ? (double)__builtin_inf() : tv.best_t * TRAV_CULL_MARGIN;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0) & __builtin_amdgcn_ballot_w64(!(e0 > cull));
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1) & __builtin_amdgcn_ballot_w64(!(e1 > cull));
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2) & __builtin_amdgcn_ballot_w64(!(e2 > cull));
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(h3) & __builtin_amdgcn_ballot_w64(!(e3 > cull));
 #define RR_LANE_BIT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
     h0 = RR_LANE_BIT(m0), h1 = RR_LANE_BIT(m1), h2 = RR_LANE_BIT(m2), h3 = RR_LANE_BIT(m3);
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
@@ -558,34 +519,50 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// One leaf reference: its 1..4 primitives in DFS order, then pop.  A REF_SINGLE reference (the certified tree: one
-// triangle behind its own widened box) carries no box of the reference's; BvhTree::intersect gets to the triangle
-// through its gating box (bvh.rs:399), so that box -- SceneDev::gates, one per primitive -- is tested first, with
-// the arithmetic every other box is tested with.
+// Does the segment miss the triangle's bounding box widened by CERT_BOX_MARGIN of its largest extent on every side?
+// (f64 throughout, round to nearest: the theorem has 7/8 of the margin to spare; the CPU checker computes the same.)
+template <bool COMPACT>
+RR_DEV bool member_box_missed(const PrimRec<COMPACT>& r, V3 o, V3 inv, double tmin, double tmax) {
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double c1 = r.tri_coord(a), c2 = r.tri_coord(3 + a), c3 = r.tri_coord(6 + a);
+        double l = c1, h = c1;
+        if (c2 < l) l = c2;
+        if (c3 < l) l = c3;
+        if (c2 > h) h = c2;
+        if (c3 > h) h = c3;
+        lo[a] = l, hi[a] = h;
+    }
+    double ext = hi[0] - lo[0];
+    if (hi[1] - lo[1] > ext) ext = hi[1] - lo[1];
+    if (hi[2] - lo[2] > ext) ext = hi[2] - lo[2];
+    const double m = ext * CERT_BOX_MARGIN;
+    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+    const double x0 = lo[0] - m, x1 = hi[0] + m, y0 = lo[1] - m, y1 = hi[1] + m, z0 = lo[2] - m, z1 = hi[2] + m;
+    double entry;
+    return !slab(nx ? x1 : x0, nx ? x0 : x1, ny ? y1 : y0, ny ? y0 : y1, nz ? z1 : z0, nz ? z0 : z1, o, inv, tmin, tmax, entry);
+}
+
+// One leaf reference: its 1..4 primitives in DFS order, then pop.  WALK_CERT, a REF_FILTERED group: a member that
+// carries a certificate is skipped when the segment misses its own widened box and the ray is not in doubt for it --
+// the reference's own test then rejects it (scene_host.cpp build_cert_tree).  The skip is taken per wave (a wave of
+// floor and sky rays skips the floor group's mesh triangles together); a wave in which some lane must test the
+// member tests it with every lane on that group, which is what the reference does anyway.
 template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
     const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
-    uint32_t count = (tv.cur & 3u) + 1u;
-    if (WALK == WALK_CERT && (tv.cur >> 30) == REF_SINGLE) {
-        const V3 inv = tv.inv;
-        const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
-        double entry;
-        bool pass;
-        if (COMPACT) {
-            const uint4* g = reinterpret_cast<const uint4*>(sc.gates) + (size_t)first * 2;
-            const uint4 a = g[0], b = g[1];
-            pass = slab_f32(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, o, inv, tmin, tmax, entry);
-        } else {
-            const uint4* g = reinterpret_cast<const uint4*>(sc.gates) + (size_t)first * 3;
-            pass = slab_f64(g[0], g[1], g[2], nx, ny, nz, o, inv, tmin, tmax, entry);
-        }
-        count = pass ? 1u : 0u;
-    }
+    const uint32_t count = (tv.cur & 3u) + 1u;
+    const bool filtered = WALK == WALK_CERT && (tv.cur >> 30) == REF_FILTERED;
     if (COUNT) wc.leaf_prims = count;
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t p = first + k;
         const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
+        if (WALK == WALK_CERT && filtered && (r.tag() & 3u) == PRIM_TRIANGLE) {
+            const uint32_t cw = r.dw(COMPACT ? PRIM_CERT_DWORD_COMPACT : PRIM_CERT_DWORD_FULL);
+            if ((cw & CERT_VALID) != 0u && !cert_in_doubt(tv.dq, cw) && member_box_missed<COMPACT>(r, o, tv.inv, tmin, tmax)) continue;
+        }
         if (COUNT) {
             const uint32_t kind = r.tag() & 3u;
             if (kind == PRIM_TRIANGLE) wc.tri++;

@@ -23,11 +23,11 @@ namespace rayrs {
 // child reference: kind << 30 | payload
 constexpr uint32_t REF_INTERIOR = 0u;  // payload = interior record index
 constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1): 1..4 primitives behind the slot's box
-constexpr uint32_t REF_SINGLE = 2u;    // payload = prim << 2.  In the two-child export: a direct leaf (no box of its own,
-                                       // bvh.rs:297, :302; the gate tree holds it as a one-primitive REF_RANGE behind
-                                       // the box of the Node it hangs under).  In the certified tree: one primitive of a
-                                       // group record behind its OWN widened box (the only slots a walk may enter
-                                       // without having passed their box: "in doubt", below)
+constexpr uint32_t REF_SINGLE = 2u;    // two-child export only: payload = prim << 2, a direct leaf (no box of its own,
+                                       // bvh.rs:297, :302); the gate tree holds it as a one-primitive REF_RANGE behind
+                                       // the box of the Node it hangs under
+constexpr uint32_t REF_FILTERED = 2u;  // certified tree only (same number, other tree): a REF_RANGE group some of whose
+                                       // members carry a certificate (MemberFilter below); payload as REF_RANGE
 constexpr uint32_t REF_NONE = 3u;
 
 // primitive tag: kind | axis << 2 | surface << 8
@@ -55,35 +55,32 @@ static_assert(sizeof(NodeF64) == 128, "NodeF64");
 struct Node4F32 {  // 128 B
     float box[4][6];
     uint32_t ref[4];
-    uint32_t cert[4];  // one certificate word per slot (below); read by the certified walk only
+    uint32_t pad[4];
 };
 struct Node4F64 {  // 256 B
     double box[4][6];
     uint32_t ref[4];
-    uint32_t cert[4];
-    uint32_t pad[8];
+    uint32_t pad[12];
 };
 
-// Certificate word of a slot: (ax, ay, az) signed bytes, then w in bits 24..30 and CERT_TIGHT in bit 31.  The
-// certified walk (device_path.h trav_interior_step<..., WALK_CERT>) carries the ray's direction as three signed bytes
-// (dx, dy, dz) -- the direction scaled to length 127, each component rounded to nearest -- and calls the slot IN
-// DOUBT for the ray when |dx ax + dy ay + dz az| < CERT_UNIT * w: the ray may then lie so close to the plane of a
-// triangle below the slot that the reference's own test of it is rounding noise (scene_host.cpp build_cert_tree
-// has the theorem and the arithmetic behind the thresholds).  A slot in doubt is never culled by the closest hit so
-// far, and a CERT_TIGHT slot -- one whose box is built from the triangles' own widened boxes instead of the
-// reference's gating boxes -- is entered when in doubt even if the segment misses its box.
-//   w = 0       never in doubt: nothing below the slot whose computed t can be far off (rectangles only; unused slots);
-//   w = 3       one triangle: (ax, ay, az) is its unit normal times 127, rounded (|cos| below 2.4 %: in doubt);
-//   w = 4..126  several triangles: the axis of a cone around their normals, w grows with the cone's half angle;
-//   w = 127     always in doubt (130 * 127 exceeds every possible sum): spheres, degenerate or needle-thin triangles,
-//               triangles too small for the scene, cones too wide -- nothing is proved about what is below.
-// A ray outside the theorem's premises (origin too far out, direction not finite or of extreme magnitude) carries
-// (0, 0, 0): every slot with w > 0 is in doubt for it.
-constexpr uint32_t CERT_NEVER = 0u;
-constexpr uint32_t CERT_ALWAYS = 127u << 24;
-constexpr uint32_t CERT_UNIT = 130;      // the threshold per unit of w (7 bits)
-constexpr uint32_t CERT_TIGHT = 1u << 31; // the slot's box is a triangle-side box: a ray in doubt enters it even when the segment misses it
+// The certified walk's member certificates.  A triangle's primitive record has a spare dword (PRIM_CERT_DWORD_*)
+// that holds its certificate word: CERT_NONE (the member is tested whenever its group is entered, as the reference
+// does), or CERT_VALID | the triangle's unit normal times 127 as three signed bytes (nx, ny, nz), rounded to
+// nearest.  The walk carries the ray's direction the same way (length 127, rounded: device_path.h cert_ray_word)
+// and, in a REF_FILTERED group, skips such a member when the segment misses its bounding box widened by 1/64 of
+// its largest extent (computed from the record's vertices: device_path.h member_box_missed) AND
+// |dx nx + dy ny + dz nz| >= CERT_THRESHOLD -- when the ray is not "in doubt", i.e. provably not so close to the
+// triangle's plane that the reference's own test of it is rounding noise (scene_host.cpp build_cert_tree states the
+// theorem and the arithmetic behind the threshold).  A ray outside the theorem's premises carries (0, 0, 0): in
+// doubt for every member.
+constexpr uint32_t CERT_NONE = 0u;
+constexpr uint32_t CERT_VALID = 1u << 31;
+constexpr int32_t CERT_THRESHOLD = 320;
 constexpr uint32_t CERT_RAY_OUTSIDE = 0u;
+constexpr double CERT_BOX_MARGIN = 0x1p-6;   // of the member's largest extent, on every side
+constexpr uint32_t PRIM_CERT_DWORD_COMPACT = 9;   // triangles only (a rectangle's payload reaches dword 9)
+constexpr uint32_t PRIM_CERT_DWORD_FULL = 18;
+
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
@@ -101,9 +98,10 @@ constexpr uint32_t PRIM_DWORDS_FULL = 20;     // 80 B
 //   WALK_FAST       the tree of single primitives behind clipped boxes, closest-hit culling: two bets
 //                   (device_path.h TRAV_CULL_MARGIN, scene_host.cpp LEAF_MARGIN);
 //   WALK_REFERENCE  the gate tree, nothing culled: the primitives BvhTree::intersect tests, by construction;
-//   WALK_CERT       the certified tree, nothing culled: a primitive of an entered group is skipped only where
-//                   "its widened box is missed" provably means "the reference rejects it" (scene_host.cpp
-//                   build_cert_tree), which the slot's certificate word decides against the ray's (Trav::dq).
+//   WALK_CERT       the same, except that a member of an entered group is skipped where "its own widened box is
+//                   missed" provably means "the reference rejects it" (scene_host.cpp build_cert_tree): members far
+//                   smaller than their gating box (the mesh triangles that share a bottom Node with the floor),
+//                   which a whole wave of floor and sky rays skips together.
 enum : int { WALK_FAST = 0, WALK_REFERENCE = 1, WALK_CERT = 2 };
 
 // One row per distinct (Material, Emission) pair; material.rs:148-238, :1056-1060.
@@ -141,8 +139,7 @@ struct SceneDev {
     // instance of the traversal kernel runs, on which of the scene's three trees `nodes` points to)
     uint32_t walk, pad1;
     double cert_center[3], cert_radius;  // WALK_CERT: the per-ray guard (device_path.h cert_ray_word)
-    double cert_ext;                     // WALK_CERT: largest extent of a certified triangle (device_path.h cert_penalty)
-    const void* gates;  // WALK_CERT: every primitive's gating box: 6 f32 + 2 pad (compact) / 6 f64 (full), by primitive record
+    uint32_t n_filtered, pad2;           // members that carry a certificate (0: the certified walk is the reference walk)
 };
 
 struct CameraDev {

@@ -40,11 +40,6 @@ typedef struct {
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab);
 
-/* Process-wide knobs of the certified tree's builder, for the scenes built AFTERWARDS (0 = default): the widest cone
- * code an interior slot may have and still keep its box as built (scene_host.cpp CERT_TIGHT_MAX_W), and 1 = keep every
- * group whole behind its gating box (the gate tree's topology with certificates: culling only). */
-void rayrs_lab_build(uint32_t cert_tight_max_w, uint32_t cert_whole_groups);
-
 /* HIP-event times (ms) of the last finished render's path rounds, three per round: traversal, hit, miss kernel (the
  * local-pool route: its launch, 0, 0).  Returns the number of rounds (negative: rayrs_status); writes min(rounds,
  * cap_rounds) * 3 floats. */

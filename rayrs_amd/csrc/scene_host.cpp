@@ -17,15 +17,11 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <limits>
 
 #include "../../include/rayrs_numeric.h"
 
 namespace rayrs {
-
-// (development: rayrs_lab.h rayrs_lab_build sets these for the scenes built afterwards; 0 = default)
-uint32_t g_cert_tight_max_w = 0, g_cert_whole_groups = 0;
 
 // ---------------------------------------------------------------- surfaces
 
@@ -660,20 +656,21 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
     front_largest(t);
 }
 
-// ------------------------------------------------------------ the certified tree
+// ------------------------------------------------------------ the certified walk
 //
-// What the default walk leaves out, and why that is the reference's answer BY THEOREM, not by measurement.
-//
-// The tree is the gate tree -- groups behind exactly their gating boxes, interior boxes the unions of those, so
-// that "the segment misses the box" means "the reference does not get there" by the monotony of the slab test --
-// with every group of CERT_MIN_GROUP or more primitives opened into a record of its own ("group record"): the
-// group's slot keeps the exact gating box and refers to that record, whose slots are the group's primitives one
-// by one, each behind its own bounding box widened by LEAF_MARGIN of its largest extent (rounded outwards to
-// f32, NOT clipped) and each with a certificate word (layout.h).  A walk that stands in a group record has
-// passed the group's gating box exactly as BvhTree::intersect does (bvh.rs:391-415), so the reference tests
-// every primitive of that record; the walk tests a primitive iff the segment enters its widened box OR its
-// certificate reads "in doubt" for this ray, and skips it otherwise.  The claim: whenever it skips a triangle,
-// the reference's own test (geometry.rs:359-375, then bvh.rs:406) rejects it.
+// The reference tests every member of a bottom Node whose box the ray enters (bvh.rs:391-415).  Where that Node holds
+// one large primitive and a few small ones -- the benchmark scenes' 50 x 50 floor shares its Node with three mesh
+// triangles; every floor and sky ray enters that box: half of all primitive tests of the reference walk -- the
+// certified walk skips a small member whose own widened box W the segment misses, and the claim is that the
+// reference's own test (geometry.rs:359-375, then bvh.rs:406) rejects that member then: BY THEOREM, not by measurement.
+// The tree is the gate tree (groups behind exactly their gating boxes, nothing culled); a group with such members is
+// marked REF_FILTERED, and such a member's primitive record carries a certificate word (layout.h); W is the member's
+// bounding box widened by CERT_BOX_MARGIN = 2^-6 of its largest extent, NOT clipped.  A walk that stands on the
+// group has passed its gating box exactly as BvhTree::intersect does, so the reference tests every member; the walk
+// tests a member unless it carries a certificate, the segment misses W and the ray is not "in doubt" for it.
+// (The same theorem carried a whole tree of single triangles in round 5's experiments -- cone certificates per slot,
+// certified culling, gating boxes tested in the leaf step; sound, and no faster than the reference walk:
+// profiles/r05_certified_walks.txt.  What pays is skipping that a whole wave does together.)
 //
 // Notation.  u = 2^-53.  Triangle p1, p2, p3; ray o + s d, s in (t0, t1); all finite doubles.  The reference
 // computes, in this order and without fused operations (device_path.h triangle_intersect is the same list):
@@ -707,7 +704,7 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
 //     12 lam ext_k(Q') < 2^-10 ext_k of the bounding box of Q' -- within 2^-9 ext_max of the bounding box of Q
 //     (the perturbations of Q' and o' are at most u |a|, u |b|, u |c|, and u |c| <= u L min(|a|,|b|) <= 2^-21 ext_max
 //     with L <= 2^31, checked in (5)) -- that is, inside the widened box W, whose margin is
-//     m = LEAF_MARGIN ext_max = 2^-6 ext_max, with (7/8) m to spare on every side.
+//     m = CERT_BOX_MARGIN ext_max = 2^-6 ext_max, with (7/8) m to spare on every side.
 // (4) ... so the slab test on W passes.  Along the line a step ds moves no coordinate by more than ds |d|_inf,
 //     so the exact parameter interval [A, B] of the line inside W contains TT with (7/8) m / |d|_inf to spare on
 //     both sides.  The slab test computes each axis' parameters as fl(fl(bound - o_k) fl(1 / d_k)): relative
@@ -723,42 +720,24 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
 //     |o - p1| that the walk's per-ray guard enforces (FlatScene::cert_radius: |o - centre|_inf <= R, so
 //     D = sqrt3 (R + the root box's largest half extent)):  tau = 2^-36 max(1, 1.01 D / min(|a|,|b|)) / sin(gamma).
 //     If tau <= 2^-10, and the triangle's sizes are sane (edges and D within 2^+-200, L <= 2^31), the word holds
-//     the normal N = a x b scaled to largest component +-127 and rounded to nearest; else CERT_ALWAYS.  The walk
-//     scales d the same way (largest component +-127, round to nearest: exact division 127 / max|d_k|, one
-//     multiply, v_rndne).  With r, s the two rounding vectors (components at most 1/2 + 2^-40),
-//         dq . nq = (127 / |d|_inf)(127 / |N|_inf) d . N + (127 / |d|_inf) d . r + (127 / |N|_inf) N . s + s . r,
-//     and the last three are at most 190.5 + 190.5 + 0.76 < 382 in magnitude.  "Not in doubt" means
-//     |dq . nq| >= CERT_THRESHOLD = 512, hence |d . N| / (|d||N|) >= (512 - 382) / (127^2 * 3) > 2^-8.6
-//     (|d|_inf >= |d| / sqrt3, likewise N): four times tau, which swallows the difference between N computed here
-//     in f64 and the exact normal of Q' (relative 4u / sin(gamma)) -- kappa >= 2^-8.6 sin(gamma') >= 2^-36 L.
-//     A ray whose origin fails the guard, or whose direction has a largest component outside [2^-400, 2^400] or a
-//     component that is not finite, carries (0, 0, 0, 127): every triangle reads "in doubt" and is tested.
-// What is in doubt is tested with the reference's own arithmetic, what is not in doubt and missed is rejected
-// by the reference: the certified walk returns BvhTree::intersect's closest hit for every ray.  Nothing is
-// culled by the closest hit so far (no certificate exists for that: device_path.h TRAV_CULL_MARGIN), so the
-// order of the visits does not matter and slots are entered in slot order.
-// About 2 % of (ray, triangle slot) pairs read "in doubt" (|cos| below 0.01 ... 0.03 depending on how the two
-// vectors quantise): they cost a primitive test each, the same test the reference makes.
-constexpr double CERT_GUARD_RADII = 4.0;  // rays from within this many root-box half extents of its centre are certified
+//     the unit normal N / |N| times 127, rounded to nearest; else the member carries no certificate.  The walk scales d
+//     the same way (d / |d| times 127: a dot product, an IEEE square root and division, three products, v_rndne).
+//     With r, s the two rounding vectors (components at most 1/2 + 2^-40) and dh, nh the unit vectors,
+//         dq . nq = 127^2 (1 + e) dh . nh + 127 (dh . r)(1 + e) + 127 nh . s + s . r,    |e| <= 4u,
+//     and the last three are at most 110 + 110 + 0.76 < 222 in magnitude (|r|_2, |s|_2 <= sqrt3 / 2).  "Not in doubt"
+//     means |dq . nq| >= CERT_THRESHOLD = 320, hence |cos(d, N)| >= (320 - 222) / 16130 > 2^-7.4: eight times tau,
+//     which swallows the difference between N computed here in f64 and the exact normal of Q' (relative 4u / sin(gamma))
+//     -- kappa >= 2^-7.4 sin(gamma') >= 2^-36 L.  A ray whose origin fails the guard, or whose direction has a largest
+//     component outside [2^-400, 2^400] or a component that is not finite, carries (0, 0, 0): in doubt for every member.
+// What is in doubt is tested with the reference's own arithmetic; what is not in doubt and missed is rejected by the
+// reference: the certified walk returns BvhTree::intersect's closest hit for every ray.  About 2 % of (ray, certified
+// member) pairs are in doubt (|cos| below 320 / 16129) and cost the test the reference makes anyway.
+constexpr double CERT_GUARD_RADII = 4.0;    // rays from within this many root-box half extents of its centre are certified
+constexpr double CERT_MEMBER_RATIO = 8.0;   // a member gets a certificate when its gating box has more than this many times W's area
 
-// Per primitive: may anything be proved about it ((5): a sane, not too thin, not too small triangle; a rectangle,
-// whose t = (pos - o_n) / d_n is three roundings from exact whatever the ray), and its unit normal.
-struct CertPrim {
-    uint8_t kind;  // 0 = nothing proved (always in doubt), 1 = triangle with a certificate, 2 = never in doubt (rectangle)
-    double n[3];
-};
-
-static CertPrim cert_prim_for(const Shape& s, double D) {
-    CertPrim c{0, {0, 0, 0}};
-    if (s.kind == PRIM_PLANE) {
-        // Plane::intersect (geometry.rs:229-271): tt = (pos - o_n) / d_n and p = o + d tt are a handful of roundings from
-        // exact whatever the ray, so the computed point lies within 2^-48 D of the exact one: a rectangle whose larger
-        // side is at least 2^-31 D is never in doubt (build_cert_tree (7))
-        const double ext = std::max(s.u1 - s.u0, s.v1 - s.v0);
-        if (ext >= 0x1p-31 * D && ext <= 0x1p200 && D <= 0x1p200 && std::isfinite(s.pos)) c.kind = 2;
-        return c;
-    }
-    if (s.kind != PRIM_TRIANGLE) return c;
+// The certificate word of a triangle ((5) above), or CERT_NONE.
+static uint32_t cert_word_for(const Shape& s, double D) {
+    if (s.kind != PRIM_TRIANGLE) return CERT_NONE;
     const double a[3] = {s.p2.x - s.p1.x, s.p2.y - s.p1.y, s.p2.z - s.p1.z};
     const double b[3] = {s.p3.x - s.p1.x, s.p3.y - s.p1.y, s.p3.z - s.p1.z};
     const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
@@ -766,105 +745,29 @@ static CertPrim cert_prim_for(const Shape& s, double D) {
     const double lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
     const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
     const double lo = 0x1p-200, hi = 0x1p200;
-    if (!(la >= lo && la <= hi && lb >= lo && lb <= hi && ln >= lo * lo && D >= lo && D <= hi)) return c;  // NaN: false
+    if (!(la >= lo && la <= hi && lb >= lo && lb <= hi && ln >= lo * lo && D >= lo && D <= hi)) return CERT_NONE;  // NaN: false
     const double emin = la < lb ? la : lb;
     const double L = std::max(1.0, 1.01 * D / emin);
-    if (!(L <= 0x1p31)) return c;
+    if (!(L <= 0x1p31)) return CERT_NONE;
     const double sin_gamma = ln / (la * lb);
     const double tau = 0x1p-36 * L / sin_gamma;
-    if (!(tau <= 0x1p-10)) return c;
-    c.kind = 1;
-    for (int k = 0; k < 3; k++) c.n[k] = n[k] / ln;
-    return c;
-}
-
-// The certificate word of a slot with the primitives ids[0, count) below it (layout.h).
-static uint32_t cert_word_for(const std::vector<CertPrim>& cp, const uint32_t* ids, size_t count) {
-    double sum[3] = {0, 0, 0}, first[3] = {0, 0, 0};
-    size_t tris = 0;
-    for (size_t i = 0; i < count; i++) {
-        const CertPrim& c = cp[ids[i]];
-        if (c.kind == 0) return CERT_ALWAYS;
-        if (c.kind != 1) continue;
-        if (tris == 0) first[0] = c.n[0], first[1] = c.n[1], first[2] = c.n[2];
-        // |d . n| does not care for the sign of n: normals are taken into the first one's half space
-        const double sg = (c.n[0] * first[0] + c.n[1] * first[1] + c.n[2] * first[2]) < 0.0 ? -1.0 : 1.0;
-        for (int k = 0; k < 3; k++) sum[k] += sg * c.n[k];
-        tris++;
-    }
-    if (tris == 0) return CERT_NEVER;
-    const double ls = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-    if (!(ls >= 0.5)) return CERT_ALWAYS;  // (normals that cancel: no axis)
-    const double ax[3] = {sum[0] / ls, sum[1] / ls, sum[2] / ls};
-    double cos_min = 1.0;
-    for (size_t i = 0; i < count; i++) {
-        const CertPrim& c = cp[ids[i]];
-        if (c.kind != 1) continue;
-        const double d = std::fabs(c.n[0] * ax[0] + c.n[1] * ax[1] + c.n[2] * ax[2]);
-        if (d < cos_min) cos_min = d;
-    }
-    // not in doubt: |dq . aq| >= CERT_UNIT w  ==>  |cos(d, axis)| >= (CERT_UNIT w - 222) / 16130 (build_cert_tree (5)),
-    // and a normal within phi of the axis has |cos(d, n)| >= |cos(d, axis)| cos(phi) - sin(phi): that has to reach 2^-8.6
-    if (!(cos_min > 0.5)) return CERT_ALWAYS;
-    const double sin_max = tris > 1 ? std::sqrt(std::max(0.0, 1.0 - cos_min * cos_min)) * 1.001 + 1e-9 : 0.0;
-    const double need = 222.0 + 16130.0 * (0.00258 + sin_max) / (tris > 1 ? cos_min * 0.999 : 1.0);
-    const uint32_t w = (uint32_t)std::ceil(need / (double)CERT_UNIT);
-    if (w >= 127) return CERT_ALWAYS;
-    uint32_t word = w << 24;
+    if (!(tau <= 0x1p-10)) return CERT_NONE;
+    uint32_t w = CERT_VALID;
     for (int k = 0; k < 3; k++) {
-        const int q = (int)std::nearbyint(ax[k] * 127.0);  // in [-127, 127]
-        word |= ((uint32_t)q & 0xffu) << (8 * k);
+        const int q = (int)std::nearbyint(n[k] / ln * 127.0);  // in [-127, 127]
+        w |= ((uint32_t)q & 0xffu) << (8 * k);
     }
-    return word;
+    return w;
 }
 
-// Bottom-up over the certified tree's records: appends the primitives below `ref` to `ids`, merges their gating
-// boxes into `gates` (6 doubles, started by the caller), and -- for a slot of a record -- sets the slot's certificate
-// word, decides whether the slot's box is taken as a triangle-side box (CERT_TIGHT: entered when in doubt) or widened
-// to the gating boxes below (entered iff the segment enters it, whatever the ray).
-#define CERT_TIGHT_MAX_W (rayrs::g_cert_tight_max_w ? rayrs::g_cert_tight_max_w : 4u)  // interior slots with wider cones take the gating boxes in (3 % of rays and more would be in doubt)
-
-static void cert_fill(WalkTree& t, const std::vector<CertPrim>& cp, const std::vector<double>& prim_gate, uint32_t ref,
-                      size_t slot, std::vector<uint32_t>& ids, double* gates_out) {
-    const size_t begin = ids.size();
-    const double inf = std::numeric_limits<double>::infinity();
-    double gates[6] = {inf, -inf, inf, -inf, inf, -inf};
-    const uint32_t kind = ref >> 30;
-    if (kind == REF_INTERIOR) {
-        const uint32_t rec = ref & 0x3fffffffu;
-        for (int c = 0; c < 4; c++) {
-            const uint32_t r = t.ref[(size_t)rec * 4 + c];
-            if ((r >> 30) != REF_NONE) cert_fill(t, cp, prim_gate, r, (size_t)rec * 4 + c, ids, gates);
-        }
-    } else if (kind == REF_RANGE || kind == REF_SINGLE) {
-        const uint32_t first = (ref & 0x3fffffffu) >> 2, count = kind == REF_RANGE ? (ref & 3u) + 1u : 1u;
-        for (uint32_t i = 0; i < count; i++) {
-            ids.push_back(first + i);
-            box_merge(gates, &prim_gate[(size_t)(first + i) * 6]);
-        }
-    }
-    if (gates_out) box_merge(gates_out, gates);
-    if (slot == (size_t)-1) return;
-    uint32_t word = cert_word_for(cp, ids.data() + begin, ids.size() - begin);
-    if (kind == REF_SINGLE) {
-        word |= CERT_TIGHT;  // one triangle behind its own widened box
-    } else if (kind == REF_INTERIOR && (word >> 24) <= CERT_TIGHT_MAX_W) {
-        word |= CERT_TIGHT;  // the union of the boxes of the record below (as built, but for an outlier record's slot)
-        const uint32_t rec = ref & 0x3fffffffu;
-        double u[6] = {inf, -inf, inf, -inf, inf, -inf};
-        for (int c = 0; c < 4; c++)
-            if ((t.ref[(size_t)rec * 4 + c] >> 30) != REF_NONE) box_merge(u, &t.box[((size_t)rec * 4 + c) * 6]);
-        for (int q = 0; q < 6; q++) t.box[slot * 6 + q] = u[q];
-    } else if (kind == REF_INTERIOR) {
-        box_merge(&t.box[slot * 6], gates);  // ... and of the gating boxes of the single primitives below
-    }
-    t.cert[slot] = word;
-}
-
-// f.gate must be built (the groups).  objs / prim_object give the shapes behind the primitive records.
-void build_cert_tree(FlatScene& f, const ObjectList& objs, const std::vector<WalkGroup>& groups, const std::vector<Aabb>& prim_box) {
+// f.gate must be built.  objs / prim_object give the shapes behind the primitive records.
+void build_cert_tree(FlatScene& f, const ObjectList& objs, const std::vector<Aabb>& prim_box) {
     WalkTree& t = f.cert;
-    t = WalkTree();
+    t = f.gate;
+    t.node_bytes.clear();
+    const size_t n = f.n_prims();
+    f.member_cert.assign(std::max<size_t>(n, 1), CERT_NONE);
+    f.n_filtered = 0;
     // the guard: rays from within CERT_GUARD_RADII half extents of the root box's centre (max norm)
     double half = 0.0;
     for (int a = 0; a < 3; a++) {
@@ -872,231 +775,30 @@ void build_cert_tree(FlatScene& f, const ObjectList& objs, const std::vector<Wal
         half = std::max(half, 0.5 * (f.root_box[2 * a + 1] - f.root_box[2 * a]));
     }
     f.cert_radius = CERT_GUARD_RADII * half;
-    if (!(f.cert_radius > 0.0) || !std::isfinite(f.cert_radius)) f.cert_radius = 0.0;  // nothing is certified
+    if (!(f.cert_radius > 0.0) || !std::isfinite(f.cert_radius)) {
+        f.cert_radius = 0.0;  // nothing is certified
+        return;
+    }
     const double D = std::sqrt(3.0) * (f.cert_radius + half);
-    std::vector<CertPrim> cp(f.n_prims());
-    f.cert_ext = 0.0;
-    for (uint32_t p = 0; p < f.n_prims(); p++) {
-        cp[p] = cert_prim_for(objs.objs[f.prim_object[p]].geom, D);
-        if (!(f.cert_radius > 0.0) && cp[p].kind == 1) cp[p].kind = 0;
-        if (cp[p].kind == 1) {
-            const Aabb& pb = prim_box[p];
-            f.cert_ext = std::max(f.cert_ext, std::max(pb.xmax - pb.xmin, std::max(pb.ymax - pb.ymin, pb.zmax - pb.zmin)));
-        }
-    }
-    // Leaves.  A group whose members are all certified (triangles, rectangles) is taken apart.  A member whose own
-    // widened box W is not much smaller than the group's gating box G becomes a leaf of its own behind W (REF_SINGLE).
-    // The others -- e.g. the three mesh triangles that share a bottom Node, hence a gating box, with the 50 x 50 floor
-    // -- go, clustered by direction of their normals, into records of their own ("outlier records": REF_SINGLE slots
-    // behind their W), each reached through ONE slot that the builder sees with the box G: that puts it near the root,
-    // where no box is the worse for containing G (a box that is entered only when hit has to contain the gating box
-    // of every single primitive below it, cert_fill).  Every other group stays whole behind G, as in the gate tree.
-    //   The tree is built in two phases.  Above, where the normals below a node spread too far for a certificate
-    // (w > CERT_TIGHT_MAX_W), its leaves are whole groups (the union of the members' W): every box up there takes the
-    // gating boxes below in, and a group's gating box is the union of its members' boxes -- no larger than what
-    // the node holds anyway -- only if the group is below it as a whole.  Below, where a certificate covers a subtree,
-    // boxes stay as built, and the subtree is built again over its single primitives, free of the groups.
-    constexpr double OUTLIER_AREA_RATIO = 8.0;
-    constexpr uint32_t PLACEHOLDER = 0x20000000u;
-    f.prim_gate.assign((size_t)f.n_prims() * 6, 0.0);
-    std::vector<WalkGroup> p1;                      // phase-1 leaves
-    std::vector<std::vector<uint32_t>> members;     // of a phase-1 group leaf (ref = REF_NONE << 30 | index here)
-    std::vector<std::vector<uint32_t>> outliers;    // per outlier record: its primitives
-    auto cone_w = [&](const uint32_t* ids, size_t n) { return (cert_word_for(cp, ids, n) >> 24) & 127u; };
-    for (const WalkGroup& g : groups) {
-        const uint32_t first = (g.ref & 0x3fffffffu) >> 2, count = (g.ref & 3u) + 1u;
-        bool certified = true;
-        for (uint32_t i = 0; i < count; i++) {
-            for (int k = 0; k < 6; k++) f.prim_gate[(size_t)(first + i) * 6 + k] = g.box[k];
-            if (cp[first + i].kind == 0) certified = false;
-        }
-        if (!certified || g_cert_whole_groups) {
-            p1.push_back(g);
-            continue;
-        }
-        const double area_g = box_area(g.box);
-        std::vector<uint32_t> in, out;
-        WalkGroup u = g;
-        for (uint32_t i = 0; i < count; i++) {
-            double w[6];
-            tight_box(prim_box[first + i], nullptr, w);
-            if (area_g <= OUTLIER_AREA_RATIO * box_area(w)) {
-                if (in.empty()) {
-                    for (int k = 0; k < 6; k++) u.box[k] = w[k];
-                } else {
-                    box_merge(u.box, w);
-                }
-                in.push_back(first + i);
-            } else {
-                out.push_back(first + i);
+    for (uint32_t r = 0; r < t.n(); r++)
+        for (int c = 0; c < 4; c++) {
+            const uint32_t ref = t.ref[(size_t)r * 4 + c];
+            if ((ref >> 30) != REF_RANGE) continue;
+            const uint32_t first = (ref & 0x3fffffffu) >> 2, count = (ref & 3u) + 1u;
+            const double area_g = box_area(&t.box[((size_t)r * 4 + c) * 6]);
+            bool any = false;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t p = first + i;
+                const Aabb& pb = prim_box[p];
+                const double ext = std::max(pb.xmax - pb.xmin, std::max(pb.ymax - pb.ymin, pb.zmax - pb.zmin));
+                const double m = ext * CERT_BOX_MARGIN;
+                const double w[6] = {pb.xmin - m, pb.xmax + m, pb.ymin - m, pb.ymax + m, pb.zmin - m, pb.zmax + m};
+                if (!(area_g > CERT_MEMBER_RATIO * box_area(w))) continue;  // (NaN: no certificate)
+                f.member_cert[p] = cert_word_for(objs.objs[f.prim_object[p]].geom, D);
+                if (f.member_cert[p] != CERT_NONE) any = true, f.n_filtered++;
             }
+            if (any) t.ref[(size_t)r * 4 + c] = (REF_FILTERED << 30) | (ref & 0x3fffffffu);
         }
-        if (in.empty() && count == 1) {  // a lone primitive far smaller than its gating box: behind that box
-            p1.push_back(g);
-            continue;
-        }
-        if (!in.empty()) {
-            u.ref = (REF_NONE << 30) | (uint32_t)members.size();
-            p1.push_back(u);
-            members.push_back(in);
-        }
-        // outliers: clusters whose normals a certificate covers
-        std::vector<std::vector<uint32_t>> cl;
-        for (uint32_t o : out) cl.push_back({o});
-        for (bool merged = true; merged;) {
-            merged = false;
-            for (size_t x = 0; x < cl.size() && !merged; x++)
-                for (size_t y = x + 1; y < cl.size() && !merged; y++) {
-                    std::vector<uint32_t> both = cl[x];
-                    both.insert(both.end(), cl[y].begin(), cl[y].end());
-                    if (cone_w(both.data(), both.size()) <= CERT_TIGHT_MAX_W) {
-                        cl[x] = both;
-                        cl.erase(cl.begin() + (std::ptrdiff_t)y);
-                        merged = true;
-                    }
-                }
-        }
-        for (const auto& c : cl) {
-            WalkGroup ps = g;
-            ps.ref = (REF_INTERIOR << 30) | (PLACEHOLDER + (uint32_t)outliers.size());
-            p1.push_back(ps);
-            outliers.push_back(c);
-        }
-    }
-    {
-        // Leaves about as large as the scene (the floor; an outlier slot, which the builder sees with its gating box)
-        // are set aside and joined on top of the tree over the others, largest last: a centroid split can only
-        // separate two of them from the mesh between them by putting half of the mesh on their side.
-        std::vector<WalkGroup> big, rest;
-        const double big_area = 0.125 * box_area(f.root_box);
-        for (const WalkGroup& l : p1) (box_area(l.box) >= big_area && big.size() < 8 ? big : rest).push_back(l);
-        if (rest.empty()) rest.swap(big);
-        std::stable_sort(big.begin(), big.end(), [](const WalkGroup& x, const WalkGroup& y) { return box_area(x.box) < box_area(y.box); });
-        WalkBuilder b1(rest);
-        b1.build();
-        const std::vector<WalkNode>& n1 = b1.nodes;
-        // the single primitives below every phase-1 node, as a range of `order`; whether anything else is below it
-        std::vector<uint32_t> order, lo(n1.size(), 0), hi(n1.size(), 0);
-        std::vector<uint8_t> other(n1.size(), 0);
-        {
-            struct Frame {
-                int32_t n;
-                int stage;
-            };
-            std::vector<Frame> st{{0, 0}};
-            while (!st.empty()) {
-                Frame& fr = st.back();
-                const WalkNode& w = n1[fr.n];
-                if (w.left < 0) {
-                    lo[fr.n] = (uint32_t)order.size();
-                    if ((w.ref >> 30) == REF_NONE) {
-                        const std::vector<uint32_t>& m = members[w.ref & 0x3fffffffu];
-                        order.insert(order.end(), m.begin(), m.end());
-                    } else {
-                        other[fr.n] = 1;
-                    }
-                    hi[fr.n] = (uint32_t)order.size();
-                    st.pop_back();
-                } else if (fr.stage == 0) {
-                    lo[fr.n] = (uint32_t)order.size();
-                    fr.stage = 1;
-                    st.push_back({w.left, 0});
-                } else if (fr.stage == 1) {
-                    fr.stage = 2;
-                    st.push_back({w.right, 0});
-                } else {
-                    hi[fr.n] = (uint32_t)order.size();
-                    other[fr.n] = other[w.left] | other[w.right];
-                    st.pop_back();
-                }
-            }
-        }
-        // phase 2: the nodes of the final binary tree; [0] is the root, filled last
-        std::vector<WalkNode> out(1);
-        auto append_tree_over = [&](const uint32_t* prims, size_t n) -> int32_t {  // exact SAH over single primitives
-            std::vector<WalkGroup> ls(n);
-            for (size_t i = 0; i < n; i++) {
-                tight_box(prim_box[prims[i]], nullptr, ls[i].box);
-                ls[i].ref = (REF_SINGLE << 30) | (prims[i] << 2);
-            }
-            WalkBuilder b2(ls);
-            b2.build();
-            const int32_t off = (int32_t)out.size();
-            for (WalkNode nd : b2.nodes) {
-                if (nd.left >= 0) nd.left += off, nd.right += off;
-                out.push_back(nd);
-            }
-            return off;
-        };
-        std::function<int32_t(int32_t)> rebuild = [&](int32_t n) -> int32_t {
-            const WalkNode& w = n1[n];
-            const bool group_leaf = w.left < 0 && (w.ref >> 30) == REF_NONE;
-            if (w.left < 0 && !group_leaf) {
-                out.push_back(w);
-                return (int32_t)out.size() - 1;
-            }
-            if (group_leaf || (!other[n] && cone_w(order.data() + lo[n], hi[n] - lo[n]) <= CERT_TIGHT_MAX_W))
-                return append_tree_over(order.data() + lo[n], hi[n] - lo[n]);
-            const int32_t l = rebuild(w.left), r = rebuild(w.right);
-            WalkNode nd = out[l];
-            box_merge(nd.box, out[r].box);
-            nd.left = l, nd.right = r, nd.ref = 0;
-            out.push_back(nd);
-            return (int32_t)out.size() - 1;
-        };
-        int32_t cur = rebuild(0);
-        for (size_t i = 0; i < big.size(); i++) {
-            WalkNode leaf;
-            for (int k = 0; k < 6; k++) leaf.box[k] = big[i].box[k];
-            leaf.left = leaf.right = -1, leaf.ref = big[i].ref;
-            // (a set-aside group leaf: the floor alone)
-            int32_t leafn;
-            if ((leaf.ref >> 30) == REF_NONE) {
-                const std::vector<uint32_t>& m = members[leaf.ref & 0x3fffffffu];
-                leafn = append_tree_over(m.data(), m.size());
-            } else {
-                leafn = (int32_t)out.size();
-                out.push_back(leaf);
-            }
-            WalkNode top = out[leafn];
-            box_merge(top.box, out[cur].box);
-            top.left = leafn, top.right = cur, top.ref = 0;
-            cur = (int32_t)out.size();
-            out.push_back(top);
-        }
-        out[0] = out[cur];
-        t.box.reserve(out.size() * 6);
-        t.ref.reserve(out.size());
-        const WideCollapse wc(out);
-        if (out[0].left < 0) {  // a single leaf (cannot happen here: the two-child tree has an interior root)
-            t = f.gate;
-            t.cert.assign((size_t)t.n() * 4, CERT_ALWAYS);
-            return;
-        }
-        t.root_ref = emit_wide(t, wc, 0, &t.depth);
-        const uint32_t n_main = t.n();
-        for (size_t i = 0; i < outliers.size(); i++) {
-            const uint32_t rec = t.n();
-            t.ref.resize(t.ref.size() + 4, REF_NONE << 30);
-            t.box.resize(t.box.size() + 24, 0.0);
-            for (size_t k = 0; k < outliers[i].size(); k++) {
-                const uint32_t p = outliers[i][k];
-                tight_box(prim_box[p], nullptr, &t.box[((size_t)rec * 4 + k) * 6]);
-                t.ref[(size_t)rec * 4 + k] = (REF_SINGLE << 30) | (p << 2);
-            }
-        }
-        for (size_t sidx = 0; sidx < (size_t)n_main * 4; sidx++) {
-            const uint32_t r = t.ref[sidx];
-            if ((r >> 30) == REF_INTERIOR && (r & 0x3fffffffu) >= PLACEHOLDER)
-                t.ref[sidx] = (REF_INTERIOR << 30) | (n_main + ((r & 0x3fffffffu) - PLACEHOLDER));
-        }
-        if (!outliers.empty()) t.depth += 3;
-        front_largest(t);
-    }
-    t.cert.assign((size_t)t.n() * 4, CERT_NEVER);
-    std::vector<uint32_t> ids;
-    ids.reserve(f.n_prims());
-    cert_fill(t, cp, f.prim_gate, t.root_ref, (size_t)-1, ids, nullptr);
 }
 
 // prim_box[p]: the reference's bounding box of the object behind primitive record p
@@ -1106,6 +808,7 @@ void build_walk_trees(FlatScene& f, const ObjectList& objs, const std::vector<Aa
     f.cert = WalkTree();
     if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
         f.walk.root_ref = f.gate.root_ref = f.cert.root_ref = f.root_ref;
+        f.member_cert.assign(std::max<size_t>(f.n_prims(), 1), CERT_NONE);
         return;
     }
     std::vector<WalkGroup> groups;
@@ -1114,7 +817,7 @@ void build_walk_trees(FlatScene& f, const ObjectList& objs, const std::vector<Aa
     std::vector<WalkGroup> singles;
     split_groups(groups, prim_box, singles);
     build_tree_over(singles, f.walk);
-    build_cert_tree(f, objs, groups, prim_box);
+    build_cert_tree(f, objs, prim_box);
 }
 
 inline bool boxes_f32_exact(const WalkTree& t) {
@@ -1138,7 +841,6 @@ void fill_nodes(WalkTree& t) {
         for (int ch = 0; ch < 4; ch++) {
             const uint32_t ref = t.ref[(size_t)r * 4 + ch];
             nodes[r].ref[ch] = ref;
-            nodes[r].cert[ch] = t.cert.empty() ? CERT_NEVER : t.cert[(size_t)r * 4 + ch];
             for (int k = 0; k < 6; k++)
                 nodes[r].box[ch][k] = (ref >> 30) == REF_NONE ? ((k & 1) ? (F)-inf : (F)inf) : (F)t.box[((size_t)r * 4 + ch) * 6 + k];
         }
@@ -1204,23 +906,6 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
         else fill_nodes<Node4F64, double>(*t);
     }
 
-    // ---- the primitives' gating boxes as the certified walk's leaf step reads them (exactly f32 when compact: they
-    // are leaf boxes of the gate tree, checked above)
-    {
-        const size_t stride = compact ? 32 : 48;
-        f.gate_bytes.assign(std::max<size_t>(n, 1) * stride, 0);
-        for (size_t p = 0; p < n && !f.prim_gate.empty(); p++)
-            for (int k = 0; k < 6; k++) {
-                const double v = f.prim_gate[p * 6 + k];
-                if (compact) {
-                    const float fv = (float)v;
-                    std::memcpy(&f.gate_bytes[p * stride + 4 * k], &fv, 4);
-                } else {
-                    std::memcpy(&f.gate_bytes[p * stride + 8 * k], &v, 8);
-                }
-            }
-    }
-
     // ---- primitive records in DFS order
     const uint32_t dw = compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL;
     f.prim_bytes.assign((size_t)n * dw * 4, 0);
@@ -1248,6 +933,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
                 else
                     put_f64(rec + 2 * k, v[k]);
             }
+            rec[compact ? PRIM_CERT_DWORD_COMPACT : PRIM_CERT_DWORD_FULL] = f.member_cert[p];  // (layout.h; CERT_NONE for most)
         }
         rec[dw - 1] = s.kind | (s.axis << 2) | (o.surface << 8);
     }

@@ -50,7 +50,6 @@ struct WalkTree {
     std::vector<uint32_t> ref;  // n * 4
     uint32_t root_ref = 0;
     uint32_t depth = 0;         // stack entries the traversal can need
-    std::vector<uint32_t> cert;  // n * 4: the slots' certificate words (layout.h CERT_*); empty = CERT_NEVER everywhere
     std::vector<uint8_t> node_bytes;  // the records as the kernels read them (Node4F32 / Node4F64)
     uint32_t n() const { return (uint32_t)(ref.size() / 4); }
 };
@@ -67,19 +66,17 @@ struct FlatScene {
     //         reaches; walked when rayrs_render_params.exact_traversal is set, and by the local-pool route;
     //   walk  single primitives behind their own widened boxes inside the gating box, closest-hit culling: two bets
     //         on the reference's arithmetic (RAYRS_WALK_FAST);
-    //   cert  the gate tree with every group of three or four primitives opened into a record of its own: single
-    //         primitives behind their widened boxes, each with a quantised normal, so that "box missed" is only
-    //         taken for "the reference rejects" where that is a theorem (scene_host.cpp build_cert_tree) -- the default.
+    //   cert  the gate tree again, the groups that have members with a certificate marked REF_FILTERED
+    //         (scene_host.cpp build_cert_tree) -- the default.
     WalkTree walk, gate, cert;
-    std::vector<double> prim_gate;      // n_prims * 6: every primitive's gating box (the certified walk tests it before a single triangle)
+    std::vector<uint32_t> member_cert;  // per primitive record: its certificate word (layout.h), also in the record itself
+    uint32_t n_filtered = 0;            // members that carry a certificate
     double cert_center[3] = {0, 0, 0};  // rays whose origin lies farther than cert_radius (max norm) from here are
-    double cert_radius = 0;             // outside the theorem's premises: every certificate reads "in doubt" for them
-    double cert_ext = 0;                // the largest extent (along an axis) of a triangle that carries a certificate
+    double cert_radius = 0;             // outside the theorem's premises: in doubt for every member
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)
     std::vector<uint8_t> prim_bytes;
-    std::vector<uint8_t> gate_bytes;  // per primitive record: its gating box, 6 f32 + 2 pad (compact) / 6 f64
     std::vector<float> hdri_quads;  // 16 floats per texel: the 2x2 footprint of a lookup at (i, j), RGBA each
     uint32_t hdri_w = 0, hdri_h = 0;
     double t0 = 0, t1 = 0;
@@ -87,8 +84,6 @@ struct FlatScene {
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }
 };
-
-extern uint32_t g_cert_tight_max_w, g_cert_whole_groups;  // development knobs of build_cert_tree (rayrs_lab.h rayrs_lab_build)
 
 // Scene::new (lib.rs:227-245) minus the upload.  Returns RAYRS_* status.
 int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int heuristic, uint32_t splits,

@@ -22,7 +22,6 @@ struct rayrs_scene {
     uint64_t n_objects = 0;
     int device = -1;
     void* d_prims = nullptr;
-    void* d_gates = nullptr;  // FlatScene::gate_bytes
     rayrs::SurfaceDev* d_surfaces = nullptr;
     float* d_hdri = nullptr;
     rayrs::Counters* d_counters = nullptr;

@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel
     uint32_t slot = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     Trav tv;
-    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0, tv.dq = 0, tv.pen = 0;
+    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0, tv.dq = 0;
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;

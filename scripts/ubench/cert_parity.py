@@ -7,8 +7,6 @@ import numpy as np
 import rayrs_amd, _oracle
 from rayrs_amd import scenes, procedural, _ffi
 hdri = procedural.make_hdri(64, 32)
-if os.environ.get("BUILD"):
-    _ffi.lib().rayrs_lab_build(*[int(x) for x in os.environ["BUILD"].split(",")])
 for level in (3, 5):
     cam_args, objs, heur = scenes.mesh_scene(level, area_light=True)
     cam_args = scenes.camera_for_resolution(cam_args, 96, 64)
@@ -20,7 +18,9 @@ for level in (3, 5):
     for walk in ("certified", "reference", "fast"):
         img, st = rayrs_amd.render(scene, cam, 8, 50, out_f64=True, walk=walk, count_work=True)
         if walk == "certified":
+            _oracle.set_cull_margin(float("inf"))
             o2, os2 = osc.use_cert_tree(scene).render(ocam, 8, 50, traversal=2)
+            _oracle.set_cull_margin(2.0 ** -10)
         elif walk == "reference":
             _oracle.set_cull_margin(float("inf"))
             o2, os2 = osc.use_walk_tree(scene, gate=True).render(ocam, 8, 50, traversal=2)
@@ -28,7 +28,7 @@ for level in (3, 5):
         else:
             o2, os2 = osc.use_walk_tree(scene).render(ocam, 8, 50, traversal=2)
         keys = ("rays", "interior_visits", "tri_tests", "plane_tests", "sphere_tests")
-        print(level, walk, "frame==recursion", np.array_equal(img.view(np.uint64), ref.view(np.uint64)),
+        print(level, walk, "filtered", scene.info()["n_filtered"], "frame==recursion", np.array_equal(img.view(np.uint64), ref.view(np.uint64)),
               "counters", [(k, st[k], os2[k]) for k in keys if st[k] != os2[k]] or "equal", "walk", st["walk"], flush=True)
 import fuzz_traversal as F
 z = np.zeros((2, 2, 3), dtype=np.float32)

@@ -14,9 +14,6 @@ cam_args, objs, heur, _, mb = scenes.config(cfg)
 if os.environ.get("CAMERA") == "close":
     cam_args = scenes.MESH_CLOSE_CAM
 cam_args = scenes.camera_for_resolution(cam_args, res, res)
-if os.environ.get("BUILD"):  # "w,whole": rayrs_lab.h rayrs_lab_build
-    from rayrs_amd import _ffi
-    _ffi.lib().rayrs_lab_build(*[int(x) for x in os.environ["BUILD"].split(",")])
 scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, procedural.make_hdri(1024, 512), device=0)
 print({k: v for k, v in scene.info().items() if "n_wide" in k or "depth" in k or k == "build_seconds"}, flush=True)
 cam = rayrs_amd.Camera(*cam_args)

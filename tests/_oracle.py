@@ -93,7 +93,7 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
-    L.orc_set_wide_cert.argtypes = [vp, vp, vp, C.POINTER(C.c_double), C.c_double, C.c_double]
+    L.orc_set_member_certs.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_double]
     L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.orc_vec_op.restype = None
     L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
@@ -216,15 +216,14 @@ class OracleScene:
                 "wide_depth": i.wide_depth}
 
     def use_cert_tree(self, product_scene):
-        """The product's certified tree and its certificate words: traversal=2 then makes the certified walk."""
+        """The product's certified tree and its certificate words: traversal=2 then makes the certified walk (the
+        cull margin must be infinite: _oracle.set_cull_margin(float("inf")), as for the gate tree)."""
         info = product_scene.info()
-        box, ref, cert, gate = product_scene.export_cert_tree()
-        box, ref, cert, gate = (np.ascontiguousarray(x) for x in (box, ref, cert, gate))
+        box, ref, mcert = (np.ascontiguousarray(x) for x in product_scene.export_cert_tree())
         assert self._L.orc_set_wide(self._h, info["cert_n_wide"], info["cert_root_ref"], info["cert_depth"],
                                     box.ctypes.data, ref.ctypes.data) == 0
         center = (C.c_double * 3)(*info["cert_center"])
-        assert self._L.orc_set_wide_cert(self._h, cert.ctypes.data, gate.ctypes.data, center, C.c_double(info["cert_radius"]),
-                                         C.c_double(info["cert_ext"])) == 0
+        assert self._L.orc_set_member_certs(self._h, mcert.ctypes.data, center, C.c_double(info["cert_radius"])) == 0
         return self
 
     def use_walk_tree(self, product_scene, gate=False):
