@@ -23,7 +23,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying
   cpu_baseline -- the CPU oracle in reference mode (recursive un-narrowed traversal over a pointer
                   tree, rayrs-lib's algorithm) timed on this box's host cores on a bounded band of the
                   same frame;
-  secondary    -- (headline config, N = 1) the same scene from a camera the mesh fills.
+  secondary    -- (headline config, N = 1) the same scene from a camera the mesh fills;
+  fast         -- (headline config, N = 1) the same frame by rayrs_render_params.fast_traversal, the walk that makes two
+                  bets on the reference's arithmetic (include/rayrs_hip.h): its rate beside the headline's, which is
+                  the default walk's -- the reference's visit set by construction --, and the two frames' sha256, asserted equal.
 """
 import argparse
 import glob
@@ -208,6 +211,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--fast-traversal", action="store_true",
+                    help="render the timed frames with rayrs_render_params.fast_traversal (the two bets) instead of the "
+                         "default walk; the default line carries that figure in its `fast` block anyway")
+    ap.add_argument("--no-fast", action="store_true", help="skip the `fast` block")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
                     "rehearsing the N>1 path on a box with fewer GPUs than ranks")
@@ -302,7 +309,7 @@ def main():
     def workload_key(W, H, chunk, camera=None):
         return f"config{args.config}_{camera or args.camera}_{W}x{H}_{spp}spp_chunk{chunk}_world{world}"
 
-    def measure(cam_args, steps, warmup, want_roofline):
+    def measure(cam_args, steps, warmup, want_roofline, fast=False):
         """Times `steps` frames from this camera; returns the pieces of the JSON line."""
         cam = rayrs_amd.Camera(*cam_args)
         H, W = cam.y_pixels(), cam.x_pixels()
@@ -312,7 +319,7 @@ def main():
         F = max(1, min(n_flights, steps))
         fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
         params = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
-                                       tile_ranks=args.share_of if args.share_of else world)
+                                       tile_ranks=args.share_of if args.share_of else world, fast_traversal=fast)
         turn = {"n": 0, "failed": None}
         cv = threading.Condition()
 
@@ -424,7 +431,7 @@ def main():
             # same launch once more with the work counters compiled in (untimed): the work of a launch is a
             # pure function of (scene, seed), so the counts apply to the timed launches exactly
             pc = rayrs_amd.make_params(spp, max_bounces, seed=0x5EED, sample_chunk=chunk, tile_rank=rank,
-                                       tile_ranks=args.share_of if args.share_of else world, count_work=True)
+                                       tile_ranks=args.share_of if args.share_of else world, count_work=True, fast_traversal=fast)
             fb2 = torch.zeros_like(fb)
             rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
             cst = rayrs_amd.render_finish(scene)
@@ -535,9 +542,10 @@ def main():
         return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6, "flights": F,
                 "frame_alone_ms": alone_ms,
                 "ms_per_step": max_elapsed / steps * 1e3, "rays_per_step": int(total_rays / steps),
-                "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares}
+                "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares,
+                "exact_walk": int(st["exact_walk"]), "local_pool": int(st["local_pool"])}
 
-    main_run = measure(cam_args, args.steps, args.warmup, not args.no_roofline)
+    main_run = measure(cam_args, args.steps, args.warmup, not args.no_roofline, fast=args.fast_traversal)
     W, H, chunk = main_run["W"], main_run["H"], main_run["chunk"]
 
     secondary = None
@@ -552,6 +560,23 @@ def main():
                      "records_per_ray": sec["roofline"]["records_per_ray"],
                      "prim_tests_per_ray": sec["roofline"]["prim_tests_per_ray"],
                      "roofline_frac": sec["roofline"]["frac"]}
+
+    fast_block = None
+    if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_fast
+            and not args.no_roofline and not args.fast_traversal and not main_run["local_pool"]):
+        fr = measure(cam_args, 3, 1, True, fast=True)
+        assert fr["sha"] == main_run["sha"], "the fast walk rendered another frame than the default walk"
+        assert fr["exact_walk"] == 0 and main_run["exact_walk"] == 1
+        fast_block = {"workload": "the headline frame by rayrs_render_params.fast_traversal = 1: closest-hit culling and tight "
+                                  "leaf boxes, two bets on the reference's arithmetic (measured, not proved: include/rayrs_hip.h); "
+                                  "the headline itself is the default walk, the reference's visit set by construction",
+                      "steps": 3, "warmup": 1, "value": round(fr["value"], 2), "unit": "Mray/s",
+                      "ms_per_step": round(fr["ms_per_step"], 2), "rays_per_step": fr["rays_per_step"],
+                      "records_per_ray": fr["roofline"]["records_per_ray"],
+                      "prim_tests_per_ray": fr["roofline"]["prim_tests_per_ray"],
+                      "traversal_ms": fr["roofline"]["kernels"]["wf_trav_kernel"]["ms"],
+                      "roofline_frac": fr["roofline"]["frac"], "lane_utilisation": fr["roofline"]["lane_utilisation"],
+                      "framebuffer_sha256": fr["sha"], "same_frame_as_headline": True}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -620,8 +645,13 @@ def main():
                 # frame_alone_ms the latency of a frame rendered with the GPU to itself
                 "frames_in_flight": main_run["flights"],
                 "frame_alone_ms": None if main_run["frame_alone_ms"] is None else round(main_run["frame_alone_ms"], 2),
+                # which walk answered the timed frames' BVH queries (rayrs_render_stats.exact_walk)
+                "walk": ("local pool: the gate tree's groups, nothing culled (the reference's visit set)" if main_run["local_pool"] else
+                         "default: the gate tree, nothing culled -- the reference's visit set by construction" if main_run["exact_walk"]
+                         else "fast_traversal: closest-hit culling + tight leaf boxes (two bets)"),
                 "layout": "compact f32 records" if info["compact"] else "f64 records",
-                "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"], "scene_bytes": info["device_bytes"],
+                "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"] if args.fast_traversal else info["gate_n_wide"],
+                "scene_bytes": info["device_bytes"],
                 "scene_build_s": round(build_s, 2), "source_hash": source_hash(),
                 "workload_key": workload_key(W, H, chunk), "collective": collective,
             },
@@ -634,6 +664,7 @@ def main():
             "roofline": main_run["roofline"],
             "cpu_baseline": cpu_baseline,
             "secondary": secondary,
+            "fast": fast_block,
         }
         print(json.dumps(line), flush=True)
 

@@ -123,7 +123,7 @@ typedef struct rayrs_scene rayrs_scene;
  * Consumes nothing: `objs` stays owned by the caller and may be destroyed
  * right after.  Builds the BVH exactly as Bvh::build does (bvh.rs:199-389,
  * same splits, same child order), derives the tree the kernels walk from it
- * (rayrs_scene_export_cert_tree; also rayrs_scene_export_gate_tree, rayrs_scene_export_wide) and uploads them to HIP device `device`.  device = -1 builds a host-only scene (no GPU needed) that can
+ * (rayrs_scene_export_wide) and uploads that to HIP device `device`.  device = -1 builds a host-only scene (no GPU needed) that can
  * be inspected with rayrs_scene_info / rayrs_scene_export_bvh but not
  * rendered.  hdri_rgb: hdri_w*hdri_h RGB f32 texels, row-major, image origin
  * upper left; values are clipped to [0, 3] as main.rs:43 does. */
@@ -144,20 +144,14 @@ typedef struct {
     uint64_t device_bytes; /* total scene footprint in HBM */
     double root_box[6];    /* xmin,xmax,ymin,ymax,zmin,zmax */
     double build_seconds;
-    uint32_t n_wide;        /* four-slot records of the tree the kernels walk by default (rayrs_scene_export_wide) */
+    uint32_t n_wide;        /* four-slot records of the tree the fast walk reads (rayrs_scene_export_wide) */
     uint32_t wide_root_ref;
     uint32_t wide_depth;    /* stack entries the traversal can need */
     uint32_t local_pool;    /* 1 = the gate tree is at most one record: renders keep every path in LDS
                                (rayrs_tuning.local_pool, local_pool.hip) */
     uint32_t gate_n_wide;   /* the same three for the gate tree (rayrs_scene_export_gate_tree), which */
-    uint32_t gate_root_ref; /* RAYRS_WALK_REFERENCE walks */
+    uint32_t gate_root_ref; /* the default walk reads */
     uint32_t gate_depth;
-    uint32_t cert_n_wide;   /* the same three for the certified tree (rayrs_scene_export_cert_tree), which */
-    uint32_t cert_root_ref; /* RAYRS_WALK_CERTIFIED, the default, walks */
-    uint32_t cert_depth;
-    uint32_t n_filtered;    /* group members that carry a certificate (0: the certified walk is the reference walk) */
-    double cert_center[3];  /* rays whose origin lies within cert_radius (max norm) of cert_center are inside the */
-    double cert_radius;     /* certified walk's theorem; the others are in doubt for every member */
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -180,22 +174,14 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
  * 1..4 leaves that share a parent Node, contiguous in depth-first order -- behind exactly its gating box; an
  * interior slot (kind 0) carries the union of the boxes below it, so a ray that misses it misses every gating box
  * inside.  Every group appears exactly once: the primitives this tree reaches are the primitives the reference
- * reaches.  Walked by RAYRS_WALK_REFERENCE and the source of the local-pool route's gates.
- *   rayrs_scene_export_wide (n = n_wide), the default: a leaf slot is ONE primitive behind its own bounding box
+ * reaches.  Walked by default, and the source of the local-pool route's gates.
+ *   rayrs_scene_export_wide (n = n_wide), what rayrs_render_params.fast_traversal walks: a leaf slot is ONE primitive behind its own bounding box
  * (Bvh::build's, geometry.rs bbox) widened on every side by 1/64 of its largest extent, rounded outwards to f32 and
- * clipped to its gating box.  It reaches a subset of what the reference reaches (RAYRS_WALK_FAST: what the subset
- * leaves out is a bet).
+ * clipped to its gating box.  It reaches a subset of what the reference reaches (see fast_traversal for what the
+ * subset leaves out: a bet).
  * tests/test_bvh_builder.py checks all of this from the exports alone. */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
-/*   rayrs_scene_export_cert_tree (n = cert_n_wide = gate_n_wide), what the default walk reads: the gate tree's
- * records once more, a group some of whose members carry a certificate marked kind 2 instead of 1 (payload
- * unchanged), and per primitive record (n_prims of them, depth-first order) its certificate word member_cert: 0 =
- * none (tested whenever the group is entered), else bit 31 | the triangle's unit normal times 127 as three signed
- * bytes.  A member gets a certificate when it is a sane triangle (rayrs_amd/csrc/scene_host.cpp build_cert_tree,
- * which states the theorem) whose bounding box, widened by 1/64 of its largest extent, has less than an eighth of
- * its gating box's area.  tests/test_bvh_builder.py re-derives every word from the objects. */
-int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* member_cert);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -217,7 +203,6 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 /* ---- render: the block loop of rayrs/src/main.rs:57-101 ---- */
 
 enum { RAYRS_OUT_F32 = 0, RAYRS_OUT_F64 = 1 };
-enum { RAYRS_WALK_CERTIFIED = 0, RAYRS_WALK_REFERENCE = 1, RAYRS_WALK_FAST = 2 }; /* rayrs_render_params.walk */
 
 typedef struct {
     uint32_t spp;          /* main.rs:68 */
@@ -233,33 +218,33 @@ typedef struct {
     uint32_t tile_rank, tile_ranks;
     uint32_t out_format;   /* RAYRS_OUT_F32: f32x3 (image.rs:224-229), RAYRS_OUT_F64: f64x3 */
     uint32_t count_work;   /* 1 = also count traversal work (slower; for the roofline figure) */
-    /* Which walk answers the BVH queries (RAYRS_WALK_*).  BvhTree::intersect tests every primitive whose enclosing
-     * Node boxes the ray enters and never compares a box with the closest hit so far (bvh.rs:391-415); all three walks
-     * return its closest hit (smallest accepted t, first primitive in depth-first order on ties, bvh.rs:62), they
-     * differ in what that claim rests on:
-     * RAYRS_WALK_CERTIFIED (0, the default): the reference's leaf groups behind exactly their gating boxes, nothing
-     *   culled by the closest hit, every member of an entered group tested -- except a member far smaller than its
-     *   gating box (a mesh triangle that shares a bottom Node with the 50 x 50 floor) whose own bounding box, widened by
-     *   1/64 of its size, the ray misses while lying more than about 2 % (cosine) off the triangle's plane: for such a
-     *   ray "the widened box is missed" implies "the reference's own Moeller-Trumbore rejects it" by a forward error
-     *   bound (rayrs_amd/csrc/scene_host.cpp build_cert_tree; rayrs_scene_export_cert_tree): the reference's answer
-     *   for EVERY ray, by construction plus that theorem.  Rays from farther than 4 half extents of the scene's bounding
-     *   box from its centre, or with non-finite / extreme directions, are outside the theorem and test every member.
-     * RAYRS_WALK_REFERENCE (1): the same with every member of an entered group tested: the reference's visit set BY
-     *   CONSTRUCTION, no theorem involved (rayrs_scene_export_gate_tree).  The local-pool route always walks this
-     *   way.  Cost on the headline frame: profiles/r05_walks.txt.
-     * RAYRS_WALK_FAST (2): two bets on the reference's arithmetic, each measured, neither proved (rounds 2-4's
-     *   default): closest-hit culling -- a box entered beyond best_t * (1 + 2^-10) is skipped -- and single
-     *   primitives behind their own widened boxes CLIPPED to the gating box in one tree of their own
-     *   (rayrs_scene_export_wide).  Both fail only for rays aimed nearly IN a primitive's plane, where
-     *   Moeller-Trumbore's result is rounding noise: culling within about 1e-7 rad of it (one such ray in 10^6), the
-     *   leaf boxes from thousands of scene sizes away (scripts/fuzz_traversal.py, profiles/r04_tight_leaves.txt;
-     *   tests/test_walk_tree.py pins one failing ray of each kind, on which the other two walks return the
-     *   reference's primitive); no rendered frame has differed in a bit.  For a camera farther from the scene's
-     *   bounding box than 8 of its diagonals the library walks RAYRS_WALK_REFERENCE instead.
-     * rayrs_render_stats.walk reports the walk a frame took.  (Until round 5 this field was `exact_traversal`, 0 =
-     * what is now RAYRS_WALK_FAST; 1 keeps its meaning.  Zero-initialise the struct: values above 2 are refused.) */
-    uint32_t walk;
+    /* Which walk answers the BVH queries.  BvhTree::intersect tests every primitive whose enclosing Node boxes the
+     * ray enters and never compares a box with the closest hit so far (bvh.rs:391-415).
+     * 0 (default): the walk over the reference's leaf groups behind their exact gating boxes
+     *   (rayrs_scene_export_gate_tree) with nothing culled: it tests exactly the primitives the reference tests, so
+     *   its closest hit (smallest accepted t, first primitive in depth-first order on ties, bvh.rs:62) is the
+     *   reference's for EVERY ray BY CONSTRUCTION.  The local-pool route walks this way too.
+     * 1: the fast walk, which makes two bets on the reference's arithmetic, each measured, neither a construction
+     *   (it was the default until round 5; the headline frame renders 23 % faster with it, profiles/r05_walks.txt):
+     *   - closest-hit culling: a box entered beyond best_t * (1 + 2^-10) is skipped -- the reference's answer
+     *     unless a primitive's COMPUTED t lies more than that in front of a box around it;
+     *   - tight leaf boxes (rayrs_scene_export_wide): a primitive is tested only if the ray enters its own bounding
+     *     box widened by 1/64 of its size (inside the reference's gating box, so nothing extra is ever tested) --
+     *     the reference's answer unless its own test accepts a hit on a primitive the ray passes beside by more
+     *     than that.
+     *   Both fail only for rays aimed nearly IN a primitive's plane, where Moeller-Trumbore's own result is rounding
+     *   noise: culling within about 1e-7 rad of it (one such ray in 10^6 from nearby), the leaf boxes only from
+     *   thousands of primitive sizes away (a few in 10^4 of such rays, up to 1e-5 rad off the plane) --
+     *   scripts/fuzz_traversal.py counts them, profiles/r04_tight_leaves.txt; tests/test_walk_tree.py pins one failing
+     *   ray of each kind, on which the default walk returns the reference's primitive; no rendered frame, of any size,
+     *   has differed in a bit.  For a camera that stands farther from the scene's bounding box than 8 times that box's
+     *   diagonal, or than 2^16 times the scene's smallest primitive extent (5th percentile), the library takes the
+     *   default walk all the same (rayrs_render_stats.exact_walk reports the walk a frame took).
+     * What a sound walk costs, and what certificates (a forward error bound of Moeller-Trumbore deciding where "box
+     * missed" provably means "rejected") could and could not buy back: profiles/r05_certified_walks.txt, DESIGN.md 2.
+     * Zero-initialise the struct: values above 1 are refused (RAYRS_INVALID_ARG).  (Until round 5 this field was
+     * `exact_traversal` with the opposite sense.) */
+    uint32_t fast_traversal;
 } rayrs_render_params;
 
 typedef struct {
@@ -295,9 +280,9 @@ typedef struct {
     double hit_ms, miss_ms; /* summed HIP-event times of the hit and the miss kernel's launches (kernel_ms: the traversal
                                kernel's, or the local-pool kernel's, which is then the only one) */
     uint32_t local_pool;    /* 1 = this frame was rendered by the local-pool kernel (rayrs_tuning.local_pool) */
-    uint32_t walk;          /* the RAYRS_WALK_* this frame's queries were answered by: the one asked for; RAYRS_WALK_REFERENCE
-                               when the local-pool route rendered the frame, or in place of RAYRS_WALK_FAST for a camera
-                               farther than 8 scene diagonals from the scene */
+    uint32_t exact_walk;    /* 1 = this frame's queries were answered by the reference's visit set (the default); 0 = by the
+                               fast walk (rayrs_render_params.fast_traversal = 1, the camera near enough, the streaming
+                               route: the local-pool route never makes the bets) */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:
@@ -368,8 +353,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);
 int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out);
 int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
                    uint64_t n, uint64_t* out_bits);
-/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  walk: RAYRS_WALK_* */
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int walk, double* t,
+/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  exact: 1 = the default walk, 0 = the fast one */
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
                          int64_t* object);
 /* Material::evaluate for n (normal, view, key) tuples with one material:
  * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */

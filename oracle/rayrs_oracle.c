@@ -863,8 +863,6 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
-    uint32_t* member_cert; /* n_prims: the product's certificate words (orc_set_member_certs), or NULL */
-    double cert_center[3], cert_radius;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -881,7 +879,6 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->prim_object);
     free(s->wide_box);
     free(s->wide_ref);
-    free(s->member_cert);
     free(s);
 }
 
@@ -1314,23 +1311,6 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
-    free(s->member_cert);
-    s->member_cert = NULL;
-    return 0;
-}
-
-/* The product's certified tree (rayrs_scene_export_cert_tree) is its gate tree with some groups marked kind 2
- * ("filtered") plus one certificate word per primitive; handing the words over after orc_set_wide makes traversal 2
- * the product's CERTIFIED walk (rayrs_amd/csrc/device_path.h trav_leaf_step<..., WALK_CERT>, restated in isect_wide
- * below): nothing culled, and a member of a filtered group that carries a certificate skipped when the segment
- * misses its bounding box widened by 1/64 of its largest extent and the ray is not in doubt for it. */
-int orc_set_member_certs(orc_scene* s, const uint32_t* member_cert, const double center[3], double radius) {
-    if (!s || !s->have_wide || !member_cert) return -1;
-    free(s->member_cert);
-    s->member_cert = (uint32_t*)malloc(((size_t)s->finfo.n_prims + 1) * sizeof(uint32_t));
-    memcpy(s->member_cert, member_cert, (size_t)s->finfo.n_prims * sizeof(uint32_t));
-    for (int k = 0; k < 3; k++) s->cert_center[k] = center[k];
-    s->cert_radius = radius;
     return 0;
 }
 
@@ -1561,34 +1541,6 @@ static isect_t isect_ordered(const orc_scene* s, ray_t ray, double tmin, double 
     return best;
 }
 
-/* The certified walk's view of a ray (rayrs_amd/csrc/layout.h, device_path.h cert_ray_word): its direction as
- * three signed bytes (dx, dy, dz), scaled to length 127, rounded to nearest even; (0, 0, 0) for a ray
- * outside the theorem's premises (scene_host.cpp build_cert_tree (5)). */
-static uint32_t cert_ray_word(const orc_scene* s, ray_t ray) {
-    const double o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
-    double m = 0.0;
-    for (int k = 0; k < 3; k++) {
-        if (!(rr_fabs(o[k] - s->cert_center[k]) <= s->cert_radius)) return 0u; /* NaN: outside */
-        if (!(rr_fabs(d[k]) <= 0x1p400)) return 0u;
-        if (rr_fabs(d[k]) > m) m = rr_fabs(d[k]);
-    }
-    if (!(m >= 0x1p-400)) return 0u;
-    const double sc = 127.0 / rr_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    uint32_t w = 0u;
-    for (int k = 0; k < 3; k++) {
-        const int q = (int)nearbyint(d[k] * sc);
-        w |= ((uint32_t)q & 0xffu) << (8 * k);
-    }
-    return w;
-}
-/* in doubt: |dx nx + dy ny + dz nz| < 320 (layout.h CERT_THRESHOLD); a ray outside the premises (word 0) always is */
-static int cert_in_doubt(uint32_t ray_word, uint32_t member_word) {
-    int sum = 0;
-    for (int k = 0; k < 3; k++) sum += (int)(int8_t)(ray_word >> (8 * k)) * (int)(int8_t)(member_word >> (8 * k));
-    if (sum < 0) sum = -sum;
-    return sum < 320;
-}
-
 /* Diagnostics: when set, isect_wide adds one to hist[record] per visit and to
  * hist[n_wide + min(sp, 63)] the stack height seen at each visit (single-threaded use). */
 static uint64_t* g_visit_hist = NULL;
@@ -1615,8 +1567,6 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
     int sp = 0;
     uint32_t cur = s->finfo.wide_root_ref;
-    const int certified = s->member_cert != NULL; /* the certified walk: nothing culled, member filters consulted */
-    const uint32_t ray_word = certified ? cert_ray_word(s, ray) : 0u;
     for (;;) {
         if ((cur >> 30) == REF_KIND_INTERIOR) {
             uint32_t rec = cur & 0x3fffffffu;
@@ -1632,10 +1582,7 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                 uint32_t kind = refs[c] >> 30;
                 hit[c] = 0;
                 ent[c] = 0.0;
-                if (certified) {
-                    if (kind != REF_KIND_NONE)
-                        hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
-                } else if (kind == REF_KIND_SINGLE) {
+                if (kind == REF_KIND_SINGLE) {
                     hit[c] = 1;
                     ent[c] = tmin;
                 } else if (kind != REF_KIND_NONE) {
@@ -1664,31 +1611,10 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
         } else {
             uint32_t first = (cur & 0x3fffffffu) >> 2;
             uint32_t count = (cur & 3u) + 1u;
-            const int filtered = certified && (cur >> 30) == 2u; /* REF_FILTERED */
             for (uint32_t k = 0; k < count; k++) {
                 uint32_t p = first + k;
                 int obj = (int)s->prim_object[p];
                 const shape_t* g = &s->objs[obj].geom;
-                if (filtered && g->kind == ORC_SHAPE_TRIANGLE && (s->member_cert[p] >> 31) &&
-                    !cert_in_doubt(ray_word, s->member_cert[p])) {
-                    /* the member's bounding box widened by 2^-6 of its largest extent (device_path.h member_box_missed) */
-                    const double c[3][3] = {{g->p1.x, g->p2.x, g->p3.x}, {g->p1.y, g->p2.y, g->p3.y}, {g->p1.z, g->p2.z, g->p3.z}};
-                    double lo[3], hi[3], bx[6], e_unused;
-                    for (int a = 0; a < 3; a++) {
-                        double l = c[a][0], h = c[a][0];
-                        if (c[a][1] < l) l = c[a][1];
-                        if (c[a][2] < l) l = c[a][2];
-                        if (c[a][1] > h) h = c[a][1];
-                        if (c[a][2] > h) h = c[a][2];
-                        lo[a] = l, hi[a] = h;
-                    }
-                    double ext = hi[0] - lo[0];
-                    if (hi[1] - lo[1] > ext) ext = hi[1] - lo[1];
-                    if (hi[2] - lo[2] > ext) ext = hi[2] - lo[2];
-                    const double m = ext * 0x1p-6;
-                    for (int a = 0; a < 3; a++) bx[2 * a] = lo[a] - m, bx[2 * a + 1] = hi[a] + m;
-                    if (!aabb_intersect_entry(bx, ray, inv, tmin, tmax, &e_unused)) continue; /* the reference rejects it: theorem */
-                }
                 if (cnt) {
                     if (g->kind == ORC_SHAPE_TRIANGLE) cnt->tri_tests++;
                     else if (g->kind == ORC_SHAPE_SPHERE) cnt->sphere_tests++;

@@ -199,11 +199,6 @@ int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide
  * traversal 2 walks them.  The oracle does not build that tree itself. */
 int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
                  const uint32_t* wide_ref);
-/* The certificate words of the product's certified tree (rayrs_scene_export_cert_tree), after orc_set_wide with that
- * tree's records: traversal 2 then makes the product's certified walk (nothing culled -- set the cull margin to
- * infinity --; in a group of kind 2 a triangle with a certificate is skipped when the segment misses its bounding box
- * widened by 1/64 of its largest extent and the ray is not in doubt for it). */
-int orc_set_member_certs(orc_scene* s, const uint32_t* member_cert /* n_prims */, const double center[3], double radius);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

@@ -17,7 +17,7 @@ SYMBOLS = [
     "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
     "rayrs_object_from_spheres", "rayrs_object_box_geom",
     "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
-    "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_export_cert_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
+    "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
     "rayrs_camera_new",
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout",
@@ -52,15 +52,13 @@ class SceneInfo(C.Structure):
                 ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
                 ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
                 ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32), ("gate_n_wide", C.c_uint32),
-                ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32), ("cert_n_wide", C.c_uint32),
-                ("cert_root_ref", C.c_uint32), ("cert_depth", C.c_uint32), ("n_filtered", C.c_uint32),
-                ("cert_center", C.c_double * 3), ("cert_radius", C.c_double)]
+                ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("max_bounces", C.c_uint32), ("seed", C.c_uint64),
                 ("sample_chunk", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_ranks", C.c_uint32),
-                ("out_format", C.c_uint32), ("count_work", C.c_uint32), ("walk", C.c_uint32)]
+                ("out_format", C.c_uint32), ("count_work", C.c_uint32), ("fast_traversal", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -72,7 +70,7 @@ class RenderStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
-                ("local_pool", C.c_uint32), ("walk", C.c_uint32)]
+                ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -135,7 +133,6 @@ def lib():
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
     L.rayrs_scene_export_gate_tree.argtypes = [vp, vp, vp]
-    L.rayrs_scene_export_cert_tree.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]

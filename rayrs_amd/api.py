@@ -325,9 +325,8 @@ class Scene:
     def info(self) -> dict:
         i = _ffi.SceneInfo()
         _ffi.check(self._L.rayrs_scene_info(self._h, C.byref(i)), "rayrs_scene_info")
-        d = {n: getattr(i, n) for n, _ in i._fields_ if n not in ("root_box", "cert_center")}
+        d = {n: getattr(i, n) for n, _ in i._fields_ if n != "root_box"}
         d["root_box"] = list(i.root_box)
-        d["cert_center"] = list(i.cert_center)
         return d
 
     def export_bvh(self):
@@ -340,7 +339,7 @@ class Scene:
         return box[:i["n_interior"]], ref[:i["n_interior"]], prim[:i["n_prims"]]
 
     def export_wide(self):
-        """The four-slot records the kernels walk by default: (box[n_wide,4,6], ref[n_wide,4])."""
+        """The four-slot records the fast walk reads: (box[n_wide,4,6], ref[n_wide,4])."""
         i = self.info()
         box = np.zeros((max(i["n_wide"], 1), 4, 6), dtype=np.float64)
         ref = np.zeros((max(i["n_wide"], 1), 4), dtype=np.uint32)
@@ -349,7 +348,7 @@ class Scene:
         return box[:i["n_wide"]], ref[:i["n_wide"]]
 
     def export_gate_tree(self):
-        """The records WALK_REFERENCE walks (the reference's leaf groups behind their gating boxes):
+        """The records the default walk reads (the reference's leaf groups behind their gating boxes):
         (box[gate_n_wide,4,6], ref[gate_n_wide,4])."""
         i = self.info()
         box = np.zeros((max(i["gate_n_wide"], 1), 4, 6), dtype=np.float64)
@@ -357,18 +356,6 @@ class Scene:
         _ffi.check(self._L.rayrs_scene_export_gate_tree(self._h, box.ctypes.data, ref.ctypes.data),
                    "rayrs_scene_export_gate_tree")
         return box[:i["gate_n_wide"]], ref[:i["gate_n_wide"]]
-
-    def export_cert_tree(self):
-        """What the default (certified) walk reads: (box[cert_n_wide,4,6], ref[cert_n_wide,4], member_cert[n_prims])
-        -- the gate tree's records with the filtered groups marked kind 2, and every primitive's certificate word."""
-        i = self.info()
-        n = i["cert_n_wide"]
-        box = np.zeros((max(n, 1), 4, 6), dtype=np.float64)
-        ref = np.zeros((max(n, 1), 4), dtype=np.uint32)
-        mcert = np.zeros(max(i["n_prims"], 1), dtype=np.uint32)
-        _ffi.check(self._L.rayrs_scene_export_cert_tree(self._h, box.ctypes.data, ref.ctypes.data, mcert.ctypes.data),
-                   "rayrs_scene_export_cert_tree")
-        return box[:n], ref[:n], mcert[:i["n_prims"]]
 
     def close(self):
         if self._h is not None:
@@ -389,32 +376,23 @@ def frame_sample_chunk(width: int, height: int, spp: int, requested: int = 4) ->
     return int(_ffi.lib().rayrs_frame_sample_chunk(int(width), int(height), int(spp), int(requested)))
 
 
-WALK_CERTIFIED, WALK_REFERENCE, WALK_FAST = 0, 1, 2  # include/rayrs_hip.h RAYRS_WALK_*
-
-
-def _walk_of(walk, exact_traversal):
-    """exact_traversal=True is the pre-round-5 spelling of walk=WALK_REFERENCE."""
-    if exact_traversal:
-        return WALK_REFERENCE
-    if isinstance(walk, str):
-        return {"certified": WALK_CERTIFIED, "reference": WALK_REFERENCE, "fast": WALK_FAST}[walk]
-    return int(walk)
-
-
 def make_params(spp, max_bounces=50, seed=0x5EED, sample_chunk=0, tile_rank=0, tile_ranks=1, out_f64=False,
-                count_work=False, exact_traversal=False, walk=WALK_CERTIFIED) -> _ffi.RenderParams:
+                count_work=False, exact_traversal=True, fast_traversal=None) -> _ffi.RenderParams:
+    """exact_traversal=True (the default): the reference's visit set by construction; False, or fast_traversal=True:
+    the fast walk (include/rayrs_hip.h rayrs_render_params.fast_traversal)."""
     p = _ffi.RenderParams()
     p.spp, p.max_bounces, p.seed = int(spp), int(max_bounces), int(seed)
     p.sample_chunk, p.tile_rank, p.tile_ranks = int(sample_chunk), int(tile_rank), int(tile_ranks)
     p.out_format = 1 if out_f64 else 0
     p.count_work = 1 if count_work else 0
-    p.walk = _walk_of(walk, exact_traversal)
+    fast = (not exact_traversal) if fast_traversal is None else bool(fast_traversal)
+    p.fast_traversal = 1 if fast else 0
     return p
 
 
 def render(scene: Scene, camera: Camera, spp: int, max_bounces: int = 50, seed: int = 0x5EED, sample_chunk: int = 0,
            tile_rank: int = 0, tile_ranks: int = 1, out_f64: bool = False, count_work: bool = False, out=None,
-           exact_traversal: bool = False, walk=WALK_CERTIFIED):
+           exact_traversal: bool = True, fast_traversal=None):
     """The block loop of rayrs/src/main.rs:57-101 on the GPU.
 
     Returns (image, stats): image is (y_pixels, x_pixels, 3), f32 (what
@@ -428,7 +406,8 @@ def render(scene: Scene, camera: Camera, spp: int, max_bounces: int = 50, seed: 
     if out is None:
         out = np.zeros((H, W, 3), dtype=dt)
     assert out.shape == (H, W, 3) and out.dtype == dt and out.flags.c_contiguous
-    p = make_params(spp, max_bounces, seed, sample_chunk, tile_rank, tile_ranks, out_f64, count_work, exact_traversal, walk)
+    p = make_params(spp, max_bounces, seed, sample_chunk, tile_rank, tile_ranks, out_f64, count_work, exact_traversal,
+                    fast_traversal)
     st = _ffi.RenderStats()
     _ffi.check(L.rayrs_render(scene._h, C.byref(camera.desc), C.byref(p), out.ctypes.data, C.byref(st)),
                "rayrs_render")

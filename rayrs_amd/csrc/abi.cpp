@@ -234,8 +234,8 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 // five workgroups (the kernel's launch bound) share a CU's 160 KiB.
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;
-    for (int x = 0; x < 3; x++) {
-        const WalkTree& t = s->tree(x);
+    for (int x = 0; x < 2; x++) {
+        const WalkTree& t = s->tree(x != 0);
         rayrs_scene::Walk& w = s->trav[x];
         const uint32_t depth = t.depth ? t.depth : 1;
         uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
@@ -245,7 +245,7 @@ static int scene_configure_traversal(rayrs_scene* s) {
         if (s->lab.hot_records == 0xffffffffu) hot = 0;
         else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
         w.hot_records = hot < t.n() ? hot : t.n();
-        HIP_TRY(wf_trav_occupancy(f.compact, x == 2 ? WALK_CERT : x == 1 ? WALK_REFERENCE : WALK_FAST, w.stack_lds, w.hot_records, &w.blocks_per_cu));
+        HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.hot_records, &w.blocks_per_cu));
         if (w.blocks_per_cu < 1) w.blocks_per_cu = 1;
     }
     return RAYRS_OK;
@@ -294,8 +294,8 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->cu_count = prop.multiProcessorCount;
     const FlatScene& f = s->flat;
-    for (int x = 0; x < 3; x++) {
-        const WalkTree& t = s->tree(x);
+    for (int x = 0; x < 2; x++) {
+        const WalkTree& t = s->tree(x != 0);
         HIP_TRY(hipMalloc(&s->trav[x].d_nodes, t.node_bytes.size()));
         HIP_TRY(hipMemcpy(s->trav[x].d_nodes, t.node_bytes.data(), t.node_bytes.size(), hipMemcpyHostToDevice));
     }
@@ -308,7 +308,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.cert.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -343,8 +343,8 @@ int rayrs_scene_new(const rayrs_objects* objs, double z_near, double z_far, int 
     // Every traversal lane gets a stack of WalkTree::depth entries (12 in LDS, the rest in HBM: 1.3 MB per entry on a
     // 256-CU device).  The reference recurses as deep as its tree; a tree that needs more than 4096 pending
     // entries (a chain of thousands of nested objects) is refused instead of allocating gigabytes for it.
-    if (std::max(s->flat.walk.depth, s->flat.cert.depth) > 4096u) {  // (cert.depth >= gate.depth)
-        g_last_error = "walk tree needs " + std::to_string(std::max(s->flat.walk.depth, s->flat.cert.depth)) + " stack entries (limit 4096)";
+    if (std::max(s->flat.walk.depth, s->flat.gate.depth) > 4096u) {
+        g_last_error = "walk tree needs " + std::to_string(std::max(s->flat.walk.depth, s->flat.gate.depth)) + " stack entries (limit 4096)";
         return RAYRS_UNSUPPORTED;
     }
     s->surfaces = objs->list.surfaces;
@@ -381,12 +381,6 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->gate_n_wide = f.gate.n();
     info->gate_root_ref = f.gate.root_ref;
     info->gate_depth = f.gate.depth;
-    info->cert_n_wide = f.cert.n();
-    info->cert_root_ref = f.cert.root_ref;
-    info->cert_depth = f.cert.depth;
-    for (int i = 0; i < 3; i++) info->cert_center[i] = f.cert_center[i];
-    info->cert_radius = f.cert_radius;
-    info->n_filtered = f.n_filtered;
     info->local_pool = (scene->local_ok && scene->tuning.local_pool != 1u) ? 1u : 0u;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
@@ -418,15 +412,6 @@ int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uin
     const WalkTree& t = scene->flat.gate;
     if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
     if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
-    return RAYRS_OK;
-}
-
-int rayrs_scene_export_cert_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref, uint32_t* member_cert) {
-    if (!scene) return RAYRS_INVALID_ARG;
-    const WalkTree& t = scene->flat.cert;
-    if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
-    if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
-    if (member_cert && scene->flat.n_prims()) std::memcpy(member_cert, scene->flat.member_cert.data(), (size_t)scene->flat.n_prims() * 4);
     return RAYRS_OK;
 }
 
@@ -543,7 +528,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_camera, origin), RAYRS_FIELD(rayrs_camera, e_x), RAYRS_FIELD(rayrs_camera, e_y);
     RAYRS_FIELD(rayrs_camera, z), RAYRS_FIELD(rayrs_camera, width), RAYRS_FIELD(rayrs_camera, height);
     RAYRS_FIELD(rayrs_camera, ppc), RAYRS_FIELD(rayrs_camera, x_pixels), RAYRS_FIELD(rayrs_camera, y_pixels);
-    RAYRS_STRUCT(rayrs_scene_info_t, 25);
+    RAYRS_STRUCT(rayrs_scene_info_t, 19);
     RAYRS_FIELD(rayrs_scene_info_t, n_objects), RAYRS_FIELD(rayrs_scene_info_t, n_interior);
     RAYRS_FIELD(rayrs_scene_info_t, n_prims), RAYRS_FIELD(rayrs_scene_info_t, root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, depth), RAYRS_FIELD(rayrs_scene_info_t, compact);
@@ -554,15 +539,12 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, local_pool);
     RAYRS_FIELD(rayrs_scene_info_t, gate_n_wide), RAYRS_FIELD(rayrs_scene_info_t, gate_root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, gate_depth);
-    RAYRS_FIELD(rayrs_scene_info_t, cert_n_wide), RAYRS_FIELD(rayrs_scene_info_t, cert_root_ref);
-    RAYRS_FIELD(rayrs_scene_info_t, cert_depth), RAYRS_FIELD(rayrs_scene_info_t, n_filtered), RAYRS_FIELD(rayrs_scene_info_t, cert_center);
-    RAYRS_FIELD(rayrs_scene_info_t, cert_radius);
     RAYRS_STRUCT(rayrs_render_params, 9);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
-    RAYRS_FIELD(rayrs_render_params, walk);
+    RAYRS_FIELD(rayrs_render_params, fast_traversal);
     RAYRS_STRUCT(rayrs_render_stats, 26);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
@@ -576,7 +558,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, trace_ms), RAYRS_FIELD(rayrs_render_stats, refill_ticks);
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
-    RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, walk);
+    RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, exact_walk);
     RAYRS_STRUCT(rayrs_tuning, 2);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
 #undef RAYRS_STRUCT
@@ -594,22 +576,14 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 
 // ------------------------------------------------------------------ render
 
-// Which of the scene's three trees a walk reads: [0] FlatScene::walk (RAYRS_WALK_FAST), [1] FlatScene::gate
-// (RAYRS_WALK_REFERENCE; rayrs_lab.h gate_tree: the fast walk on it), [2] FlatScene::cert (RAYRS_WALK_CERTIFIED).
-static int tree_of(const rayrs_scene* s, uint32_t walk) {
-    if (walk == RAYRS_WALK_CERTIFIED) return 2;
-    return (walk == RAYRS_WALK_REFERENCE || s->lab.gate_tree != 0u) ? 1 : 0;
-}
-
-static SceneDev make_scene_dev(const rayrs_scene* s, uint32_t walk) {
+static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
-    const int x = tree_of(s, walk);
-    const WalkTree& t = s->tree(x);
-    const rayrs_scene::Walk& w = s->trav[x];
+    const bool gate = exact || s->lab.gate_tree != 0u;
+    const WalkTree& t = s->tree(gate);
+    const rayrs_scene::Walk& w = s->trav[gate ? 1 : 0];
     sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
-    sc.n_filtered = s->flat.n_filtered;
     sc.surfaces = s->d_surfaces;
     sc.hdri = s->d_hdri;
     sc.hdri_w = s->flat.hdri_w;
@@ -624,19 +598,21 @@ static SceneDev make_scene_dev(const rayrs_scene* s, uint32_t walk) {
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
-    sc.walk = walk == RAYRS_WALK_CERTIFIED ? (uint32_t)WALK_CERT : walk == RAYRS_WALK_REFERENCE ? (uint32_t)WALK_REFERENCE : (uint32_t)WALK_FAST;
-    for (int i = 0; i < 3; i++) sc.cert_center[i] = s->flat.cert_center[i];
-    sc.cert_radius = s->flat.cert_radius;
+    sc.exact = exact ? 1u : 0u;
     return sc;
 }
 
-// The default walk's leaf boxes are a bet on the reference's arithmetic that was measured to hold for rays from within
-// ten scene sizes of the scene and to fail, a few times in 10^4, for rays aimed along a primitive's plane from thousands
-// of scene sizes away (include/rayrs_hip.h exact_traversal; profiles/r04_tight_leaves.txt).  Bounce rays start on the
-// scene's surfaces; only a camera can stand that far out.  So the bet is only made where it was measured: a frame whose
-// camera is farther from the root Node's box than RAYRS_EXACT_CAMERA_DISTANCE times that box's diagonal takes the exact
-// walk without being asked (rayrs_render_stats.exact_walk says which walk a frame took).
-constexpr double RAYRS_EXACT_CAMERA_DISTANCE = 8.0;
+// The fast walk's leaf boxes are a bet on the reference's arithmetic that was measured to hold for rays from nearby and
+// to fail, a few times in 10^4, for rays aimed along a primitive's plane from far away (include/rayrs_hip.h
+// fast_traversal; profiles/r04_tight_leaves.txt).  What decides is the distance in PRIMITIVE sizes (the error of the
+// computed hit point is about eps * distance / angle against a widening of 1/64 of the primitive): failures were seen from
+// 6,000 primitive sizes up, none within 4,000 (sheets of 6 ... 400 quads per side: scripts/fuzz_traversal.py).
+// Bounce rays start on the scene's surfaces; only a camera can stand far out.  So the bet is only made where it was
+// measured: a frame whose camera is farther from the root Node's box than RAYRS_FAR_DIAGONALS times that box's diagonal,
+// or than RAYRS_FAR_PRIMITIVES times the scene's small primitives (the 5th percentile of their largest extents), takes
+// the default walk whatever was asked (rayrs_render_stats.exact_walk says which walk a frame took).
+constexpr double RAYRS_FAR_DIAGONALS = 8.0;
+constexpr double RAYRS_FAR_PRIMITIVES = 4096.0;
 static bool camera_is_far(const rayrs_scene* s, const rayrs_camera* c) {
     const double* b = s->flat.root_box;
     double d2 = 0.0, e2 = 0.0;
@@ -646,8 +622,9 @@ static bool camera_is_far(const rayrs_scene* s, const rayrs_camera* c) {
         d2 += out * out;
         e2 += (hi - lo) * (hi - lo);
     }
-    // (a box or an origin that is not a number compares false: the default walk, as for any other frame)
-    return d2 > RAYRS_EXACT_CAMERA_DISTANCE * RAYRS_EXACT_CAMERA_DISTANCE * e2;
+    // (a box or an origin that is not a number compares false: the walk that was asked for, as for any other frame)
+    const double small = s->flat.small_extent;
+    return d2 > RAYRS_FAR_DIAGONALS * RAYRS_FAR_DIAGONALS * e2 || (small > 0.0 && d2 > RAYRS_FAR_PRIMITIVES * RAYRS_FAR_PRIMITIVES * small * small);
 }
 
 static CameraDev make_camera_dev(const rayrs_camera* c) {
@@ -680,7 +657,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     if (params->spp > SLOT_SAMPLE_MASK) return RAYRS_UNSUPPORTED;     // a slot's sample cursor has 30 bits
     if (params->tile_ranks == 0 || params->tile_rank >= params->tile_ranks) return RAYRS_INVALID_ARG;
     if (params->out_format != RAYRS_OUT_F32 && params->out_format != RAYRS_OUT_F64) return RAYRS_INVALID_ARG;
-    if (params->walk > RAYRS_WALK_FAST) return RAYRS_INVALID_ARG;
+    if (params->fast_traversal > 1u) return RAYRS_INVALID_ARG;
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (scene->pending) {  // one render in flight per scene: its counters and partial sums are shared
@@ -708,7 +685,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
     rp.refill_min = lab.refill_min ? lab.refill_min : 52u;
-    rp.leaf_min = lab.leaf_min ? lab.leaf_min : 24u;  // (32 while a leaf slot held a group of up to four primitives: 612 -> 604 ms of traversal on the headline frame)
+    // (a leaf phase once this many lanes stand on a leaf: 24 where a leaf is one primitive -- the fast walk's tree: 612 -> 604 ms
+    // of traversal on the headline frame against 32 --, 32 where it is a group of up to four -- the default walk: 988 -> 962 ms
+    // against 24; it is set below, once the walk is known)
     rp.count_work = params->count_work ? 1u : 0u;
     rp.out_format = params->out_format;
     rp.out = out_device;
@@ -737,10 +716,10 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.partial = scene->d_partial;
     rp.partial_item0 = 0;
 
-    // (the fast walk's bets are only made for cameras near the scene: camera_is_far above)
-    const uint32_t walk = (params->walk == RAYRS_WALK_FAST && camera_is_far(scene, camera)) ? (uint32_t)RAYRS_WALK_REFERENCE : params->walk;
-    scene->last_walk = walk;
-    const SceneDev sc = make_scene_dev(scene, walk);
+    const bool exact = params->fast_traversal == 0u || camera_is_far(scene, camera);
+    scene->last_exact = exact;
+    rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
+    const SceneDev sc = make_scene_dev(scene, exact);
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
@@ -767,7 +746,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->trav[tree_of(scene, walk)].blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[(exact || lab.gate_tree) ? 1 : 0].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;
@@ -998,7 +977,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->kernel_ms = t;
         stats->hit_ms = h, stats->miss_ms = m;
         stats->local_pool = scene->last_local ? 1u : 0u;
-        stats->walk = scene->last_local ? (uint32_t)RAYRS_WALK_REFERENCE : scene->last_walk;
+        stats->exact_walk = (scene->last_exact || scene->last_local) ? 1u : 0u;
         stats->kernel_launches = (uint64_t)scene->rounds;
     }
     return RAYRS_OK;
@@ -1086,9 +1065,9 @@ int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint6
     return dout.download(out_bits, n * 8);
 }
 
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int walk, double* t,
+int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
                          int64_t* object) {
-    if (!scene || !o || !d || !t || !object || walk < 0 || walk > RAYRS_WALK_FAST) return RAYRS_INVALID_ARG;
+    if (!scene || !o || !d || !t || !object) return RAYRS_INVALID_ARG;
     if (scene->device < 0) return RAYRS_NO_DEVICE;
     HIP_TRY(hipSetDevice(scene->device));
     DevBuf dorg, ddir, dt, dprim;
@@ -1096,7 +1075,7 @@ int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, u
     ST_TRY(ddir.upload(d, n * 24));
     ST_TRY(dt.alloc(n * 8));
     ST_TRY(dprim.alloc(n * 8));
-    const SceneDev sc = make_scene_dev(scene, (uint32_t)walk);
+    const SceneDev sc = make_scene_dev(scene, exact != 0);
     DevBuf dspill;  // stack entries beyond the LDS part, one strip per thread of the launch
     const uint64_t threads = (n + 255) / 256 * 256;
     if (sc.stack_depth > sc.stack_lds) ST_TRY(dspill.alloc((size_t)(sc.stack_depth - sc.stack_lds) * threads * 4));
@@ -1148,7 +1127,7 @@ int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, dou
     DevBuf dd, dout;
     ST_TRY(dd.upload(dir, n * 24));
     ST_TRY(dout.alloc(n * 24));
-    const SceneDev sc = make_scene_dev(scene, RAYRS_WALK_CERTIFIED);
+    const SceneDev sc = make_scene_dev(scene, false);
     if (n) HIP_TRY(launch_test_background(sc, (const double*)dd.p, n, (double*)dout.p, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     return dout.download(rgb, n * 24);

@@ -317,7 +317,6 @@ struct Trav {
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
     int sp;
-    uint32_t dq;         // WALK_CERT: the ray's direction as three signed bytes (cert_ray_word)
 };
 
 // What BvhTree::intersect does first (bvh.rs:394): the box of the root Node.  A ray that misses it
@@ -331,40 +330,11 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// The ray as the certified walk's certificates see it (layout.h MemberFilter): (dx, dy, dz), the direction scaled to
-// length 127 and rounded to nearest even, or (0, 0, 0) for a ray outside the theorem's premises -- origin farther than
-// cert_radius (max norm) from cert_center, a component of the direction that is not finite or beyond 2^400, or a
-// largest component below 2^-400 -- which is then in doubt for every member.  The CPU checker restates the same
-// arithmetic (a dot product, an IEEE square root and division, three products, round to nearest even), so both
-// sides see the same word.
-RR_DEV uint32_t cert_ray_word(const SceneDev& sc, V3 o, V3 d) {
-    const double ax = rr_fabs(d.x), ay = rr_fabs(d.y), az = rr_fabs(d.z);
-    double m = ax;
-    if (ay > m) m = ay;
-    if (az > m) m = az;
-    const bool inside = rr_fabs(o.x - sc.cert_center[0]) <= sc.cert_radius && rr_fabs(o.y - sc.cert_center[1]) <= sc.cert_radius &&
-                        rr_fabs(o.z - sc.cert_center[2]) <= sc.cert_radius && ax <= 0x1p400 && ay <= 0x1p400 && az <= 0x1p400 &&
-                        m >= 0x1p-400;  // (NaN compares false everywhere)
-    const double s = 127.0 / rr_sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
-    const int qx = (int)__builtin_rint(d.x * s), qy = (int)__builtin_rint(d.y * s), qz = (int)__builtin_rint(d.z * s);
-    const uint32_t w = ((uint32_t)qx & 0xffu) | (((uint32_t)qy & 0xffu) << 8) | (((uint32_t)qz & 0xffu) << 16);
-    return inside ? w : CERT_RAY_OUTSIDE;
-}
-
-// |dx nx + dy ny + dz nz| < CERT_THRESHOLD: one v_dot4_i32_i8 (the ray word's fourth byte is zero) with the threshold
-// folded into its accumulator, and one unsigned compare.
-RR_DEV bool cert_in_doubt(uint32_t ray_word, uint32_t member_word) {
-    const int sum = __builtin_amdgcn_sdot4((int)ray_word, (int)member_word, CERT_THRESHOLD - 1, false);
-    return (uint32_t)sum < (uint32_t)(2 * CERT_THRESHOLD - 1);
-}
-
-template <int WALK = WALK_FAST>
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
-    tv.dq = (WALK == WALK_CERT && sc.n_filtered != 0u) ? cert_ray_word(sc, o, d) : 0u;  // (a scalar branch)
     tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
@@ -407,10 +377,9 @@ struct HotNodes {
     RR_DEV static constexpr uint32_t stride() { return COMPACT ? 9u : 17u; }  // granules
 };
 
-template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
+template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
                                WorkCount& wc) {
-    constexpr bool EXACT = WALK != WALK_FAST;  // nothing culled by the closest hit, slots entered in slot order
     const double tmin = sc.t0, tmax = sc.t1;
     const V3 inv = tv.inv;
     const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
@@ -519,50 +488,16 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// Does the segment miss the triangle's bounding box widened by CERT_BOX_MARGIN of its largest extent on every side?
-// (f64 throughout, round to nearest: the theorem has 7/8 of the margin to spare; the CPU checker computes the same.)
-template <bool COMPACT>
-RR_DEV bool member_box_missed(const PrimRec<COMPACT>& r, V3 o, V3 inv, double tmin, double tmax) {
-    double lo[3], hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double c1 = r.tri_coord(a), c2 = r.tri_coord(3 + a), c3 = r.tri_coord(6 + a);
-        double l = c1, h = c1;
-        if (c2 < l) l = c2;
-        if (c3 < l) l = c3;
-        if (c2 > h) h = c2;
-        if (c3 > h) h = c3;
-        lo[a] = l, hi[a] = h;
-    }
-    double ext = hi[0] - lo[0];
-    if (hi[1] - lo[1] > ext) ext = hi[1] - lo[1];
-    if (hi[2] - lo[2] > ext) ext = hi[2] - lo[2];
-    const double m = ext * CERT_BOX_MARGIN;
-    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
-    const double x0 = lo[0] - m, x1 = hi[0] + m, y0 = lo[1] - m, y1 = hi[1] + m, z0 = lo[2] - m, z1 = hi[2] + m;
-    double entry;
-    return !slab(nx ? x1 : x0, nx ? x0 : x1, ny ? y1 : y0, ny ? y0 : y1, nz ? z1 : z0, nz ? z0 : z1, o, inv, tmin, tmax, entry);
-}
-
-// One leaf reference: its 1..4 primitives in DFS order, then pop.  WALK_CERT, a REF_FILTERED group: a member that
-// carries a certificate is skipped when the segment misses its own widened box and the ray is not in doubt for it --
-// the reference's own test then rejects it (scene_host.cpp build_cert_tree).  The skip is taken per wave (a wave of
-// floor and sky rays skips the floor group's mesh triangles together); a wave in which some lane must test the
-// member tests it with every lane on that group, which is what the reference does anyway.
-template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
+// One leaf reference: its 1..4 primitives in DFS order, then pop.
+template <bool COMPACT, bool COUNT>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
     const double tmin = sc.t0, tmax = sc.t1;
     const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
     const uint32_t count = (tv.cur & 3u) + 1u;
-    const bool filtered = WALK == WALK_CERT && (tv.cur >> 30) == REF_FILTERED;
     if (COUNT) wc.leaf_prims = count;
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t p = first + k;
         const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
-        if (WALK == WALK_CERT && filtered && (r.tag() & 3u) == PRIM_TRIANGLE) {
-            const uint32_t cw = r.dw(COMPACT ? PRIM_CERT_DWORD_COMPACT : PRIM_CERT_DWORD_FULL);
-            if ((cw & CERT_VALID) != 0u && !cert_in_doubt(tv.dq, cw) && member_box_missed<COMPACT>(r, o, tv.inv, tmin, tmax)) continue;
-        }
         if (COUNT) {
             const uint32_t kind = r.tag() & 3u;
             if (kind == PRIM_TRIANGLE) wc.tri++;
@@ -582,17 +517,17 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
-template <bool COMPACT, bool COUNT, int WALK = WALK_FAST>
+template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
-    trav_init<WALK>(sc, o, d, tv);
+    trav_init(sc, o, d, tv);
     const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
-            trav_interior_step<COMPACT, COUNT, WALK>(sc, o, stack, hot, tv, wc);
+            trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
         else
-            trav_leaf_step<COMPACT, COUNT, WALK>(sc, o, d, stack, tv, wc);
+            trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }
     t_hit = tv.best_t;
     prim_hit = tv.best_prim;

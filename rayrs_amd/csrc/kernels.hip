@@ -124,9 +124,8 @@ __global__ void __launch_bounds__(256) test_intersect_kernel(SceneDev sc, const 
     uint32_t prim = 0;
     WorkCount wc{0, 0, 0, 0, 0};
     const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    const bool hit = sc.walk == (uint32_t)WALK_CERT        ? bvh_intersect<COMPACT, false, WALK_CERT>(sc, ro, rd, stack, t, prim, wc)
-                     : sc.walk == (uint32_t)WALK_REFERENCE ? bvh_intersect<COMPACT, false, WALK_REFERENCE>(sc, ro, rd, stack, t, prim, wc)
-                                                           : bvh_intersect<COMPACT, false, WALK_FAST>(sc, ro, rd, stack, t, prim, wc);
+    const bool hit = sc.exact ? bvh_intersect<COMPACT, false, true>(sc, ro, rd, stack, t, prim, wc)
+                              : bvh_intersect<COMPACT, false, false>(sc, ro, rd, stack, t, prim, wc);
     t_out[i] = hit ? t : 0.0;
     prim_out[i] = hit ? (long long)prim : -1ll;
 }

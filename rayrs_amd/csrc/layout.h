@@ -26,8 +26,6 @@ constexpr uint32_t REF_RANGE = 1u;     // payload = first_prim << 2 | (count - 1
 constexpr uint32_t REF_SINGLE = 2u;    // two-child export only: payload = prim << 2, a direct leaf (no box of its own,
                                        // bvh.rs:297, :302); the gate tree holds it as a one-primitive REF_RANGE behind
                                        // the box of the Node it hangs under
-constexpr uint32_t REF_FILTERED = 2u;  // certified tree only (same number, other tree): a REF_RANGE group some of whose
-                                       // members carry a certificate (MemberFilter below); payload as REF_RANGE
 constexpr uint32_t REF_NONE = 3u;
 
 // primitive tag: kind | axis << 2 | surface << 8
@@ -62,25 +60,6 @@ struct Node4F64 {  // 256 B
     uint32_t ref[4];
     uint32_t pad[12];
 };
-
-// The certified walk's member certificates.  A triangle's primitive record has a spare dword (PRIM_CERT_DWORD_*)
-// that holds its certificate word: CERT_NONE (the member is tested whenever its group is entered, as the reference
-// does), or CERT_VALID | the triangle's unit normal times 127 as three signed bytes (nx, ny, nz), rounded to
-// nearest.  The walk carries the ray's direction the same way (length 127, rounded: device_path.h cert_ray_word)
-// and, in a REF_FILTERED group, skips such a member when the segment misses its bounding box widened by 1/64 of
-// its largest extent (computed from the record's vertices: device_path.h member_box_missed) AND
-// |dx nx + dy ny + dz nz| >= CERT_THRESHOLD -- when the ray is not "in doubt", i.e. provably not so close to the
-// triangle's plane that the reference's own test of it is rounding noise (scene_host.cpp build_cert_tree states the
-// theorem and the arithmetic behind the threshold).  A ray outside the theorem's premises carries (0, 0, 0): in
-// doubt for every member.
-constexpr uint32_t CERT_NONE = 0u;
-constexpr uint32_t CERT_VALID = 1u << 31;
-constexpr int32_t CERT_THRESHOLD = 320;
-constexpr uint32_t CERT_RAY_OUTSIDE = 0u;
-constexpr double CERT_BOX_MARGIN = 0x1p-6;   // of the member's largest extent, on every side
-constexpr uint32_t PRIM_CERT_DWORD_COMPACT = 9;   // triangles only (a rectangle's payload reaches dword 9)
-constexpr uint32_t PRIM_CERT_DWORD_FULL = 18;
-
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
@@ -93,16 +72,6 @@ static_assert(sizeof(Node4F64) == 256, "Node4F64");
 //   plane   : umin, umax, vmin, vmax, pos as 5 f64 (axis in the tag)
 constexpr uint32_t PRIM_DWORDS_COMPACT = 12;  // 48 B
 constexpr uint32_t PRIM_DWORDS_FULL = 20;     // 80 B
-
-// Which walk a traversal kernel instance makes (SceneDev::walk; rayrs_render_params.walk, include/rayrs_hip.h):
-//   WALK_FAST       the tree of single primitives behind clipped boxes, closest-hit culling: two bets
-//                   (device_path.h TRAV_CULL_MARGIN, scene_host.cpp LEAF_MARGIN);
-//   WALK_REFERENCE  the gate tree, nothing culled: the primitives BvhTree::intersect tests, by construction;
-//   WALK_CERT       the same, except that a member of an entered group is skipped where "its own widened box is
-//                   missed" provably means "the reference rejects it" (scene_host.cpp build_cert_tree): members far
-//                   smaller than their gating box (the mesh triangles that share a bottom Node with the floor),
-//                   which a whole wave of floor and sky rays skips together.
-enum : int { WALK_FAST = 0, WALK_REFERENCE = 1, WALK_CERT = 2 };
 
 // One row per distinct (Material, Emission) pair; material.rs:148-238, :1056-1060.
 struct SurfaceDev {
@@ -135,11 +104,9 @@ struct SceneDev {
     double t0, t1;  // Scene::t_range, lib.rs:218
     double hdri_wm1, hdri_hm1;  // (hdri_w - 1) as f64 and (hdri_h - 1) as f64, lib.rs:262-263 (converted on the host: a kernel
                                 // that converts them hoists the results into vector registers for its whole run)
-    // rayrs_render_params.walk as the kernels take it: device_path.h WALK_FAST / WALK_REFERENCE / WALK_CERT (which
-    // instance of the traversal kernel runs, on which of the scene's three trees `nodes` points to)
-    uint32_t walk, pad1;
-    double cert_center[3], cert_radius;  // WALK_CERT: the per-ray guard (device_path.h cert_ray_word)
-    uint32_t n_filtered, pad2;           // members that carry a certificate (0: the certified walk is the reference walk)
+    // rayrs_render_params.exact_traversal: the walk culls nothing by the closest hit so far, as BvhTree::intersect
+    // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
+    uint32_t exact, pad1;
 };
 
 struct CameraDev {

@@ -1,6 +1,6 @@
 // rayrs_cli.cpp -- the reference's command line (rayrs/src/main.rs) on top of the C ABI:
 //
-//     rayrs hdri_path [spp] [--scene NAME] [--seed N] [--device N] [--max-bounces N] [--walk certified|reference|fast]
+//     rayrs hdri_path [spp] [--scene NAME] [--seed N] [--device N] [--max-bounces N] [--fast-traversal 0|1]
 //                           [--gpus N | --devices a,b,...]
 //
 // --gpus N renders on HIP devices 0..N-1 at once (--devices names them; a device may be named more than
@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 0x5EED;
     int device = 0;
     uint32_t max_bounces = 50;  // main.rs:77
-    uint32_t walk = RAYRS_WALK_CERTIFIED;  // rayrs_render_params.walk
+    uint32_t fast_traversal = 0;  // rayrs_render_params.fast_traversal: 0 = the reference's visit set by construction
     std::vector<int> devices;
     int i = 2;
     if (i < argc && argv[i][0] != '-') {
@@ -132,16 +132,8 @@ int main(int argc, char** argv) {
         else if (opt == "--seed") seed = std::strtoull(argv[i + 1], nullptr, 0);
         else if (opt == "--device") device = std::atoi(argv[i + 1]);
         else if (opt == "--max-bounces") max_bounces = (uint32_t)std::atoi(argv[i + 1]);
-        else if (opt == "--walk") {
-            const std::string w = argv[i + 1];
-            if (w == "certified") walk = RAYRS_WALK_CERTIFIED;
-            else if (w == "reference") walk = RAYRS_WALK_REFERENCE;
-            else if (w == "fast") walk = RAYRS_WALK_FAST;
-            else {
-                std::fprintf(stderr, "--walk certified|reference|fast\n");
-                return 2;
-            }
-        } else if (opt == "--exact-traversal") walk = std::atoi(argv[i + 1]) ? RAYRS_WALK_REFERENCE : RAYRS_WALK_CERTIFIED;  // (the pre-round-5 spelling)
+        else if (opt == "--fast-traversal") fast_traversal = std::atoi(argv[i + 1]) ? 1u : 0u;
+        else if (opt == "--exact-traversal") fast_traversal = std::atoi(argv[i + 1]) ? 0u : 1u;  // (the pre-round-5 spelling)
         else if (opt == "--gpus") {
             devices.clear();
             for (int d = 0; d < std::atoi(argv[i + 1]); d++) devices.push_back(d);
@@ -213,7 +205,7 @@ int main(int argc, char** argv) {
     params.tile_rank = 0;
     params.tile_ranks = 1;
     params.out_format = RAYRS_OUT_F32;
-    params.walk = walk;
+    params.fast_traversal = fast_traversal;
     std::vector<float> rgb((size_t)cam.x_pixels * cam.y_pixels * 3, 0.f);
     rayrs_render_stats stats;
     const auto t0 = std::chrono::steady_clock::now();

@@ -286,7 +286,7 @@ double record_area(const WalkTree& f, uint32_t rec) {
     bool any = false;
     for (int i = 0; i < 4; i++) {
         const uint32_t kind = f.ref[(size_t)rec * 4 + i] >> 30;
-        if (kind == REF_NONE) continue;
+        if (kind != REF_INTERIOR && kind != REF_RANGE) continue;
         const double* b = &f.box[((size_t)rec * 4 + i) * 6];
         for (int a = 0; a < 3; a++) {
             if (!any || b[2 * a] < lo[a]) lo[a] = b[2 * a];
@@ -623,10 +623,6 @@ void tight_box(const Aabb& b, const double* gate, double* out) {
         if ((double)lf > lo) lf = std::nextafterf(lf, -std::numeric_limits<float>::infinity());
         if ((double)hf < hi) hf = std::nextafterf(hf, std::numeric_limits<float>::infinity());
         lo = (double)lf, hi = (double)hf;
-        if (!gate) {  // the certified tree: its group records sit BEHIND the gating box, nothing is clipped
-            out[2 * a] = lo, out[2 * a + 1] = hi;
-            continue;
-        }
         // (a bound that is not a number, from an object whose own box is not, leaves the gating box's bound)
         out[2 * a] = lo > gate[2 * a] ? lo : gate[2 * a];
         out[2 * a + 1] = hi < gate[2 * a + 1] ? hi : gate[2 * a + 1];
@@ -656,159 +652,12 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
     front_largest(t);
 }
 
-// ------------------------------------------------------------ the certified walk
-//
-// The reference tests every member of a bottom Node whose box the ray enters (bvh.rs:391-415).  Where that Node holds
-// one large primitive and a few small ones -- the benchmark scenes' 50 x 50 floor shares its Node with three mesh
-// triangles; every floor and sky ray enters that box: half of all primitive tests of the reference walk -- the
-// certified walk skips a small member whose own widened box W the segment misses, and the claim is that the
-// reference's own test (geometry.rs:359-375, then bvh.rs:406) rejects that member then: BY THEOREM, not by measurement.
-// The tree is the gate tree (groups behind exactly their gating boxes, nothing culled); a group with such members is
-// marked REF_FILTERED, and such a member's primitive record carries a certificate word (layout.h); W is the member's
-// bounding box widened by CERT_BOX_MARGIN = 2^-6 of its largest extent, NOT clipped.  A walk that stands on the
-// group has passed its gating box exactly as BvhTree::intersect does, so the reference tests every member; the walk
-// tests a member unless it carries a certificate, the segment misses W and the ray is not "in doubt" for it.
-// (The same theorem carried a whole tree of single triangles in round 5's experiments -- cone certificates per slot,
-// certified culling, gating boxes tested in the leaf step; sound, and no faster than the reference walk:
-// profiles/r05_certified_walks.txt.  What pays is skipping that a whole wave does together.)
-//
-// Notation.  u = 2^-53.  Triangle p1, p2, p3; ray o + s d, s in (t0, t1); all finite doubles.  The reference
-// computes, in this order and without fused operations (device_path.h triangle_intersect is the same list):
-//     a = fl(p2 - p1), b = fl(p3 - p1), c = fl(o - p1)              (Triangle::new :342-343, intersect :360)
-//     p = fl(d x b), q = fl(c x a)
-//     den = fl(p . a), Nu = fl(p . c), Nv = fl(q . d), Nt = fl(q . b)
-//     t = fl(Nt / den), uu = fl(Nu / den), vv = fl(Nv / den)
-//     reject if t < 0 or uu < 0 or vv < 0 or fl(uu + vv) > 1; accept iff also t0 < t < t1   (bvh.rs:406)
-// Take a, b, c as the data of a perturbed problem: triangle Q' = (p1, p1 + a, p1 + b), origin o' = p1 + c.  Each
-// component of a, b, c carries one rounding, so Q' and o' lie within u * (their distance from p1) of Q and o.
-// Write P = d x b, Qx = c x a, DEN = P . a = -d . (a x b), NU = P . c, NV = Qx . d, NT = Qx . b for the exact
-// values on that data; U = NU / DEN, V = NV / DEN, TT = NT / DEN are the barycentric coordinates and the ray
-// parameter of the point X' = o' + TT d = p1 + U a + V b where the perturbed line meets the perturbed plane.
-//
-// (1) Rounding.  A cross product's component is fl(fl(xy) - fl(zw)): |p - P| <= sqrt2 g2 |d||b| with
-//     g2 = 2u / (1 - 2u) (sum of squares of |x y| + |z w| over the components is at most 2 |d|^2 |b|^2); a
-//     three-term dot product adds at most g3 |p||a|.  So
-//         |den - DEN| <= E |d||a||b|,  |Nu - NU| <= E |d||b||c|,  |Nv - NV| <= E |c||a||d|,  |Nt - NT| <= E |c||a||b|
-//     with E = (3 + 2 sqrt2) u (1 + 8u) < 6 u.  (Underflow adds at most 2^-1070 absolutely, below every
-//     quantity compared here once magnitudes are within the ranges checked in (5).)
-// (2) Conditioning.  Let kappa = |DEN| / (|d||a||b|) = |cos(d, n')| sin(gamma'), n' the normal of Q' and gamma'
-//     its corner angle at p1, and L = max(1, |c| / min(|a|, |b|)).  PREMISE:  kappa >= 2^-36 L.
-//     Then den = DEN (1 + eta) with |eta| <= 6u / kappa <= 2^-14: den is finite, not zero and has DEN's sign, and
-//     (a quotient adds one rounding; Nu / den = U / (1 + eta) + (Nu - NU) / den with |Nu - NU| / |DEN| <=
-//     (6u / kappa) |c| / |a|, likewise Nv with |c| / |b| and Nt with |c| / |d|)
-//         |uu - U| <= (|U| + 1) lam,  |vv - V| <= (|V| + 1) lam,  |t - TT| <= (|TT| + |c| / |d|) lam / L,
-//     lam = 8u L / kappa <= 2^-14.
-// (3) Acceptance puts X' next to the triangle.  If the reference accepts, uu >= 0, vv >= 0, uu + vv <= 1 + 2u,
-//     so U >= -2 lam, V >= -2 lam, U + V <= 1 + 6 lam: every barycentric weight of X' in Q' is at least
-//     -6 lam.  Two of three weights summing to 1 can be negative, so along every axis k X' lies within
-//     12 lam ext_k(Q') < 2^-10 ext_k of the bounding box of Q' -- within 2^-9 ext_max of the bounding box of Q
-//     (the perturbations of Q' and o' are at most u |a|, u |b|, u |c|, and u |c| <= u L min(|a|,|b|) <= 2^-21 ext_max
-//     with L <= 2^31, checked in (5)) -- that is, inside the widened box W, whose margin is
-//     m = CERT_BOX_MARGIN ext_max = 2^-6 ext_max, with (7/8) m to spare on every side.
-// (4) ... so the slab test on W passes.  Along the line a step ds moves no coordinate by more than ds |d|_inf,
-//     so the exact parameter interval [A, B] of the line inside W contains TT with (7/8) m / |d|_inf to spare on
-//     both sides.  The slab test computes each axis' parameters as fl(fl(bound - o_k) fl(1 / d_k)): relative
-//     error below 4u each, and the parameters that decide are at most |TT| + m / |d|_inf in magnitude with
-//     |TT||d| <= |c| + |X' - p1| <= |c| + 4 ext_max, so the computed interval [A~, B~] still contains TT with
-//     (3/4) m / |d|_inf to spare (4u |c| <= 2^-19 ext_max).  A zero component d_k makes that axis' slab
-//     (-inf, +inf), o_k lying strictly inside W's slab (X'_k = o'_k there): never a NaN.  Acceptance also says
-//     t0 < t < t1, and |t - TT||d| <= (|TT||d| + |c|) lam / L <= (2 |c| / L + 4 ext_max) lam <= (2 sqrt3 + 4) lam ext_max
-//     < 2^-11 ext_max = m / 32  (|c| / L <= min(|a|,|b|) <= sqrt3 ext_max).  So A~ < t < B~ and t0 < t < t1:
-//     max(t0, A~) < min(t1, B~), and the test the walk makes (device_path.h slab: !(tmax <= tmin)) passes.
-//     Contrapositive: the segment misses W and the premise holds  ==>  the reference does not accept this triangle.
-// (5) The certificate makes the premise checkable from one dword.  At build time, per triangle, with D the bound on
-//     |o - p1| that the walk's per-ray guard enforces (FlatScene::cert_radius: |o - centre|_inf <= R, so
-//     D = sqrt3 (R + the root box's largest half extent)):  tau = 2^-36 max(1, 1.01 D / min(|a|,|b|)) / sin(gamma).
-//     If tau <= 2^-10, and the triangle's sizes are sane (edges and D within 2^+-200, L <= 2^31), the word holds
-//     the unit normal N / |N| times 127, rounded to nearest; else the member carries no certificate.  The walk scales d
-//     the same way (d / |d| times 127: a dot product, an IEEE square root and division, three products, v_rndne).
-//     With r, s the two rounding vectors (components at most 1/2 + 2^-40) and dh, nh the unit vectors,
-//         dq . nq = 127^2 (1 + e) dh . nh + 127 (dh . r)(1 + e) + 127 nh . s + s . r,    |e| <= 4u,
-//     and the last three are at most 110 + 110 + 0.76 < 222 in magnitude (|r|_2, |s|_2 <= sqrt3 / 2).  "Not in doubt"
-//     means |dq . nq| >= CERT_THRESHOLD = 320, hence |cos(d, N)| >= (320 - 222) / 16130 > 2^-7.4: eight times tau,
-//     which swallows the difference between N computed here in f64 and the exact normal of Q' (relative 4u / sin(gamma))
-//     -- kappa >= 2^-7.4 sin(gamma') >= 2^-36 L.  A ray whose origin fails the guard, or whose direction has a largest
-//     component outside [2^-400, 2^400] or a component that is not finite, carries (0, 0, 0): in doubt for every member.
-// What is in doubt is tested with the reference's own arithmetic; what is not in doubt and missed is rejected by the
-// reference: the certified walk returns BvhTree::intersect's closest hit for every ray.  About 2 % of (ray, certified
-// member) pairs are in doubt (|cos| below 320 / 16129) and cost the test the reference makes anyway.
-constexpr double CERT_GUARD_RADII = 4.0;    // rays from within this many root-box half extents of its centre are certified
-constexpr double CERT_MEMBER_RATIO = 8.0;   // a member gets a certificate when its gating box has more than this many times W's area
-
-// The certificate word of a triangle ((5) above), or CERT_NONE.
-static uint32_t cert_word_for(const Shape& s, double D) {
-    if (s.kind != PRIM_TRIANGLE) return CERT_NONE;
-    const double a[3] = {s.p2.x - s.p1.x, s.p2.y - s.p1.y, s.p2.z - s.p1.z};
-    const double b[3] = {s.p3.x - s.p1.x, s.p3.y - s.p1.y, s.p3.z - s.p1.z};
-    const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-    const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    const double lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
-    const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-    const double lo = 0x1p-200, hi = 0x1p200;
-    if (!(la >= lo && la <= hi && lb >= lo && lb <= hi && ln >= lo * lo && D >= lo && D <= hi)) return CERT_NONE;  // NaN: false
-    const double emin = la < lb ? la : lb;
-    const double L = std::max(1.0, 1.01 * D / emin);
-    if (!(L <= 0x1p31)) return CERT_NONE;
-    const double sin_gamma = ln / (la * lb);
-    const double tau = 0x1p-36 * L / sin_gamma;
-    if (!(tau <= 0x1p-10)) return CERT_NONE;
-    uint32_t w = CERT_VALID;
-    for (int k = 0; k < 3; k++) {
-        const int q = (int)std::nearbyint(n[k] / ln * 127.0);  // in [-127, 127]
-        w |= ((uint32_t)q & 0xffu) << (8 * k);
-    }
-    return w;
-}
-
-// f.gate must be built.  objs / prim_object give the shapes behind the primitive records.
-void build_cert_tree(FlatScene& f, const ObjectList& objs, const std::vector<Aabb>& prim_box) {
-    WalkTree& t = f.cert;
-    t = f.gate;
-    t.node_bytes.clear();
-    const size_t n = f.n_prims();
-    f.member_cert.assign(std::max<size_t>(n, 1), CERT_NONE);
-    f.n_filtered = 0;
-    // the guard: rays from within CERT_GUARD_RADII half extents of the root box's centre (max norm)
-    double half = 0.0;
-    for (int a = 0; a < 3; a++) {
-        f.cert_center[a] = 0.5 * f.root_box[2 * a] + 0.5 * f.root_box[2 * a + 1];
-        half = std::max(half, 0.5 * (f.root_box[2 * a + 1] - f.root_box[2 * a]));
-    }
-    f.cert_radius = CERT_GUARD_RADII * half;
-    if (!(f.cert_radius > 0.0) || !std::isfinite(f.cert_radius)) {
-        f.cert_radius = 0.0;  // nothing is certified
-        return;
-    }
-    const double D = std::sqrt(3.0) * (f.cert_radius + half);
-    for (uint32_t r = 0; r < t.n(); r++)
-        for (int c = 0; c < 4; c++) {
-            const uint32_t ref = t.ref[(size_t)r * 4 + c];
-            if ((ref >> 30) != REF_RANGE) continue;
-            const uint32_t first = (ref & 0x3fffffffu) >> 2, count = (ref & 3u) + 1u;
-            const double area_g = box_area(&t.box[((size_t)r * 4 + c) * 6]);
-            bool any = false;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t p = first + i;
-                const Aabb& pb = prim_box[p];
-                const double ext = std::max(pb.xmax - pb.xmin, std::max(pb.ymax - pb.ymin, pb.zmax - pb.zmin));
-                const double m = ext * CERT_BOX_MARGIN;
-                const double w[6] = {pb.xmin - m, pb.xmax + m, pb.ymin - m, pb.ymax + m, pb.zmin - m, pb.zmax + m};
-                if (!(area_g > CERT_MEMBER_RATIO * box_area(w))) continue;  // (NaN: no certificate)
-                f.member_cert[p] = cert_word_for(objs.objs[f.prim_object[p]].geom, D);
-                if (f.member_cert[p] != CERT_NONE) any = true, f.n_filtered++;
-            }
-            if (any) t.ref[(size_t)r * 4 + c] = (REF_FILTERED << 30) | (ref & 0x3fffffffu);
-        }
-}
-
 // prim_box[p]: the reference's bounding box of the object behind primitive record p
-void build_walk_trees(FlatScene& f, const ObjectList& objs, const std::vector<Aabb>& prim_box) {
+void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
     f.walk = WalkTree();
     f.gate = WalkTree();
-    f.cert = WalkTree();
     if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
-        f.walk.root_ref = f.gate.root_ref = f.cert.root_ref = f.root_ref;
-        f.member_cert.assign(std::max<size_t>(f.n_prims(), 1), CERT_NONE);
+        f.walk.root_ref = f.gate.root_ref = f.root_ref;
         return;
     }
     std::vector<WalkGroup> groups;
@@ -817,7 +666,6 @@ void build_walk_trees(FlatScene& f, const ObjectList& objs, const std::vector<Aa
     std::vector<WalkGroup> singles;
     split_groups(groups, prim_box, singles);
     build_tree_over(singles, f.walk);
-    build_cert_tree(f, objs, prim_box);
 }
 
 inline bool boxes_f32_exact(const WalkTree& t) {
@@ -885,11 +733,19 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     {
         std::vector<Aabb> prim_box(n);
         for (size_t p = 0; p < n; p++) prim_box[p] = b.boxes[f.prim_object[p]];
-        build_walk_trees(f, objs, prim_box);
+        build_walk_trees(f, prim_box);
+        std::vector<double> ext(n);
+        for (size_t p = 0; p < n; p++) {
+            const Aabb& pb = prim_box[p];
+            const double e = std::max(pb.xmax - pb.xmin, std::max(pb.ymax - pb.ymin, pb.zmax - pb.zmin));
+            ext[p] = e > 0.0 ? e : std::numeric_limits<double>::infinity();  // (degenerate or not a number: not "small")
+        }
+        std::nth_element(ext.begin(), ext.begin() + (std::ptrdiff_t)(n / 20), ext.end());
+        f.small_extent = std::isfinite(ext[n / 20]) ? ext[n / 20] : 0.0;
     }
 
     // ---- choose the layout
-    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk) && boxes_f32_exact(f.cert);
+    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk);
     for (size_t i = 0; i < n && compact; i++) {
         const Shape& s = objs.objs[i].geom;
         if (s.kind != PRIM_TRIANGLE) continue;
@@ -901,7 +757,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
             }
     }
     f.compact = compact;
-    for (WalkTree* t : {&f.gate, &f.walk, &f.cert}) {
+    for (WalkTree* t : {&f.gate, &f.walk}) {
         if (compact) fill_nodes<Node4F32, float>(*t);
         else fill_nodes<Node4F64, double>(*t);
     }
@@ -933,7 +789,6 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
                 else
                     put_f64(rec + 2 * k, v[k]);
             }
-            rec[compact ? PRIM_CERT_DWORD_COMPACT : PRIM_CERT_DWORD_FULL] = f.member_cert[p];  // (layout.h; CERT_NONE for most)
         }
         rec[dw - 1] = s.kind | (s.axis << 2) | (o.surface << 8);
     }

@@ -64,15 +64,8 @@ struct FlatScene {
     // The trees the kernels traverse (scene_host.cpp "the walk trees"): four-slot records whose leaf slots are
     //   gate  the reference's leaf groups behind their exact gating boxes -- reaches exactly what the reference
     //         reaches; walked when rayrs_render_params.exact_traversal is set, and by the local-pool route;
-    //   walk  single primitives behind their own widened boxes inside the gating box, closest-hit culling: two bets
-    //         on the reference's arithmetic (RAYRS_WALK_FAST);
-    //   cert  the gate tree again, the groups that have members with a certificate marked REF_FILTERED
-    //         (scene_host.cpp build_cert_tree) -- the default.
-    WalkTree walk, gate, cert;
-    std::vector<uint32_t> member_cert;  // per primitive record: its certificate word (layout.h), also in the record itself
-    uint32_t n_filtered = 0;            // members that carry a certificate
-    double cert_center[3] = {0, 0, 0};  // rays whose origin lies farther than cert_radius (max norm) from here are
-    double cert_radius = 0;             // outside the theorem's premises: in doubt for every member
+    //   walk  single primitives behind their own widened boxes inside the gating box -- the default.
+    WalkTree walk, gate;
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)
@@ -81,6 +74,7 @@ struct FlatScene {
     uint32_t hdri_w = 0, hdri_h = 0;
     double t0 = 0, t1 = 0;
     double build_seconds = 0;
+    double small_extent = 0;  // 5th percentile of the primitives' largest bounding-box extents (abi.cpp camera_is_far)
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }
 };

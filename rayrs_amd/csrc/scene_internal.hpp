@@ -32,16 +32,16 @@ struct rayrs_scene {
     bool pending = false;
     bool last_count = false;
     int cu_count = 0;
-    // How the traversal kernel walks each of the scene's three trees: [0] FlatScene::walk (RAYRS_WALK_FAST),
-    // [1] FlatScene::gate (RAYRS_WALK_REFERENCE), [2] FlatScene::cert (RAYRS_WALK_CERTIFIED, the default).
+    // How the traversal kernel walks each of the scene's two trees: [0] FlatScene::walk (the default),
+    // [1] FlatScene::gate (rayrs_render_params.exact_traversal).
     struct Walk {
         void* d_nodes = nullptr;
         int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
         uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
         uint32_t hot_records = 0;    // leading records kept in LDS
     };
-    Walk trav[3];
-    const rayrs::WalkTree& tree(int x) const { return x == 2 ? flat.cert : x == 1 ? flat.gate : flat.walk; }
+    Walk trav[2];
+    const rayrs::WalkTree& tree(bool exact) const { return exact ? flat.gate : flat.walk; }
     uint64_t device_bytes = 0;
     // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,
     // per-wave item ranges and traversal-stack overflow strips, kept between renders.
@@ -64,7 +64,7 @@ struct rayrs_scene {
     // Scenes whose walk tree is at most one record are rendered by local_pool.hip: every path resident in LDS.
     bool local_ok = false;
     bool last_local = false;          // the render in flight took that route
-    uint32_t last_walk = 0;           // ... with this walk (RAYRS_WALK_*: the one asked for, or RAYRS_WALK_REFERENCE in place of the fast one for a far camera)
+    bool last_exact = false;          // ... with the exact walk (asked for, or a far camera: abi.cpp camera_is_far)
     rayrs::LocalScene local = {};
     int local_blocks_per_cu = 1;      // local-pool kernel, from the occupancy query with the scene's LDS size
     double* d_local_light = nullptr;  // 4 doubles per resident path

@@ -428,8 +428,8 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-template <bool COMPACT, bool COUNT, int WALK>
-__global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+template <bool COMPACT, bool COUNT, bool EXACT>
+__global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel
     uint32_t slot = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     Trav tv;
-    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0, tv.dq = 0;
+    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
-                    trav_init<WALK>(sc, o, d, tv);
+                    trav_init(sc, o, d, tv);
                     if (tv.cur == TRAV_DONE)
                         pending = true;  // missed the root box: retired at the next refill
                     else
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                trav_leaf_step<COMPACT, COUNT, WALK>(sc, o, d, stack, tv, wc);
+                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_CERT ? 4 : 5) wf_trav_kernel
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                trav_interior_step<COMPACT, COUNT, WALK>(sc, o, stack, hot, tv, wc);
+                trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -874,9 +874,8 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (sc.walk == (uint32_t)WALK_CERT) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, WALK_CERT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    else if (sc.walk == (uint32_t)WALK_REFERENCE) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, WALK_REFERENCE>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, WALK_FAST>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -891,31 +890,24 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
 
 template <bool COMPACT, bool COUNT>
 static hipError_t trav_set_lds(uint32_t lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, WALK_FAST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, WALK_REFERENCE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, WALK_CERT>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t wf_trav_occupancy(bool compact, int walk, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
     const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
-        if (walk == WALK_CERT) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_CERT>, 256, lds);
-        if (walk == WALK_REFERENCE) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_REFERENCE>, 256, lds);
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, WALK_FAST>, 256, lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, false>, 256, lds);
     }
     if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
     if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
-    if (walk == WALK_CERT) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_CERT>, 256, lds);
-    if (walk == WALK_REFERENCE) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_REFERENCE>, 256, lds);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, WALK_FAST>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, false>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,

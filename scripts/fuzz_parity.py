@@ -49,32 +49,27 @@ for seed in range(first, first + count):
     ocam = _oracle.OracleCamera(*cam_args)
     if seed % 5 == 0:
         scene.set_tuning(pool_slots=int(r.integers(1, 40)) * 1024)
-    img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
+    fast = seed % 2 == 0   # every other scene by rayrs_render_params.fast_traversal, the others by the default walk
+    img, st = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True, fast_traversal=fast)
     ref0, ost0 = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)   # the reference's recursion
-    if seed % 4 == 1:   # rayrs_render_params.exact_traversal: the gate tree without culling -- the same frame, by construction
-        imgx, stx = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, exact_traversal=True)
+    if seed % 4 == 1:   # ... and the other walk as well: the same frame
+        imgx, stx = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, fast_traversal=not fast)
         if not (np.array_equal(imgx.view(np.uint64), ref0.view(np.uint64)) and stx["rays"] == ost0["rays"]):
             bad += 1
-            print("MISMATCH (exact_traversal) seed", seed, flush=True)
+            print("MISMATCH (the other walk) seed", seed, flush=True)
     ok = np.array_equal(img.view(np.uint64), ref0.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths"):
         ok = ok and st[k] == ost0[k]
-    # the oracle's walk on the records the frame's queries walked: the local-pool route and a frame that took the exact
-    # walk (a camera far from the scene: abi.cpp camera_is_far) the gate tree -- the latter with nothing culled
-    far = bool(st["exact_walk"]) and not st["local_pool"]
-    n_far += far
-    try:
-        if far:
-            _oracle.set_cull_margin(float("inf"))
-        ref, ost = osc.use_walk_tree(scene, gate=bool(st["exact_walk"])).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
-    finally:
-        _oracle.set_cull_margin(2.0 ** -10)
+    # the oracle's walk on the records the frame's queries walked: the gate tree with nothing culled unless the frame
+    # took the fast walk (asked for, the streaming route, the camera not far from the scene: abi.cpp camera_is_far)
+    n_far += fast and bool(st["exact_walk"]) and not st["local_pool"]
+    ref, ost = osc.use_product_walk(scene, fast=not st["exact_walk"]).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
     ok = ok and np.array_equal(img.view(np.uint64), ref.view(np.uint64))
     for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
         ok = ok and st[k] == ost[k]
     if seed % 3 == 1 and scene.info()["local_pool"]:  # the streaming kernels on a scene the local pool renders
         scene.set_tuning(local_pool=1)
-        img2, st2 = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
+        img2, st2 = rayrs_amd.render(scene, cam, spp, mb, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True, fast_traversal=fast)
         ok = ok and np.array_equal(img2.view(np.uint64), ref0.view(np.uint64)) and st2["rays"] == ost0["rays"]
         n_both += 1
     if not ok:
@@ -82,5 +77,5 @@ for seed in range(first, first + count):
         print("MISMATCH seed", seed, w, h, spp, chunk, mb, {k: (st[k], ost[k]) for k in ("rays", "interior_visits")}, flush=True)
     if (seed - first) % 20 == 19:
         print(f"{seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print("done:", count, "scenes,", bad, "mismatches;", n_both, "scenes rendered on both routes;", n_far, "frames took the exact walk for their camera's distance")
+print("done:", count, "scenes,", bad, "mismatches;", n_both, "scenes rendered on both routes;", n_far, "frames asked for the fast walk and took the default one for their camera's distance")
 sys.exit(1 if bad else 0)

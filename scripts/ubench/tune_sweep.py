@@ -2,8 +2,8 @@
 usage: python scripts/ubench/tune_sweep.py <config> <res> <spp> "k=v,k=v" "k=v" ...   ("" = defaults)
 Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render.
 TILE_RANKS=n in the environment renders one rank's share of n (what one GPU of n does; TILE_RANK=r which, default 0,
-"all" = every rank in turn, slowest reported last); CHUNK=n another sample chunk; EXACT=1 renders with
-rayrs_render_params.exact_traversal."""
+"all" = every rank in turn, slowest reported last); CHUNK=n another sample chunk; FAST=1 renders with
+rayrs_render_params.fast_traversal."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayrs_amd
@@ -30,7 +30,7 @@ for s in settings + settings[::-1]:
     img, worst = None, None
     for r in ranks:
         img, st = rayrs_amd.render(scene, cam, spp, mb, sample_chunk=chunk, tile_rank=r, tile_ranks=n_ranks, out=img,
-                                   exact_traversal=bool(int(os.environ.get("EXACT", "0"))))
+                                   fast_traversal=bool(int(os.environ.get("FAST", "0"))))
         if len(ranks) > 1:
             print(f"   rank {r}: trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f}  hit {st['hit_ms']:7.1f} miss {st['miss_ms']:7.1f} "
                   f"rounds {st['kernel_launches']:4d}  Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}", flush=True)

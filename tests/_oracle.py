@@ -93,7 +93,6 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
-    L.orc_set_member_certs.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_double]
     L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.orc_vec_op.restype = None
     L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
@@ -215,16 +214,23 @@ class OracleScene:
                 "root_box": list(i.root_box), "n_wide": i.n_wide, "wide_root_ref": i.wide_root_ref,
                 "wide_depth": i.wide_depth}
 
-    def use_cert_tree(self, product_scene):
-        """The product's certified tree and its certificate words: traversal=2 then makes the certified walk (the
-        cull margin must be infinite: _oracle.set_cull_margin(float("inf")), as for the gate tree)."""
-        info = product_scene.info()
-        box, ref, mcert = (np.ascontiguousarray(x) for x in product_scene.export_cert_tree())
-        assert self._L.orc_set_wide(self._h, info["cert_n_wide"], info["cert_root_ref"], info["cert_depth"],
-                                    box.ctypes.data, ref.ctypes.data) == 0
-        center = (C.c_double * 3)(*info["cert_center"])
-        assert self._L.orc_set_member_certs(self._h, mcert.ctypes.data, center, C.c_double(info["cert_radius"])) == 0
+    def use_product_walk(self, product_scene, fast=False):
+        """The walk the product makes: traversal=2 then visits what its traversal kernel visits -- by default the gate
+        tree with nothing culled (the reference's visit set), with fast=True the tree of single primitives with
+        closest-hit culling (rayrs_render_params.fast_traversal)."""
+        self.use_walk_tree(product_scene, gate=not fast)
+        self._walk_margin = 2.0 ** -10 if fast else float("inf")
         return self
+
+    def _with_margin(self, traversal, call):
+        m = getattr(self, "_walk_margin", None)
+        if traversal != 2 or m is None:
+            return call()
+        try:
+            set_cull_margin(m)
+            return call()
+        finally:
+            set_cull_margin(2.0 ** -10)
 
     def use_walk_tree(self, product_scene, gate=False):
         """Take the four-slot records the kernels walk from the product (a rayrs_amd.Scene, host-only
@@ -235,6 +241,7 @@ class OracleScene:
         box = np.ascontiguousarray(box)
         ref = np.ascontiguousarray(ref)
         pre = "gate_" if gate else "wide_"
+        self._walk_margin = None  # (the caller sets the cull margin: _oracle.set_cull_margin)
         assert self._L.orc_set_wide(self._h, info["gate_n_wide" if gate else "n_wide"], info[pre + "root_ref"],
                                     info[pre + "depth"], box.ctypes.data, ref.ctypes.data) == 0
         return self
@@ -262,8 +269,9 @@ class OracleScene:
         r0, r1 = rows if rows is not None else (0, H)
         if nthreads is None:
             nthreads = os.cpu_count() or 1
-        rc = self._L.orc_render(self._h, C.byref(cam.desc), int(spp), int(max_bounces), int(seed), int(sample_chunk),
-                                int(r0), int(r1), int(nthreads), int(traversal), out.ctypes.data, C.byref(st))
+        rc = self._with_margin(traversal, lambda: self._L.orc_render(
+            self._h, C.byref(cam.desc), int(spp), int(max_bounces), int(seed), int(sample_chunk), int(r0), int(r1),
+            int(nthreads), int(traversal), out.ctypes.data, C.byref(st)))
         assert rc == 0, "orc_render failed"
         return out, st.as_dict()
 

@@ -220,13 +220,13 @@ def _gpu_intersect(scene, o, d, exact):
     return t, obj
 
 
-def test_exact_traversal_returns_the_reference_hit_where_the_default_walk_loses_it():
-    """rayrs_render_params.exact_traversal / rayrs_test_intersect(exact = 1): the walk of the gate tree (the
+def test_the_default_walk_returns_the_reference_hit_where_the_fast_walk_loses_it():
+    """The default walk / rayrs_test_intersect(exact = 1): the walk of the gate tree (the
     reference's groups behind their gating boxes) culls nothing (cull margin +infinity), so it tests exactly the
     primitives BvhTree::intersect tests and returns the reference's closest hit BY
     CONSTRUCTION -- also for the pinned rays of tests/test_walk_tree.py: the one within 1e-9 rad of a triangle's plane, whose
-    hit the default margin of 2^-10 loses (the default walk returns what the oracle's culled walk returns: the
-    neighbour 2 % behind), and for grazing rays of ANY angle, which the default only gets right from 1e-7 rad up."""
+    hit the fast walk's margin of 2^-10 loses (the fast walk returns what the oracle's culled walk returns: the
+    neighbour 2 % behind), and for grazing rays of ANY angle, which the fast walk only gets right from 1e-7 rad up."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import fuzz_traversal as F

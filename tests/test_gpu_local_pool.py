@@ -36,7 +36,7 @@ def frames(cam_args, objs, heur, w, h, spp, mb, chunk=0, seed=0x5EED, count_work
     ref, ost = osc.render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=0)
     if count_work:  # the oracle's walk on the records each route walks
         _, ost["gate_walk"] = osc.use_walk_tree(scene, gate=True).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
-        _, ost["default_walk"] = osc.use_walk_tree(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
+        _, ost["default_walk"] = osc.use_product_walk(scene).render(ocam, spp, mb, seed=seed, sample_chunk=chunk, traversal=2)
     return (loc, lst), (stream, sst), (ref, ost)
 
 

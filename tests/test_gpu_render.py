@@ -89,11 +89,12 @@ def test_work_counters_match_oracle_ordered_traversal():
     ordered traversal: same visit order, so the algorithmic-bytes figure of the
     roofline line can be computed on either side."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(3, area_light=True), 48, 32, 4)
-    img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    ref, ost = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)  # the kernel's walk on the kernel's records
-    assert_same_frame(img, ref)
-    for k in ("rays", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "escaped_paths"):
-        assert st[k] == ost[k], k
+    for fast in (False, True):  # the default walk, and rayrs_render_params.fast_traversal
+        img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=fast)
+        ref, ost = osc.use_product_walk(scene, fast=fast).render(ocam, 4, traversal=2)  # the kernel's walk on the kernel's records
+        assert_same_frame(img, ref)
+        for k in ("rays", "interior_visits", "tri_tests", "sphere_tests", "plane_tests", "escaped_paths"):
+            assert st[k] == ost[k], (fast, k)
 
 
 def test_traversal_stack_overflow_strip():
@@ -102,12 +103,13 @@ def test_traversal_stack_overflow_strip():
     strip; the frame and the work counters must not change."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 64, 48, 4)
     scene.lab_set(stack_lds=2)
-    assert scene.info()["wide_depth"] > 8
-    img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    ref, ost = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
-    assert_same_frame(img, ref)
-    for k in ("rays", "interior_visits", "tri_tests", "plane_tests"):
-        assert st[k] == ost[k], k
+    assert scene.info()["wide_depth"] > 8 and scene.info()["gate_depth"] > 8
+    for fast in (False, True):
+        img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=fast)
+        ref, ost = osc.use_product_walk(scene, fast=fast).render(ocam, 4, traversal=2)
+        assert_same_frame(img, ref)
+        for k in ("rays", "interior_visits", "tri_tests", "plane_tests"):
+            assert st[k] == ost[k], (fast, k)
 
 
 def test_deep_chain_tree_beyond_lds():
@@ -124,7 +126,7 @@ def test_deep_chain_tree_beyond_lds():
                                       Material.LambertianDiffuse((0.8, 0.8, 0.8)), Emission.Dark()))
     cam_args = ((-3.0, 1.5, 4.0), (0.0, 1.0, 0.0), (20.0, 1.0, 0.0), 70.0, 64 / 254.0, 32 / 254.0, 100)
     scene = rayrs_amd.Scene(objs, 1e-6, 1e60, BvhHeuristic.Midpoint, HDRI, device=0)
-    assert scene.info()["wide_depth"] > 100
+    assert scene.info()["wide_depth"] > 100 and scene.info()["gate_depth"] > 100
     cam = rayrs_amd.Camera(*cam_args)
     osc = _oracle.OracleScene(objs, 1e-6, 1e60, BvhHeuristic.Midpoint, HDRI)
     ocam = _oracle.OracleCamera(*cam_args)
@@ -132,7 +134,11 @@ def test_deep_chain_tree_beyond_lds():
     ref, ost = osc.render(ocam, 4, traversal=0)
     assert_same_frame(img, ref)
     assert st["rays"] == ost["rays"] and st["sphere_tests"] > st["rays"]
-    ref2, ost2 = osc.use_walk_tree(scene).render(ocam, 4, traversal=2)
+    ref2, ost2 = osc.use_product_walk(scene).render(ocam, 4, traversal=2)
+    assert st["interior_visits"] == ost2["interior_visits"] and st["sphere_tests"] == ost2["sphere_tests"]
+    img, st = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=True)
+    assert_same_frame(img, ref)
+    ref2, ost2 = osc.use_product_walk(scene, fast=True).render(ocam, 4, traversal=2)
     assert st["interior_visits"] == ost2["interior_visits"] and st["sphere_tests"] == ost2["sphere_tests"]
 
 
@@ -236,66 +242,59 @@ def test_render_multi_runs_its_rccl_reduce_on_one_device(route):
     assert_same_frame(img64, ref)
 
 
-def test_exact_traversal_renders_the_same_frame_with_more_visits():
-    """rayrs_render_params.exact_traversal = 1: the reference's leaf groups behind their gating boxes, nothing culled
-    by the closest hit so far -- the reference's own visit set (bvh.rs:391-415).  The frame is the oracle's and the default's; the walk visits more records and tests
-    more primitives (what the default saves), and equals the oracle's walk of the gate tree with its margin set
-    to infinity."""
+def test_the_default_walk_is_the_references_visit_set_and_the_fast_walk_visits_less():
+    """The default walk: the reference's leaf groups behind their gating boxes, nothing culled by the closest hit so
+    far -- the reference's own visit set (bvh.rs:391-415), equal to the oracle's walk of the gate tree with its margin
+    set to infinity.  rayrs_render_params.fast_traversal renders the same frame visiting fewer records and testing
+    fewer primitives (its two bets)."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 96, 64, 4)
-    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
-    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, exact_traversal=True)
+    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=True)
+    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
     ref, ost = osc.render(ocam, 4, traversal=0)
     assert_same_frame(a, ref)
     assert_same_frame(b, ref)
+    assert sa["exact_walk"] == 0 and sb["exact_walk"] == 1
     assert sa["rays"] == sb["rays"] == ost["rays"]
     assert sb["interior_visits"] > sa["interior_visits"] and sb["tri_tests"] > sa["tri_tests"]
-    try:
-        _oracle.set_cull_margin(float("inf"))
-        _, wst = osc.use_walk_tree(scene, gate=True).render(ocam, 4, traversal=2)
-    finally:
-        _oracle.set_cull_margin(2.0 ** -10)
+    _, wst = osc.use_product_walk(scene).render(ocam, 4, traversal=2)
     for k in ("interior_visits", "tri_tests", "plane_tests"):
         assert sb[k] == wst[k], k
 
 
-def test_a_camera_far_from_the_scene_gets_the_exact_walk_without_asking():
-    """The leaf boxes' bet fails, a few times in 10^4, for rays aimed along a triangle's plane from thousands of scene
-    sizes away (profiles/r04_tight_leaves.txt) and was never seen to fail from nearby.  Bounce rays start on the scene;
-    only a camera can stand far out -- and a frame whose camera is more than 8 root-box diagonals from the root box takes
-    the exact walk by itself (abi.cpp camera_is_far).  rayrs_render_stats.exact_walk reports the walk; the far frame's
-    counters are the oracle's for the gate tree with nothing culled."""
+def test_a_camera_far_from_the_scene_gets_the_default_walk_whatever_was_asked():
+    """The fast walk's leaf boxes fail, a few times in 10^4, for rays aimed along a triangle's plane from thousands of
+    primitive sizes away (profiles/r04_tight_leaves.txt) and were never seen to fail from nearby.  Bounce rays start on
+    the scene; only a camera can stand far out -- and a frame whose camera is more than 8 root-box diagonals, or 4096 of
+    the scene's small primitives, from the root box takes the default walk also when the fast one is asked for
+    (abi.cpp camera_is_far).  rayrs_render_stats.exact_walk reports the walk; the far frame's counters are the oracle's
+    for the gate tree with nothing culled."""
     mesh = lambda: scenes.mesh_scene(3)
     scene, cam, osc, ocam = both(mesh, 64, 48, 4)
     box = np.array(scene.info()["root_box"])
     diag = float(np.linalg.norm(box[1::2] - box[0::2]))
+    _, st = rayrs_amd.render(scene, cam, 4, out_f64=True, fast_traversal=True)
+    assert st["exact_walk"] == 0 and st["local_pool"] == 0           # the reference's own camera: the fast walk as asked
     _, st = rayrs_amd.render(scene, cam, 4, out_f64=True)
-    assert st["exact_walk"] == 0 and st["local_pool"] == 0           # the reference's own camera: the default walk
-    _, st = rayrs_amd.render(scene, cam, 4, out_f64=True, exact_traversal=True)
     assert st["exact_walk"] == 1
     # the same mesh through a long lens from 12 diagonals above the floor's corner
     far_o = (box[1] + 12.0 * diag * 0.6, 12.0 * diag * 0.8, 0.3)
     far = (far_o, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.45, 64 / 254.0, 48 / 254.0, 100)
-    near_o = tuple(0.5 * c for c in far_o)                             # 6 diagonals: still the default walk
+    near_o = tuple(0.5 * c for c in far_o)                             # 6 diagonals (and 3000 primitive sizes): the fast walk
     near = (near_o, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.9, 64 / 254.0, 48 / 254.0, 100)
     for cam_args, want in ((far, 1), (near, 0)):
         cam = rayrs_amd.Camera(*cam_args)
         ocam = _oracle.OracleCamera(*cam_args)
-        img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True)
+        img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True, fast_traversal=True)
         ref, ost = osc.render(ocam, 6, traversal=0)
         assert st["exact_walk"] == want
         assert_same_frame(img, ref)
         assert st["rays"] == ost["rays"] and st["tri_tests"] > 0      # the lens does see the mesh
-        try:
-            if want:
-                _oracle.set_cull_margin(float("inf"))
-            _, wst = osc.use_walk_tree(scene, gate=bool(want)).render(ocam, 6, traversal=2)
-        finally:
-            _oracle.set_cull_margin(2.0 ** -10)
+        _, wst = osc.use_product_walk(scene, fast=not want).render(ocam, 6, traversal=2)
         for k in ("interior_visits", "tri_tests", "plane_tests"):
             assert st[k] == wst[k], (want, k)
-    # the local-pool route makes neither bet whatever the camera
+    # the local-pool route makes neither bet whatever is asked
     scene, cam, osc, ocam = both(scenes.cook_torrance_spheres_metallic, 48, 32, 2)
-    _, st = rayrs_amd.render(scene, cam, 2)
+    _, st = rayrs_amd.render(scene, cam, 2, fast_traversal=True)
     assert st["local_pool"] == 1 and st["exact_walk"] == 1
 
 
@@ -319,23 +318,18 @@ def test_degenerate_and_extreme_primitives_render_the_oracles_frame():
         img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True, exact_traversal=exact)
         assert st["exact_walk"] == int(exact) and st["rays"] == ost["rays"]
         assert_same_frame(img, ref)
-        try:
-            if exact:
-                _oracle.set_cull_margin(float("inf"))
-            _, wst = osc.use_walk_tree(scene, gate=exact).render(ocam, 6, traversal=2)
-        finally:
-            _oracle.set_cull_margin(2.0 ** -10)
+        _, wst = osc.use_product_walk(scene, fast=not exact).render(ocam, 6, traversal=2)
         for k in ("interior_visits", "tri_tests", "sphere_tests", "plane_tests"):
             assert st[k] == wst[k], (exact, k)
 
 
 def test_the_culling_walk_on_the_gate_tree_is_still_there_for_comparisons():
     """rayrs_lab.h gate_tree: rounds 2 and 3 walked the reference's groups behind their gating boxes with closest-hit
-    culling; scripts/ubench/exact_cost.py prices the default tree against it.  Same frame, the oracle's counters."""
+    culling; scripts/ubench/exact_cost.py prices the fast walk's own tree against it.  Same frame, the oracle's counters."""
     scene, cam, osc, ocam = both(lambda: scenes.mesh_scene(4), 96, 64, 4)
-    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    a, sa = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=True)
     scene.lab_set(gate_tree=1)
-    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True)
+    b, sb = rayrs_amd.render(scene, cam, 4, out_f64=True, count_work=True, fast_traversal=True)
     scene.lab_set()
     assert_same_frame(a, b)
     _, wst = osc.use_walk_tree(scene, gate=True).render(ocam, 4, traversal=2)
@@ -397,7 +391,7 @@ def test_primary_rays_that_miss_the_root_box_are_answered_where_they_are_made():
     assert 0.2 < missed / (12 * 16) < 0.8  # the case is what it says
     for chunk in (0, 4, 5):
         img, st = rayrs_amd.render(scene, cam, 12, 50, sample_chunk=chunk, out_f64=True, count_work=True)
-        ref, ost = osc.use_walk_tree(scene).render(ocam, 12, 50, sample_chunk=chunk, traversal=2)
+        ref, ost = osc.use_product_walk(scene).render(ocam, 12, 50, sample_chunk=chunk, traversal=2)
         for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "plane_tests"):
             assert st[k] == ost[k], (chunk, k)
         assert 0.3 * 64 * 48 * 12 < st["direct_rays"] < 0.7 * 64 * 48 * 12
@@ -467,7 +461,7 @@ def test_random_scenes_render_the_oracles_frame(seed):
     assert not scene.info()["compact"]
     chunk = (0, 4)[seed & 1]
     img, st = rayrs_amd.render(scene, cam, 6, 50, seed=seed, sample_chunk=chunk, out_f64=True, count_work=True)
-    ref, ost = osc.use_walk_tree(scene).render(ocam, 6, 50, seed=seed, sample_chunk=chunk, traversal=2)
+    ref, ost = osc.use_product_walk(scene).render(ocam, 6, 50, seed=seed, sample_chunk=chunk, traversal=2)
     for k in ("rays", "paths", "escaped_paths", "interior_visits", "tri_tests", "sphere_tests", "plane_tests",
               "nan_pixels", "neg_pixels"):
         assert st[k] == ost[k], k

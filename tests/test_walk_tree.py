@@ -1,6 +1,7 @@
-"""The tree the kernels walk (rayrs_amd/csrc/scene_host.cpp build_walk_trees) returns the
-reference's hits.  CPU only: the product builds the tree host-side (device = -1), the oracle walks
-it with the kernel's rules (traversal 2: nearest slot first, boxes beyond the closest hit culled)
+"""The trees the kernels walk (rayrs_amd/csrc/scene_host.cpp build_walk_trees) return the
+reference's hits.  CPU only: the product builds the trees host-side (device = -1), the oracle walks
+them with the kernel's rules (traversal 2: the fast walk's tree nearest slot first, boxes beyond the closest hit
+culled; the default walk's gate tree with nothing culled)
 and is compared with its restatement of the reference's recursion (traversal 0, bvh.rs:391-415),
 bit for bit, on the cases where a different topology could show: degenerate rays, unhittable flat
 boxes, direct leaves, coincident and abutting primitives (equal-t ties, bvh.rs:62)."""
@@ -23,7 +24,7 @@ def both_walks(objs, heur, o, d, t0=1e-6, t1=1e6):
     wt, wobj = osc.intersect_many(o, d, t0, t1, traversal=2)
     assert np.array_equal(wobj, robj)
     assert np.array_equal(wt.view(np.uint64), rt.view(np.uint64))
-    # rayrs_render_params.exact_traversal's walk: the gate tree, nothing culled
+    # the default walk: the gate tree, nothing culled
     osg = _oracle.OracleScene(objs, t0, t1, heur, HDRI).use_walk_tree(prod, gate=True)
     try:
         _oracle.set_cull_margin(float("inf"))
@@ -156,33 +157,42 @@ def test_hostile_rays_and_scene_scales():
 
 
 def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
-    """The default walk's two bets (closest-hit culling at 1 + 2^-10, single primitives behind boxes widened by
-    1/64; the reference does neither: include/rayrs_hip.h exact_traversal) against the reference's recursion where
+    """The fast walk's two bets (rayrs_render_params.fast_traversal: closest-hit culling at 1 + 2^-10, single primitives
+    behind boxes widened by 1/64; the reference does neither, and neither does the default walk) against the reference's recursion where
     Moeller-Trumbore is least accurate: sliver triangles, nearly flat sheets, origins up to 1e6 scene sizes away,
     general directions down to 1e-7 rad over the sheet and rays aimed along a triangle's own plane.
-    The default walk must match on the general family and on grazing rays 1e-7 rad and more off the plane from
-    within 8 root-box diagonals of the scene (from farther out a frame takes the exact walk by itself: abi.cpp
-    camera_is_far); the exact walk (gate tree, nothing culled) on every ray of every family, by construction.
+    The fast walk must match on the general family and on grazing rays 1e-7 rad and more off the plane from
+    within 8 root-box diagonals and 4096 small-primitive sizes of the scene (from farther out a frame takes the default
+    walk whatever it asks for: abi.cpp camera_is_far) -- on the sheets of 6 ... 40 quads per side on which that was
+    measured in round 4, with a floor under them, and on a sheet of 350 well-shaped quads per side; on a sheet of 320
+    SLIVER quads per side (seed 11, round 5) its culling loses hits to in-plane rays at 1e-7 rad and more from ANY
+    distance (a few in 10^4): counted here, not required -- which is why the fast walk is the caller's choice and not
+    the default.  The default walk (gate tree, nothing culled) matches on every ray of every family, by construction.
     scripts/fuzz_traversal.py is the same over 1e8 rays; this is 1.6 M.  The probe measures the cull margin itself:
     how far in front of a box around it a hit's t can lie."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import fuzz_traversal as F
     hdri = np.zeros((2, 2, 3), dtype=np.float32)
-    worst_general, hits, elsewhere = -1.0, 0, 0
-    for seed in range(1, 9):  # seed 4: an exactly flat sheet, whose boxes nothing can enter (geometry.rs:474)
+    worst_general, hits, elsewhere, fine_slivers = -1.0, 0, 0, 0
+    # seed 4: an exactly flat sheet, whose boxes nothing can enter (geometry.rs:474); 11 and 22: sheets of 250+ quads per side (a
+    # camera 8 diagonals out stands thousands of primitive sizes away), 11 of slivers; 13: a floor fifty sheets wide under the sheet
+    for seed in list(range(1, 9)) + [11, 13, 22]:
         objs, heur, scale, verts, idx = F.scene_for(seed)
         t0, t1 = 1e-6 * scale, 1e9 * scale
         prod = rayrs_amd.Scene(objs, t0, t1, heur, hdri, device=-1)
         osc = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(prod)
         osg = _oracle.OracleScene(objs, t0, t1, heur, hdri).use_walk_tree(prod, gate=True)
-        for name, o, d in F.families(seed, verts, idx, scale, 200_000, prod.info()["root_box"]):
+        for name, o, d in F.families(seed, verts, idx, scale, 200_000 if seed < 10 else 60_000, prod.info()["root_box"],
+                                     F.small_extent(verts, idx)):
             rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)
             wt, wobj = osc.intersect_batch(o, d, t0, t1, traversal=2)
             same = (wobj == robj) & (wt.view(np.uint64) == rt.view(np.uint64))
-            if name in F.REQUIRED:
+            if name in F.REQUIRED and not (seed == 11 and name != "general"):
                 assert same.all(), (seed, name)
                 hits += int((robj >= 0).sum())
+            elif name in F.REQUIRED:
+                fine_slivers += int((~same).sum())
             else:
                 elsewhere += int((~same).sum())
             try:
@@ -197,12 +207,14 @@ def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
                 assert beyond == 0
     assert hits > 500_000
     assert 0 < elsewhere < 2000  # the bets do fail out there (a few in 1e4 rays aimed along a plane from far away)
+    assert 0 < fine_slivers < 100  # ... and, on finely tessellated slivers, from nearby too
     assert worst_general < 2.0 ** -40  # general rays: a hit precedes a box of its own by ulps only
 
 
 def test_the_bets_are_heuristics_and_this_is_where_they_end():
-    """The failures the default walk cannot exclude, pinned (found by scripts/fuzz_traversal.py), one of each kind;
-    rayrs_render_params.exact_traversal's walk -- the gate tree, nothing culled -- returns the reference's answer.
+    """The failures the fast walk (rayrs_render_params.fast_traversal) cannot exclude, pinned (found by
+    scripts/fuzz_traversal.py), one of each kind; the default walk -- the gate tree, nothing culled -- returns the
+    reference's answer.
     Culling: a ray within 1e-9 rad of a triangle's plane from 4600 triangle sizes away puts that triangle's t 2 % in
     front of its gating box (seed 79); a walk that has already found the neighbour behind it skips the box.
     Leaf boxes: a ray aimed along a triangle's plane from 130 000 scene sizes away, 1e-5 rad off it (seed 2): the
