@@ -337,6 +337,13 @@ typedef struct {
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
 int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
 
+/* The boundary's version: bumped whenever a struct of this header changes the meaning of a field or an entry point
+ * its behaviour.  5 = round 5: rayrs_render_params.exact_traversal became fast_traversal (opposite sense: zero is now
+ * the reference's visit set), the device self-test hooks left this header.  Every struct a caller fills must be zero-initialised
+ * first: fields are added where padding used to be, and values out of a field's range are refused. */
+#define RAYRS_ABI_VERSION 5
+uint32_t rayrs_abi_version(void);
+
 /* ---- layout of the structs above as THIS library was compiled, for bindings in other languages
  * to check theirs against (tests/test_abi.py does it for rayrs_amd/_ffi.py, and INTEGRATION.md's
  * #[repr(C)] structs carry the same numbers).  Writes up to `cap` words to `out` and returns the
@@ -344,25 +351,6 @@ int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
  * rayrs_emission, rayrs_camera, rayrs_scene_info_t, rayrs_render_params, rayrs_render_stats,
  * rayrs_tuning: sizeof, number of fields, then offsetof of every field in declaration order. */
 uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);
-
-/* ---- device self-test hooks (used by tests/ to check single functions
- *      of the hot path on the GPU against the oracle) ---- */
-
-/* fn: 0 sin 1 cos 2 tan 3 log 4 exp 5 acos 6 atan2(x[i], y[i]) 7 sqrt
- *     8 x/y 9 rng bits (x,y reinterpreted: unused) */
-int rayrs_test_math(int device, int fn, const double* x, const double* y, uint64_t n, double* out);
-int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint64_t* sample, const uint32_t* draw,
-                   uint64_t n, uint64_t* out_bits);
-/* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  exact: 1 = the default walk, 0 = the fast one */
-int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
-                         int64_t* object);
-/* Material::evaluate for n (normal, view, key) tuples with one material:
- * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */
-int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
-                        const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
-                        uint32_t* draws);
-/* Scene::background for n directions. */
-int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
 
 /* ---- file formats either side of the path (host only) ---- */
 

@@ -20,12 +20,15 @@ SYMBOLS = [
     "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
     "rayrs_camera_new",
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
-    "rayrs_abi_layout",
-    "rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material",
-    "rayrs_test_background",
+    "rayrs_abi_layout", "rayrs_abi_version",
     "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
     "rayrs_hdr_load", "rayrs_hdr_save", "rayrs_image_to_bytes", "rayrs_ppm_save", "rayrs_png_save",
 ]
+
+
+# rayrs_amd/csrc/rayrs_selftest.h and rayrs_lab.h: private hooks of the library (tests/ and scripts/ only)
+PRIVATE_SYMBOLS = ["rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material", "rayrs_test_background",
+                   "rayrs_lab_set", "rayrs_lab_round_ms"]
 
 
 class MaterialDesc(C.Structure):
@@ -142,6 +145,8 @@ def lib():
     L.rayrs_frame_sample_chunk.restype = C.c_uint32
     L.rayrs_abi_layout.argtypes = [vp, C.c_uint32]
     L.rayrs_abi_layout.restype = C.c_uint32
+    L.rayrs_abi_version.argtypes = []
+    L.rayrs_abi_version.restype = C.c_uint32
     L.rayrs_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(CameraDesc), C.POINTER(RenderParams), vp,
                                      C.POINTER(RenderStats)]
     L.rayrs_camera_new.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_uint32,

@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "local_pool.h"
 #include "rayrs_lab.h"
+#include "rayrs_selftest.h"
 #include "scene_host.hpp"
 #include "scene_internal.hpp"
 #include "wavefront.h"
@@ -512,6 +513,8 @@ uint32_t rayrs_frame_sample_chunk(uint32_t x_pixels, uint32_t y_pixels, uint32_t
     while (chunk < spp && pixels * ((spp + chunk - 1) / chunk) > (1ull << 30)) chunk *= 2;
     return chunk >= spp ? 0u : (uint32_t)chunk;  // 0 = one sequential sum per pixel (the reference's order)
 }
+
+uint32_t rayrs_abi_version(void) { return RAYRS_ABI_VERSION; }
 
 uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     std::vector<uint32_t> t;

@@ -186,6 +186,24 @@ def test_the_public_header_lists_no_experiment_selector():
     for word in ("leaf_group", "trav_queries", "stream_pool", "hit_blocks_per_cu", "pipelines", "rayrs_lab", "refill_min"):
         assert not re.search(rf"\b{word}\b(?!\.h)", hdr), word
     assert not os.path.exists(os.path.join(ROOT, "rayrs_amd", "csrc", "stream_pool.hip"))
+    # the device self-test hooks are not the boundary either: rayrs_amd/csrc/rayrs_selftest.h declares them
+    assert "rayrs_test_" not in hdr
+    priv = open(os.path.join(ROOT, "rayrs_amd", "csrc", "rayrs_selftest.h")).read() + open(os.path.join(ROOT, "rayrs_amd", "csrc", "rayrs_lab.h")).read()
+    L = _ffi.lib()
+    for name in _ffi.PRIVATE_SYMBOLS:
+        assert re.search(rf"\b{name}\s*\(", priv), name
+        assert hasattr(L, name), name
+
+
+def test_abi_version_and_zero_initialised_params():
+    """RAYRS_ABI_VERSION is what the library was compiled with; a zero-initialised rayrs_render_params asks for the
+    reference's visit set (fast_traversal = 0), and a field out of range is refused, not interpreted."""
+    L = _ffi.lib()
+    hdr = open(os.path.join(ROOT, "include", "rayrs_hip.h")).read()
+    assert int(re.search(r"#define RAYRS_ABI_VERSION (\d+)", hdr).group(1)) == L.rayrs_abi_version() >= 5
+    p = _ffi.RenderParams()
+    assert p.fast_traversal == 0
+    assert rayrs_amd.make_params(4).fast_traversal == 0 and rayrs_amd.make_params(4, fast_traversal=True).fast_traversal == 1
 
 
 def test_which_route_a_scene_takes_is_decided_at_scene_new_and_needs_no_gpu():
