@@ -335,11 +335,12 @@ def main():
                 turn["n"] += 1
                 cv.notify_all()
 
-        def frames(n_frames, stagger_s=0.0):
-            """Renders n_frames frames, frame k on flight k % F; returns their stats in frame order.  Flight i starts
-            i * stagger_s late, so that the flights' frames end at different times."""
+        def frames(n_frames, stagger_s=0.0, nf=None):
+            """Renders n_frames frames, frame k on flight k % nf (default: all F flights); returns their stats in frame
+            order.  Flight i starts i * stagger_s late, so that the flights' frames end at different times."""
             stats = [None] * n_frames
             turn["n"], turn["failed"] = 0, None
+            nf = max(1, min(nf or F, F, n_frames))
 
             def flight(i):
                 try:
@@ -348,7 +349,7 @@ def main():
                     if i and stagger_s > 0.0:
                         time.sleep(i * stagger_s)
                     with torch.cuda.stream(f["stream"]):
-                        for k in range(i, n_frames, F):
+                        for k in range(i, n_frames, nf):
                             fb.zero_()
                             rayrs_amd.render_launch(f["scene"], cam, params, fb.data_ptr(), f["stream"].cuda_stream)
                             if use_dist and args.backend == "nccl":
@@ -368,15 +369,22 @@ def main():
                         turn["failed"] = e
                         cv.notify_all()
 
-            if F == 1:
+            if nf == 1:
                 flight(0)
             else:
-                th = [threading.Thread(target=flight, args=(i,)) for i in range(F)]
+                th = [threading.Thread(target=flight, args=(i,)) for i in range(nf)]
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
             if turn["failed"] is not None:
+                if use_dist:
+                    # a flight that died before its collective leaves the other ranks waiting in the reduce for ever:
+                    # end the process (torch.distributed.run then ends the job) instead of raising into a hung group
+                    import traceback
+                    traceback.print_exception(type(turn["failed"]), turn["failed"], turn["failed"].__traceback__)
+                    sys.stderr.flush()
+                    os._exit(3)
                 raise turn["failed"]
             return stats
 
@@ -386,8 +394,11 @@ def main():
             torch.cuda.synchronize(dev)
 
         st = None
-        if warmup:
-            st = frames(warmup)[-1]
+        # every flight renders at least one untimed frame: a clone's first frame allocates its path pool, stack strip
+        # and round events (with --warmup 1 and two flights the second one did that inside the timed region)
+        n_warm = max(warmup, F) if (warmup and F > 1) else warmup
+        if n_warm:
+            st = frames(n_warm)[-1]
         fence()
         t_begin = time.perf_counter()
         timed = frames(steps, stagger_s=(st["trace_ms"] * 1e-3 / F) if (st is not None and F > 1 and not args.no_stagger) else 0.0)
@@ -396,6 +407,15 @@ def main():
         st = timed[-1]
         fb = fbs[(steps - 1) % F]
         rays = sum(t["rays"] for t in timed)
+        # frames in flight make ms_per_step a throughput figure; beside it, the same frames one after the other (one
+        # flight: render, reduce, next frame), so that an N-GPU line can be read against the 1-GPU line like for like
+        unpipelined_s = None
+        if F > 1:
+            fence()
+            t_u = time.perf_counter()
+            frames(2, nf=1)
+            fence()
+            unpipelined_s = (time.perf_counter() - t_u) / 2.0
         alone_ms = None
         if F > 1 and want_roofline:
             # the kernels' own durations: one more frame, rendered alone (with frames in flight the kernels of two
@@ -412,13 +432,15 @@ def main():
         hit_ms = [t["hit_ms"] for t in timed_for_kernels]
         miss_ms = [t["miss_ms"] for t in timed_for_kernels]
 
-        tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tot = torch.tensor([float(rays), elapsed, unpipelined_s or 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         if use_dist:
             r = tot[:1].clone()
             e = tot[1:].clone()
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
-            total_rays, max_elapsed = float(r.item()), float(e.item())
+            total_rays, max_elapsed = float(r.item()), float(e[0].item())
+            if unpipelined_s is not None:
+                unpipelined_s = float(e[1].item())
         else:
             total_rays, max_elapsed = float(rays), elapsed
         checksum, fb_sha = 0.0, None
@@ -540,6 +562,7 @@ def main():
                 "fp64_valu_busy": valu_busy, "valu_wave_instructions_per_ray": valu_per_ray, "pmc_source": pmc_src,
             }
         return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6, "flights": F,
+                "warm_frames": n_warm, "unpipelined_ms": None if unpipelined_s is None else unpipelined_s * 1e3,
                 "frame_alone_ms": alone_ms,
                 "ms_per_step": max_elapsed / steps * 1e3, "rays_per_step": int(total_rays / steps),
                 "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares,
@@ -644,7 +667,11 @@ def main():
                 # runs beside the start of the next), so ms_per_step = timed region / steps is a throughput figure and
                 # frame_alone_ms the latency of a frame rendered with the GPU to itself
                 "frames_in_flight": main_run["flights"],
+                "untimed_frames_before_the_timed_region": main_run["warm_frames"],  # = warmup, or one per flight if that is more
                 "frame_alone_ms": None if main_run["frame_alone_ms"] is None else round(main_run["frame_alone_ms"], 2),
+                # the same work without the overlap: two more frames rendered one after the other on one flight, render +
+                # framebuffer reduce each, max over ranks -- the figure to hold against a 1-GPU line's ms_per_step
+                "unpipelined_ms_per_frame": None if main_run["unpipelined_ms"] is None else round(main_run["unpipelined_ms"], 2),
                 # which walk answered the timed frames' BVH queries (rayrs_render_stats.exact_walk)
                 "walk": ("local pool: the gate tree's groups, nothing culled (the reference's visit set)" if main_run["local_pool"] else
                          "default: the gate tree, nothing culled -- the reference's visit set by construction" if main_run["exact_walk"]

@@ -1727,7 +1727,33 @@ typedef struct {
     trav_counters trav;
 } path_counters;
 
+/* A path's trace (orc_path_trace): per loop iteration of radiance() the object the query found (-1: none), its t (0 for
+ * a miss), and the throughput and the RNG's draw index on leaving the iteration. */
+typedef struct {
+    uint32_t cap, n;
+    int64_t* obj;
+    double* t;
+    double* thr;
+    uint32_t* draw;
+} path_trace;
+
+static void trace_put(path_trace* tr, uint32_t b, int64_t obj, double t, v3 thr, uint32_t draw) {
+    if (!tr) return;
+    if (b < tr->cap) {
+        tr->obj[b] = obj, tr->t[b] = t, tr->draw[b] = draw;
+        tr->thr[3 * b] = thr.x, tr->thr[3 * b + 1] = thr.y, tr->thr[3 * b + 2] = thr.z;
+    }
+    tr->n = b + 1;
+}
+
+static v3 radiance_traced(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng, int traversal, path_counters* pc,
+                          path_trace* tr);
 static v3 radiance(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng, int traversal, path_counters* pc) {
+    return radiance_traced(s, r, max_bounces, rng, traversal, pc, NULL);
+}
+
+static v3 radiance_traced(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng, int traversal, path_counters* pc,
+                          path_trace* tr) {
     v3 throughput = V(1.0, 1.0, 1.0);
     v3 light = V(0.0, 0.0, 0.0);
     for (uint32_t b = 0; b < max_bounces; b++) {
@@ -1743,15 +1769,21 @@ static v3 radiance(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng
                 light = v_add(light, v_mul(throughput, emis_emit(&s->emis[obj->emis])));
                 throughput = v_mul(throughput, ev.color);
                 double p = rr_max(rr_max(throughput.x, throughput.y), throughput.z);
-                if (rng_next(rng) > p) return light;
+                if (rng_next(rng) > p) {
+                    trace_put(tr, b, h.obj, h.t, throughput, rng->draw);
+                    return light;
+                }
                 throughput = v_div_assign(throughput, p);
                 r.o = position;
                 r.d = ev.dir;
+                trace_put(tr, b, h.obj, h.t, throughput, rng->draw);
             } else {
+                trace_put(tr, b, h.obj, h.t, throughput, rng->draw);
                 return light;
             }
         } else {
             if (pc) pc->escaped++;
+            trace_put(tr, b, -1, 0.0, throughput, rng->draw);
             return v_add(light, v_mul(throughput, background(s, r.d)));
         }
     }
@@ -2066,6 +2098,21 @@ void orc_primary_ray(const orc_camera* c, uint32_t i, uint32_t j, uint64_t key, 
     *draw = rng.draw;
     v_to(r.o, o);
     v_to(r.d, d);
+}
+
+/* The sample (pixel row, col of the image; sample index) exactly as orc_render starts it (path key, primary ray,
+ * radiance), with its trace: returns the number of loop iterations; the first min(that, cap) entries of the arrays are
+ * filled.  rgb: radiance()'s return value. */
+uint32_t orc_path_trace(const orc_scene* s, const orc_camera* c, uint32_t row, uint32_t col, uint32_t sample, uint64_t seed,
+                        uint32_t max_bounces, int traversal, uint32_t cap, int64_t* obj, double* t, double* thr,
+                        uint32_t* draw, double rgb[3]) {
+    rng_t rng;
+    rng.key = rr_path_key(seed, (uint64_t)row * c->x_pixels + col, sample);
+    rng.draw = 0;
+    ray_t r = primary_ray(c, c->y_pixels - row, c->x_pixels - col, &rng); /* main.rs:74-75: camera origin is lower right */
+    path_trace tr = {cap, 0, obj, t, thr, draw};
+    v_to(radiance_traced(s, r, max_bounces, &rng, traversal, NULL, &tr), rgb);
+    return tr.n;
 }
 
 uint32_t orc_radiance(const orc_scene* s, const double o[3], const double d[3], uint32_t max_bounces, uint64_t key,

@@ -169,6 +169,12 @@ int orc_material_evaluate(const orc_material* m, const double position[3], const
 void orc_background(const orc_scene* s, const double dir[3], double rgb[3]);
 void orc_primary_ray(const orc_camera* c, uint32_t i, uint32_t j, uint64_t key, uint32_t* draw, double o[3],
                      double d[3]);
+/* One sample as orc_render starts it (path key from (seed, pixel, sample), primary ray, radiance) with its trace: per
+ * iteration of radiance()'s loop the object found (-1 none), t (0 for a miss), the throughput and the RNG draw index
+ * on leaving the iteration.  Returns the number of iterations; min(that, cap) entries are written. */
+uint32_t orc_path_trace(const orc_scene* s, const orc_camera* c, uint32_t row, uint32_t col, uint32_t sample, uint64_t seed,
+                        uint32_t max_bounces, int traversal, uint32_t cap, int64_t* obj, double* t, double* thr,
+                        uint32_t* draw, double rgb[3]);
 /* radiance() for one path; returns number of BVH queries. */
 uint32_t orc_radiance(const orc_scene* s, const double o[3], const double d[3], uint32_t max_bounces, uint64_t key,
                       uint32_t* draw, int traversal, double rgb[3]);

@@ -27,7 +27,7 @@ SYMBOLS = [
 
 
 # rayrs_amd/csrc/rayrs_selftest.h and rayrs_lab.h: private hooks of the library (tests/ and scripts/ only)
-PRIVATE_SYMBOLS = ["rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_material", "rayrs_test_background",
+PRIVATE_SYMBOLS = ["rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_path_trace", "rayrs_test_material", "rayrs_test_background",
                    "rayrs_lab_set", "rayrs_lab_round_ms"]
 
 
@@ -157,6 +157,8 @@ def lib():
     L.rayrs_test_math.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp]
     L.rayrs_test_rng.argtypes = [C.c_int, C.c_uint64, vp, vp, vp, C.c_uint64, vp]
     L.rayrs_test_intersect.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, vp, vp]
+    L.rayrs_test_path_trace.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_int, C.c_uint32,
+                                        vp, vp, vp, vp, vp, vp]
     L.rayrs_test_material.argtypes = [C.c_int, mp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     L.rayrs_test_background.argtypes = [vp, vp, C.c_uint64, vp]
     L.rayrs_io_last_error.restype = C.c_char_p

@@ -1093,6 +1093,49 @@ int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, u
     return RAYRS_OK;
 }
 
+int rayrs_test_path_trace(rayrs_scene* scene, const rayrs_camera* camera, uint64_t seed, uint32_t max_bounces,
+                          const uint32_t* pixel, const uint32_t* sample, uint64_t n, int exact, uint32_t cap,
+                          uint32_t* n_queries, int64_t* object, double* t, double* throughput, uint32_t* draw, double* rgb) {
+    if (!scene || !camera || !pixel || !sample || !n_queries || !object || !t || !throughput || !draw || !rgb || cap == 0)
+        return RAYRS_INVALID_ARG;
+    if (scene->device < 0) return RAYRS_NO_DEVICE;
+    for (uint64_t i = 0; i < n; i++)
+        if ((pixel[i] >> 16) >= camera->y_pixels || (pixel[i] & 0xffffu) >= camera->x_pixels) return RAYRS_INVALID_ARG;
+    HIP_TRY(hipSetDevice(scene->device));
+    DevBuf dpix, dsam, dn, dprim, dt, dthr, ddraw, drgb, dspill;
+    ST_TRY(dpix.upload(pixel, n * 4));
+    ST_TRY(dsam.upload(sample, n * 4));
+    ST_TRY(dn.alloc(n * 4));
+    ST_TRY(dprim.alloc(n * cap * 4));
+    ST_TRY(dt.alloc(n * cap * 8));
+    ST_TRY(dthr.alloc(n * cap * 24));
+    ST_TRY(ddraw.alloc(n * cap * 4));
+    ST_TRY(drgb.alloc(n * 24));
+    HIP_TRY(hipMemset(dprim.p, 0xff, n * cap * 4));
+    HIP_TRY(hipMemset(dt.p, 0, n * cap * 8));
+    HIP_TRY(hipMemset(dthr.p, 0, n * cap * 24));
+    HIP_TRY(hipMemset(ddraw.p, 0, n * cap * 4));
+    const SceneDev sc = make_scene_dev(scene, exact != 0);
+    const CameraDev cam = make_camera_dev(camera);
+    const uint64_t threads = (n + 255) / 256 * 256;
+    if (sc.stack_depth > sc.stack_lds) ST_TRY(dspill.alloc((size_t)(sc.stack_depth - sc.stack_lds) * threads * 4));
+    if (n)
+        HIP_TRY(launch_test_path_trace(scene->flat.compact, sc, cam, seed, max_bounces, (const uint32_t*)dpix.p,
+                                       (const uint32_t*)dsam.p, n, cap, (uint32_t*)dn.p, (uint32_t*)dprim.p, (double*)dt.p,
+                                       (double*)dthr.p, (uint32_t*)ddraw.p, (double*)drgb.p, (uint32_t*)dspill.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> prim(n * cap);
+    ST_TRY(dn.download(n_queries, n * 4));
+    ST_TRY(dprim.download(prim.data(), n * cap * 4));
+    ST_TRY(dt.download(t, n * cap * 8));
+    ST_TRY(dthr.download(throughput, n * cap * 24));
+    ST_TRY(ddraw.download(draw, n * cap * 4));
+    ST_TRY(drgb.download(rgb, n * 24));
+    for (uint64_t k = 0; k < n * cap; k++)  // DFS slot -> object index in insertion order
+        object[k] = prim[k] == 0xffffffffu ? -1 : (int64_t)scene->flat.prim_object[prim[k]];
+    return RAYRS_OK;
+}
+
 int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,
                         const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
                         uint32_t* draws) {

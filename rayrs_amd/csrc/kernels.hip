@@ -148,6 +148,97 @@ hipError_t launch_test_intersect(bool compact, const SceneDev& sc, const double*
     return hipGetLastError();
 }
 
+// One sample exactly as the path kernels run it -- the path key, the primary ray (wavefront.hip next_sample), then the
+// loop of lib.rs:521-560 with the device functions of device_path.h -- in ONE lane from the first ray to the last, with
+// its trace: per loop iteration the primitive the query found (0xffffffff: none), its t, and the throughput and the
+// RNG's draw index on leaving the iteration (rayrs_selftest.h rayrs_test_path_trace; the CPU checker keeps the same).
+template <bool COMPACT>
+__global__ void __launch_bounds__(256) test_path_trace_kernel(SceneDev sc, CameraDev cam, uint64_t seed, uint32_t max_bounces,
+                                                              const uint32_t* pix, const uint32_t* sample, uint64_t n,
+                                                              uint32_t cap, uint32_t* n_out, uint32_t* prim_out, double* t_out,
+                                                              double* thr_out, uint32_t* draw_out, double* rgb_out,
+                                                              uint32_t* spill) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const LaneStack stack{lds_stack + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane, spill + i, sc.stack_lds,
+                          gridDim.x * blockDim.x};
+    if (i >= n) return;
+    const uint32_t row = pix[i] >> 16, col = pix[i] & 0xffffu;
+    Rng rng{rr_path_key(seed, (uint64_t)row * cam.W + col, (uint64_t)sample[i]), 0};
+    V3 o, d;
+    primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);  // image origin is upper left, camera origin lower right (main.rs:74-75)
+    V3 thr = mk(1.0, 1.0, 1.0), light = mk(0.0, 0.0, 0.0), result = mk(0.0, 0.0, 0.0);
+    uint32_t b = 0;
+    bool returned = false;
+    auto put = [&](uint32_t prim, double t) {
+        if (b < cap) {
+            const size_t at = (size_t)i * cap + b;
+            prim_out[at] = prim, t_out[at] = t, draw_out[at] = rng.draw;
+            thr_out[3 * at] = thr.x, thr_out[3 * at + 1] = thr.y, thr_out[3 * at + 2] = thr.z;
+        }
+    };
+    for (; b < max_bounces && !returned; b++) {
+        double t = 0.0;
+        uint32_t prim = 0xffffffffu;
+        WorkCount wc{0, 0, 0, 0, 0};
+        const bool hit = sc.exact ? bvh_intersect<COMPACT, false, true>(sc, o, d, stack, t, prim, wc)
+                                  : bvh_intersect<COMPACT, false, false>(sc, o, d, stack, t, prim, wc);
+        if (!hit) {
+            put(0xffffffffu, 0.0);
+            result = v_add(light, v_mul(thr, background(sc, d)));  // lib.rs:555
+            returned = true;
+            continue;
+        }
+        const PrimRec<COMPACT> rec = load_prim<COMPACT>(sc.prims, prim);
+        const V3 position = v_add(o, v_scale(d, t));
+        const V3 normal = prim_normal<COMPACT>(rec, position);
+        const V3 view = v_unit(v_scale(d, -1.0));
+        const SurfaceDev* surf = sc.surfaces + (rec.tag() >> 8);
+        const Scatter ev = material_evaluate(surf, normal, view, rng);
+        if (!ev.scatter) {  // lib.rs:550
+            put(prim, t);
+            result = light, returned = true;
+            continue;
+        }
+        light = v_add(light, v_mul(thr, mk(surf->emit[0], surf->emit[1], surf->emit[2])));
+        thr = v_mul(thr, ev.color);
+        const double p = rr_max(rr_max(thr.x, thr.y), thr.z);
+        if (rng.next() > p) {
+            put(prim, t);
+            result = light, returned = true;
+            continue;
+        }
+        thr = mk(thr.x / p, thr.y / p, thr.z / p);  // DivAssign, vecmath.rs:708-714
+        o = position, d = ev.dir;
+        put(prim, t);
+    }
+    if (!returned) result = light;  // lib.rs:559
+    n_out[i] = b;
+    rgb_out[3 * i] = result.x, rgb_out[3 * i + 1] = result.y, rgb_out[3 * i + 2] = result.z;
+}
+
+hipError_t launch_test_path_trace(bool compact, const SceneDev& sc, const CameraDev& cam, uint64_t seed, uint32_t max_bounces,
+                                  const uint32_t* pix, const uint32_t* sample, uint64_t n, uint32_t cap, uint32_t* n_out,
+                                  uint32_t* prim_out, double* t_out, double* thr_out, uint32_t* draw_out, double* rgb_out,
+                                  uint32_t* spill, hipStream_t stream) {
+    const uint32_t lds = lds_bytes_for(sc.stack_lds);
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (compact) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&test_path_trace_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(test_path_trace_kernel<true>, dim3(blocks), dim3(256), lds, stream, sc, cam, seed, max_bounces, pix,
+                           sample, n, cap, n_out, prim_out, t_out, thr_out, draw_out, rgb_out, spill);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&test_path_trace_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(test_path_trace_kernel<false>, dim3(blocks), dim3(256), lds, stream, sc, cam, seed, max_bounces, pix,
+                           sample, n, cap, n_out, prim_out, t_out, thr_out, draw_out, rgb_out, spill);
+    }
+    return hipGetLastError();
+}
+
 __global__ void test_material_kernel(const SurfaceDev* surf, const double* normal, const double* view,
                                      const uint64_t* key, uint64_t n, int32_t* scattered, double* color, double* dir,
                                      uint32_t* draws) {

@@ -23,6 +23,14 @@ int rayrs_test_rng(int device, uint64_t seed, const uint64_t* pixel, const uint6
 /* Bvh::intersect for n rays (o,d = n*3): t[i] and the object index (-1 miss).  exact: 1 = the default walk, 0 = the fast one */
 int rayrs_test_intersect(rayrs_scene* scene, const double* o, const double* d, uint64_t n, int exact, double* t,
                          int64_t* object);
+/* n samples, each exactly as a render starts and runs it -- the path key of (seed, pixel, sample), the primary ray, the
+ * loop of lib.rs:521-560 -- in one lane each, with their traces: for sample i, n_queries[i] loop iterations, and for
+ * the first min(n_queries[i], cap) of them object[i*cap + b] (-1: the query found nothing), t (0 then), throughput
+ * (3 doubles) and the RNG draw index on leaving iteration b; rgb[i*3..]: radiance()'s value.  pixel[i] = row << 16 |
+ * col in image coordinates.  exact: as rayrs_test_intersect. */
+int rayrs_test_path_trace(rayrs_scene* scene, const rayrs_camera* camera, uint64_t seed, uint32_t max_bounces,
+                          const uint32_t* pixel, const uint32_t* sample, uint64_t n, int exact, uint32_t cap,
+                          uint32_t* n_queries, int64_t* object, double* t, double* throughput, uint32_t* draw, double* rgb);
 /* Material::evaluate for n (normal, view, key) tuples with one material:
  * scattered[i] 0/1, color/dir = n*3, draws[i] = number of draws consumed. */
 int rayrs_test_material(int device, const rayrs_material* mat, const double* normal, const double* view,

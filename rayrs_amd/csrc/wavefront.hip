@@ -410,7 +410,9 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
         for (uint32_t k = 0; k < count; k += 64u) {
             const bool valid = k + lane < count;
             const uint32_t slot = win * WINDOW + (valid ? (uint32_t)list[k + lane] : 0u);
-            // an IDLE slot has no item (wf_init_kernel: cursor word 0): nothing of its line needs reading
+            // an IDLE slot has no item BY DEFINITION: wf_init_kernel writes the state bytes only, and the slot's line still
+            // holds whatever the previous frame left there -- so nothing of it may be read (tests/test_gpu_render.py
+            // ::test_two_different_frames_back_to_back_on_one_scene); the item starts from zeros made here
             ItemRegs ir;
             ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
             ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;

@@ -103,6 +103,9 @@ def lib():
     L.orc_aabb_expand.restype = None
     L.orc_bvh_intersect_batch.argtypes = [vp, C.c_uint64, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     L.orc_cull_margin_probe.argtypes = [vp, C.c_uint64, vp, vp, C.c_double, C.c_double, C.c_int, vp]
+    L.orc_path_trace.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, vp, vp, vp, vp,
+                                 C.POINTER(C.c_double)]
+    L.orc_path_trace.restype = C.c_uint32
     L.orc_set_cull_margin.argtypes = [C.c_double]
     L.orc_set_cull_margin.restype = None
     L.orc_set_math_mode.argtypes = [C.c_int]
@@ -322,6 +325,21 @@ class OracleScene:
         for i in range(len(dirs)):
             self._L.orc_background(self._h, d3(dirs[i]), rgb)
             out[i] = rgb[:]
+        return out
+
+    def path_traces(self, cam, pixels, samples, seed, max_bounces=50, cap=64, traversal=0):
+        """Traces of the samples (row, col, sample index) as orc_render runs them: dict of arrays n[k], obj[k, cap],
+        t[k, cap], thr[k, cap, 3], draw[k, cap], rgb[k, 3] (entries beyond n[k] are -1 / 0)."""
+        k = len(pixels)
+        out = dict(n=np.zeros(k, dtype=np.uint32), obj=np.full((k, cap), -1, dtype=np.int64), t=np.zeros((k, cap)),
+                   thr=np.zeros((k, cap, 3)), draw=np.zeros((k, cap), dtype=np.uint32), rgb=np.zeros((k, 3)))
+        rgb = (C.c_double * 3)()
+        for i, ((row, col), s) in enumerate(zip(pixels, samples)):
+            obj = np.full(cap, -1, dtype=np.int64); t = np.zeros(cap); thr = np.zeros((cap, 3)); dr = np.zeros(cap, dtype=np.uint32)
+            n = self._L.orc_path_trace(self._h, C.byref(cam.desc), int(row), int(col), int(s), int(seed), int(max_bounces),
+                                       int(traversal), int(cap), obj.ctypes.data, t.ctypes.data, thr.ctypes.data, dr.ctypes.data, rgb)
+            out["n"][i] = n
+            out["obj"][i], out["t"][i], out["thr"][i], out["draw"][i], out["rgb"][i] = obj, t, thr, dr, rgb[:]
         return out
 
     def radiance(self, o, d, max_bounces, key, draw=0, traversal=0):

@@ -45,6 +45,23 @@ SCENES = {
 }
 
 FRAME = dict(w=40, h=24, spp=6, max_bounces=50, seed=0x5EED)
+TRACE = dict(paths=64, cap=64)  # per golden scene: this many seeded samples of the golden frame, traced bounce by bounce
+
+
+def trace_samples(name):
+    """The (row, col) pixels and sample indices of a scene's traced paths: seeded, spread over the golden frame."""
+    r = np.random.default_rng(abs(hash_name(name)) % (2 ** 32))
+    rows = r.integers(0, FRAME["h"], TRACE["paths"])
+    cols = r.integers(0, FRAME["w"], TRACE["paths"])
+    samples = r.integers(0, FRAME["spp"], TRACE["paths"])
+    return np.stack([rows, cols], axis=1).astype(np.uint32), samples.astype(np.uint32)
+
+
+def hash_name(name):
+    h = 1469598103934665603
+    for c in name.encode():
+        h = ((h ^ c) * 1099511628211) % (2 ** 64)
+    return h
 HDRI_SHAPE = (64, 32)
 
 
@@ -104,6 +121,11 @@ def main():
         img, st = osc.render(ocam, FRAME["spp"], FRAME["max_bounces"], seed=FRAME["seed"], traversal=0)
         out[f"frame/{name}/rgb"] = img
         out[f"frame/{name}/rays"] = np.array([st["rays"]], dtype=np.uint64)
+        # per-path traces: what the query of every bounce found, its t, the throughput, the draw index
+        pix, sam = trace_samples(name)
+        tr = osc.path_traces(ocam, pix, sam, FRAME["seed"], FRAME["max_bounces"], TRACE["cap"], traversal=0)
+        for k, v in tr.items():
+            out[f"trace/{name}/{k}"] = v
     cam_args, objs, heur = scenes.diffuse_single_sphere()
     osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, hdri)
     dirs = np.random.default_rng(5).normal(size=(256, 3))

@@ -56,6 +56,20 @@ def test_oracle_intersections_and_frame(name):
     assert st2["rays"] == st["rays"] and np.array_equal(bits(img2), bits(img))
 
 
+@pytest.mark.parametrize("name", list(G.SCENES))
+def test_oracle_path_traces(name):
+    """64 seeded samples of the golden frame, bounce by bounce: object, t, throughput, draw index."""
+    cam_args, objs, heur = G.SCENES[name]()
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI, builder=1)
+    ocam = _oracle.OracleCamera(*scenes.camera_for_resolution(cam_args, G.FRAME["w"], G.FRAME["h"]))
+    pix, sam = G.trace_samples(name)
+    tr = osc.path_traces(ocam, pix, sam, G.FRAME["seed"], G.FRAME["max_bounces"], G.TRACE["cap"], traversal=0)
+    assert int(tr["n"].max()) <= G.TRACE["cap"] and int(tr["n"].min()) >= 1 and int(tr["n"].max()) >= 3
+    for k, v in tr.items():
+        g = GOLD[f"trace/{name}/{k}"]
+        assert np.array_equal(bits(v), bits(g)) if v.dtype == np.float64 else np.array_equal(v, g), k
+
+
 def test_oracle_background_vectors():
     cam_args, objs, heur = scenes.diffuse_single_sphere()
     osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
@@ -85,6 +99,34 @@ def test_gpu_material_vectors(name):
     assert np.array_equal(nd, GOLD[f"mat/{name}/draws"])
     assert np.array_equal(bits(col[hit]), bits(GOLD[f"mat/{name}/color"][hit]))
     assert np.array_equal(bits(dr[hit]), bits(GOLD[f"mat/{name}/dir"][hit]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(G.SCENES))
+def test_gpu_path_traces(name):
+    """The golden traces reproduced on the GPU, lane by lane, by both walks (rayrs_selftest.h rayrs_test_path_trace:
+    the device functions of the path kernels run as one loop per lane): every bounce's object, t bits, throughput
+    bits and draw index, and the sample's radiance."""
+    import rayrs_amd
+    from rayrs_amd import _ffi
+    cam_args, objs, heur = G.SCENES[name]()
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    cam = rayrs_amd.Camera(*scenes.camera_for_resolution(cam_args, G.FRAME["w"], G.FRAME["h"]))
+    pix, sam = G.trace_samples(name)
+    k, cap = len(pix), G.TRACE["cap"]
+    packed = np.ascontiguousarray((pix[:, 0] << 16) | pix[:, 1], dtype=np.uint32)
+    sam = np.ascontiguousarray(sam, dtype=np.uint32)
+    for exact in (1, 0):
+        n = np.zeros(k, dtype=np.uint32); obj = np.zeros((k, cap), dtype=np.int64); t = np.zeros((k, cap))
+        thr = np.zeros((k, cap, 3)); draw = np.zeros((k, cap), dtype=np.uint32); rgb = np.zeros((k, 3))
+        _ffi.check(scene._L.rayrs_test_path_trace(scene._h, C.byref(cam.desc), G.FRAME["seed"], G.FRAME["max_bounces"],
+                                                  packed.ctypes.data, sam.ctypes.data, k, exact, cap, n.ctypes.data,
+                                                  obj.ctypes.data, t.ctypes.data, thr.ctypes.data, draw.ctypes.data,
+                                                  rgb.ctypes.data), "rayrs_test_path_trace")
+        for key, v in (("n", n), ("obj", obj), ("draw", draw)):
+            assert np.array_equal(v, GOLD[f"trace/{name}/{key}"]), (exact, key)
+        for key, v in (("t", t), ("thr", thr), ("rgb", rgb)):
+            assert np.array_equal(bits(v), bits(GOLD[f"trace/{name}/{key}"])), (exact, key)
 
 
 @pytest.mark.gpu

@@ -181,3 +181,42 @@ def test_segments_of_whole_tiles_are_resolved_behind_their_launch():
     osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
     ref, ost = osc.render(_oracle.OracleCamera(*cam_args), 64, 32, seed=9, sample_chunk=4, traversal=0)
     assert same_bits(many, ref) and stn["rays"] == ost["rays"]
+
+
+def test_a_scene_at_the_local_pools_limits_renders_with_fewer_workgroups_per_cu():
+    """Sixteen primitives in four groups of four and sixteen distinct surface rows: the most a local-pool scene may hold
+    (LP_MAX_PRIMS).  Its primitive records and surface rows take so much of a workgroup's LDS that fewer than the three
+    workgroups per CU the kernel is built for fit (the launch takes the count from the occupancy query
+    with the scene's real LDS size -- if it assumed three, the launch would fail or the frame be wrong).  Behavioural: the
+    frame, ray and path counts are the oracle's on both routes."""
+    from rayrs_amd.api import BvhHeuristic, Emission, Fresnel, Material, Object
+    mats = [Material.LambertianDiffuse((0.8, 0.7, 0.6)), Material.Reflect((0.8, 0.8, 0.8)), Material.Glass((1, 1, 1), 1.45),
+            Material.CookTorrance((1, 1, 1), 0.2, Fresnel.SchlickMetallic((0.8, 0.6, 0.4))),
+            Material.Plastic((0.6, 0.7, 0.8), (1, 1, 1), 0.1, 1.45), Material.CookTorranceGlass((1, 1, 1), 0.1, 1.45),
+            Material.Refract((1, 1, 1), 1.3), Material.CookTorranceRefract((1, 1, 1), 0.15, 1.45)]
+    objs = []
+    for i in range(16):
+        m = mats[i % 8]
+        e = Emission.new(2.0 + i, (1.0, 0.9, 0.8)) if i in (3, 12) else Emission.Dark()
+        # sixteen distinct rows: the same material with another emission, or another colour, is another row
+        if i >= 8 and not e.emissive:
+            e = Emission.new(0.0, (0.1 * (i - 7), 0.5, 0.5))
+        objs.append(Object.sphere(0.45, (1.1 * (i - 7.5), 1.0, 0.3 * ((i * 7) % 3)), m, e))
+    heur = BvhHeuristic.Midpoint
+    cam_args = ((0.0, 6.0, 16.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 65.0, 96 / 254.0, 48 / 254.0, 100)
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    info = scene.info()
+    assert info["local_pool"] == 1 and info["n_prims"] == 16 and info["n_surfaces"] == 16 and info["gate_n_wide"] == 1
+    cam = rayrs_amd.Camera(*cam_args)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+    ocam = _oracle.OracleCamera(*cam_args)
+    ref, ost = osc.render(ocam, 24, 50, seed=11, sample_chunk=4, traversal=0)
+    loc, lst = rayrs_amd.render(scene, cam, 24, 50, seed=11, sample_chunk=4, out_f64=True, count_work=True)
+    assert lst["local_pool"] == 1 and lst["rays"] == ost["rays"] and lst["paths"] == ost["paths"]
+    assert same_bits(loc, ref)
+    _, wst = osc.use_product_walk(scene).render(ocam, 24, 50, seed=11, sample_chunk=4, traversal=2)
+    for k in ("interior_visits", "sphere_tests"):
+        assert lst[k] == wst[k], k
+    scene.set_tuning(local_pool=1)
+    stream, sst = rayrs_amd.render(scene, cam, 24, 50, seed=11, sample_chunk=4, out_f64=True)
+    assert sst["local_pool"] == 0 and sst["rays"] == ost["rays"] and same_bits(stream, ref)

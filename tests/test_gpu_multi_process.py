@@ -25,6 +25,14 @@ def run(cmd):
     return json.loads(lines[0])
 
 
+def _with(args, **repl):
+    out = list(args)
+    for k, v in repl.items():
+        i = out.index("--" + k)
+        out[i + 1] = str(v)
+    return out
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_with_n_ranks_assembles_the_single_rank_frame(world):
     one = run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
@@ -38,6 +46,24 @@ def test_bench_with_n_ranks_assembles_the_single_rank_frame(world):
     assert many["rays_per_step"] == one["rays_per_step"]
     assert many["config"]["sample_chunk"] == one["config"]["sample_chunk"]
     assert many["scaling"] == "strong" and many["value"] > 0
+
+
+def test_five_ranks_a_ragged_frame_and_three_frames_in_flight():
+    """As many ranks as this pool lets touch one card beside the test runner itself (six processes in all: the eight ranks
+    of a full node are refused by its process guard, so eight are rehearsed on the CPU -- tests/test_multi_rank.py -- and
+    as eight handles of rayrs_render_multi inside one process -- tests/test_gpu_render.py), a frame whose sides are not
+    multiples of the 8 x 8 tile, three frames in flight per rank, four timed steps: the assembled frame is the
+    single-process frame, and the line carries the un-pipelined figure beside the pipelined one."""
+    ragged = _with(COMMON, res=250, steps=4, warmup=1)
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + ragged)
+    port = 29900 + (os.getpid() % 1000)
+    six = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=5",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "5",
+               "--backend", "gloo", "--device", "0"] + ragged)
+    assert six["n_gpus"] == 5 and six["config"]["frames_in_flight"] == 3 and six["config"]["resolution"] == [250, 250]
+    assert six["framebuffer_sha256"] == one["framebuffer_sha256"] and six["rays_per_step"] == one["rays_per_step"]
+    assert six["config"]["unpipelined_ms_per_frame"] > 0 and one["config"]["unpipelined_ms_per_frame"] is None
+    assert six["config"]["untimed_frames_before_the_timed_region"] == 3   # one per flight (--warmup 1)
 
 
 def test_bench_with_one_rank_runs_the_rccl_reduce():
@@ -56,14 +82,6 @@ def test_bench_with_one_rank_runs_the_rccl_reduce():
     assert coll["librccl_mapped"] and "librccl" in coll["librccl_mapped"]
     assert forced["framebuffer_sha256"] == one["framebuffer_sha256"]
     assert forced["rays_per_step"] == one["rays_per_step"] and forced["n_gpus"] == 1
-
-
-def _with(args, **repl):
-    out = list(args)
-    for k, v in repl.items():
-        i = out.index("--" + k)
-        out[i + 1] = str(v)
-    return out
 
 
 def test_frames_in_flight_render_the_same_frames_in_frame_order():

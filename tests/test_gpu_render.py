@@ -224,14 +224,15 @@ def test_render_multi_runs_its_rccl_reduce_on_one_device(route):
     """What a multi-GPU node executes after the ranks have rendered -- dlopen of librccl, ncclCommInitAll, the grouped
     in-place ncclReduce to rank 0 -- is skipped when every handle sits on one device (there is nothing to reduce).
     rayrs_lab.h force_rccl runs it anyway, with a communicator of that one device: the frame must not change by a bit,
-    with one handle and with three (summed on the device first), on either route, and librccl must really be mapped."""
+    with one handle, with three and with the eight of a full node (summed on the device first), on either route, and
+    librccl must really be mapped."""
     fn = (lambda: scenes.mesh_scene(3, area_light=True)) if route == "streaming" else scenes.cook_torrance_spheres_metallic
     scene, cam, osc, ocam = both(fn, 77, 45, 6)
     assert scene.info()["local_pool"] == (1 if route == "local_pool" else 0)
     full, st = rayrs_amd.render(scene, cam, 6, sample_chunk=4)
     scene.lab_set(force_rccl=1)
-    clones = [scene] + [scene.clone_to_device(0) for _ in range(2)]   # clones take the scene's settings along
-    for handles in (clones[:1], clones):
+    clones = [scene] + [scene.clone_to_device(0) for _ in range(7)]   # clones take the scene's settings along
+    for handles in (clones[:1], clones[:3], clones):                  # one, three, and a full node's eight ranks
         img, mst = rayrs_amd.render_multi(handles, cam, 6, sample_chunk=4)
         assert np.array_equal(img.view(np.uint32), full.view(np.uint32)), len(handles)
         assert mst["rays"] == st["rays"] and mst["paths"] == st["paths"] == 77 * 45 * 6
@@ -500,3 +501,27 @@ def test_light_side_array_eager_and_on_demand():
     ref, ost = osc.render(ocam, 16, 50, sample_chunk=4, traversal=0)
     assert st["rays"] == ost["rays"]
     assert_same_frame(img, ref)
+
+
+def test_two_different_frames_back_to_back_on_one_scene():
+    """The path pool is kept between renders and wf_init_kernel rewrites the state bytes only: an IDLE slot's line still
+    holds the previous frame's item, cursor and light bits.  Nothing may read them: a larger frame, then a
+    smaller one with another spp, chunk and seed (fewer slots than before: most of the old lines stay stale), then the
+    first again, each bit-identical to the oracle's frame and to its own first render."""
+    cam_args, objs, heur = scenes.mesh_scene(3, area_light=True)   # an emitter: light bits get set
+    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=0)
+    osc = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI)
+    frames = []
+    for (w, h, spp, chunk, seed) in ((96, 64, 8, 4, 1), (40, 24, 5, 0, 2), (96, 64, 8, 4, 1), (64, 40, 12, 4, 3)):
+        ca = scenes.camera_for_resolution(cam_args, w, h)
+        img, st = rayrs_amd.render(scene, rayrs_amd.Camera(*ca), spp, 50, seed=seed, sample_chunk=chunk, out_f64=True)
+        ref, ost = osc.render(_oracle.OracleCamera(*ca), spp, 50, seed=seed, sample_chunk=chunk)
+        assert st["rays"] == ost["rays"] and st["paths"] == ost["paths"]
+        assert_same_frame(img, ref)
+        frames.append(img)
+    assert_same_frame(frames[0], frames[2])
+    # the same with a pool far smaller than the items (slots are reused within a frame too)
+    scene.set_tuning(pool_slots=2048)
+    ca = scenes.camera_for_resolution(cam_args, 96, 64)
+    img, _ = rayrs_amd.render(scene, rayrs_amd.Camera(*ca), 8, 50, seed=1, sample_chunk=4, out_f64=True)
+    assert_same_frame(img, frames[0])

@@ -63,10 +63,3 @@ def test_local_pool_kernel_fits_three_workgroups_per_cu(tmp_path):
             assert scratch == 0, (name, scratch)
         elif inst.startswith("1ELb0E"):  # COMPACT = true, COUNT = false
             assert scratch <= 16, (name, scratch)
-
-
-def test_local_pool_lds_budget_is_asked_not_assumed():
-    """Three workgroups of the local-pool kernel fit a CU's 160 KiB only up to about a dozen primitives and surface
-    rows: the launch takes its workgroup count from the occupancy query with the scene's real LDS size."""
-    src = open(os.path.join(CSRC, "abi.cpp")).read()
-    assert "lp_occupancy(" in src and "local_blocks_per_cu" in src
