@@ -48,19 +48,20 @@ def test_bench_with_n_ranks_assembles_the_single_rank_frame(world):
     assert many["scaling"] == "strong" and many["value"] > 0
 
 
-def test_five_ranks_a_ragged_frame_and_three_frames_in_flight():
-    """As many ranks as this pool lets touch one card beside the test runner itself (six processes in all: the eight ranks
-    of a full node are refused by its process guard, so eight are rehearsed on the CPU -- tests/test_multi_rank.py -- and
-    as eight handles of rayrs_render_multi inside one process -- tests/test_gpu_render.py), a frame whose sides are not
+def test_four_ranks_a_ragged_frame_and_three_frames_in_flight():
+    """As many ranks as this pool lets touch one card beside the test runner and the launcher (six processes in all; five
+    ranks were killed by its process guard in round 5, so the eight of a full node are rehearsed on the CPU --
+    tests/test_multi_rank.py -- and as eight handles of rayrs_render_multi inside one process --
+    tests/test_gpu_render.py), a frame whose sides are not
     multiples of the 8 x 8 tile, three frames in flight per rank, four timed steps: the assembled frame is the
     single-process frame, and the line carries the un-pipelined figure beside the pipelined one."""
     ragged = _with(COMMON, res=250, steps=4, warmup=1)
     one = run([sys.executable, "bench.py", "--gpus", "1"] + ragged)
     port = 29900 + (os.getpid() % 1000)
-    six = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=5",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "5",
+    six = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "4",
                "--backend", "gloo", "--device", "0"] + ragged)
-    assert six["n_gpus"] == 5 and six["config"]["frames_in_flight"] == 3 and six["config"]["resolution"] == [250, 250]
+    assert six["n_gpus"] == 4 and six["config"]["frames_in_flight"] == 3 and six["config"]["resolution"] == [250, 250]
     assert six["framebuffer_sha256"] == one["framebuffer_sha256"] and six["rays_per_step"] == one["rays_per_step"]
     assert six["config"]["unpipelined_ms_per_frame"] > 0 and one["config"]["unpipelined_ms_per_frame"] is None
     assert six["config"]["untimed_frames_before_the_timed_region"] == 3   # one per flight (--warmup 1)
