@@ -53,6 +53,8 @@ F64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # stack arithmetic, 32-bit selects -- is overhead against this.
 OPS_RECORD_COMPACT = 111   # 4 slots x (6 cvt + 6 sub + 6 mul + 6 min/max) + 4 + 4 compares + 1 mul (cull) + 6 (rank)
 OPS_RECORD_F64 = 87        # the same without the 24 f32 -> f64 conversions
+OPS_RECORD_NO_CULL = 11    # of either: the cull margin's multiply, 4 cull compares, 6 rank compares -- the fast walk only; the
+                           # default walk (nothing culled, slots entered in slot order) is not charged with them
 OPS_TRIANGLE_COMPACT = 98  # 9 cvt + 9 sub + 2 cross (18) + 4 dot (20) + 3 div x 11 + 1 add + 8 compares
 OPS_TRIANGLE_F64 = 89
 OPS_SPHERE = 66            # geometry.rs:106-132: 3 sub, 3 dot, sqrt (10), 2 div x 11, 12 others
@@ -80,6 +82,8 @@ MATERIAL_UNIT = ["lambertian", "reflect", "refract", "glass", "cook_torrance", "
 def traversal_ops(stats, info):
     """Useful f64-rate lane operations of the frame's BVH walks (records entered, primitives tested)."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
+    if stats.get("exact_walk"):  # (the local-pool kernel's loop over a record's gates neither culls nor ranks either)
+        rec -= OPS_RECORD_NO_CULL
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
     return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
             + stats["plane_tests"] * OPS_PLANE)
