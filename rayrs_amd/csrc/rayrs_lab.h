@@ -35,6 +35,8 @@ typedef struct {
     uint32_t gate_tree;     /* 1 = the default walk (with closest-hit culling) over the gate tree instead of the tree
                                of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
                                profiles/r04_tight_leaves.txt */
+    uint32_t walk_list_refs; /* default walk on compact records: leaf groups a ray's list holds before the ray is left to
+                               the one-kernel walk, 3 .. the built-in limit (34); small values exercise that path */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

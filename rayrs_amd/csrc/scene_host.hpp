@@ -51,6 +51,10 @@ struct WalkTree {
     uint32_t root_ref = 0;
     uint32_t depth = 0;         // stack entries the traversal can need
     std::vector<uint8_t> node_bytes;  // the records as the kernels read them (Node4F32 / Node4F64)
+    // compact gate tree only (device_path.h GATE32): per primitive record p 8 floats, the gating box of the leaf group
+    // that starts at p (zeros elsewhere), and a bound on every |box bound| in the tree (at least 2^-60)
+    std::vector<float> leaf_box;
+    float bound = 0.0f;
     uint32_t n() const { return (uint32_t)(ref.size() / 4); }
 };
 

@@ -41,4 +41,5 @@ for s in settings + settings[::-1]:
         ref = img.copy()
     same = bool((img.view("u4") == ref.view("u4")).all())
     print(f"[{s or 'defaults':40s}] trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f} ms  rounds {st['kernel_launches']:4d}  "
-          f"Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}  hit {st['hit_ms']:7.1f} miss {st['miss_ms']:7.1f}  same_bits={same}", flush=True)
+          f"Mray/s {st['rays'] / st['trace_ms'] / 1e3:8.1f}  hit {st['hit_ms']:7.1f} miss {st['miss_ms']:7.1f}  same_bits={same}  "
+          f"sha {__import__('hashlib').sha256(img.tobytes()).hexdigest()[:12]}", flush=True)
