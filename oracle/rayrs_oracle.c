@@ -863,8 +863,6 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
-    int gate32;         /* orc_set_gate32: the walk tests the records' boxes in f32 (device_path.h GATE32) */
-    float gate_bound;   /* ... with this bound on every |box bound| */
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -1313,26 +1311,6 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
-    s->gate32 = 0;
-    return 0;
-}
-
-/* The default walk of the product on compact records (device_path.h GATE32): the boxes of a record are tested in f32
- * with every rounding pushed outwards, a leaf group's own gating box exactly (f64) before its primitives, the root
- * Node's box not at all.  The bound of the f32 test's error term is computed as scene_host.cpp gate32_tables
- * computes it: the largest |bound| among the root box and the used slots, at least 2^-60, rounded up to f32. */
-int orc_set_gate32(orc_scene* s, int on) {
-    if (!s || !s->built || !s->have_wide) return -1;
-    double bound = 0x1p-60;
-    for (int k = 0; k < 6; k++) bound = fmax(bound, fabs(s->finfo.root_box[k]));
-    for (size_t r = 0; r < (size_t)s->finfo.n_wide * 4; r++) {
-        if ((s->wide_ref[r] >> 30) == REF_KIND_NONE) continue;
-        for (int k = 0; k < 6; k++) bound = fmax(bound, fabs(s->wide_box[r * 6 + k]));
-    }
-    float bf = (float)bound;
-    if ((double)bf < bound) bf = nextafterf(bf, INFINITY);
-    s->gate_bound = bf;
-    s->gate32 = on ? 1 : 0;
     return 0;
 }
 
@@ -1573,117 +1551,7 @@ void orc_set_visit_histogram(uint64_t* hist) { g_visit_hist = hist; }
  * slot), the rest pushed farthest first.  Every leaf slot is a group of the reference's tree
  * behind its gating box, so the primitives tested are a subset of those the reference reaches
  * that contains the closest hit. */
-/* ---- device_path.h GATE32, operation for operation (f32, round to nearest, fmaf with one rounding) */
-typedef struct {
-    float v[3], cn[3], cf[3];
-} slab32_t;
-
-static void slab32_axis(double o, double v, float bound, float* v32, float* cn, float* cf) {
-    const int ok = fabs(v) < 0x1p40 && fabs(o) < 0x1p80;
-    *v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * *v32;
-    const float e = ok ? (fabsf(o32) + bound) * (fabsf(*v32) * 0x1p-20f) : INFINITY;
-    *cn = -oi - e;
-    *cf = e - oi;
-}
-
-static int slab32_may_enter(const double* bx, const slab32_t* s, float t0_lo, float t1_hi) {
-    float lo = t0_lo, hi = t1_hi;
-    float l[3], u[3];
-    for (int a = 0; a < 3; a++) {
-        const int neg = s->v[a] < 0.0f;
-        const float n = (float)bx[2 * a + (neg ? 1 : 0)], f = (float)bx[2 * a + (neg ? 0 : 1)];
-        l[a] = fmaf(n, s->v[a], s->cn[a]);
-        u[a] = fmaf(f, s->v[a], s->cf[a]);
-    }
-    lo = fmaxf(fmaxf(fmaxf(l[0], l[1]), l[2]), lo);
-    hi = fminf(fminf(fminf(u[0], u[1]), u[2]), hi);
-    return !(hi < lo);
-}
-
-static void f32_around(double x, float* below, float* above) {
-    const float f = (float)x;
-    *below = (double)f > x ? nextafterf(f, -INFINITY) : f;
-    *above = (double)f < x ? nextafterf(f, INFINITY) : f;
-}
-
-static isect_t isect_wide_gate32(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
-    isect_t best = {0, 0.0, -1};
-    uint32_t best_prim = 0xffffffffu;
-    v3 inv = V(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-    slab32_t sl;
-    slab32_axis(ray.o.x, inv.x, s->gate_bound, &sl.v[0], &sl.cn[0], &sl.cf[0]);
-    slab32_axis(ray.o.y, inv.y, s->gate_bound, &sl.v[1], &sl.cn[1], &sl.cf[1]);
-    slab32_axis(ray.o.z, inv.z, s->gate_bound, &sl.v[2], &sl.cn[2], &sl.cf[2]);
-    {   /* rays that miss the root Node's box never reach the walk: the kernels that make them answer them */
-        double entry;
-        if (!aabb_intersect_entry(s->finfo.root_box, ray, inv, tmin, tmax, &entry)) return best;
-    }
-    float t0_lo, t0_hi, t1_lo, t1_hi;
-    f32_around(tmin, &t0_lo, &t0_hi);
-    f32_around(tmax, &t1_lo, &t1_hi);
-    const size_t cap = (size_t)s->finfo.wide_depth + 8u;
-    uint32_t* stack = (uint32_t*)malloc(cap * 2 * sizeof(uint32_t));
-    uint32_t* bstack = stack + cap; /* the slot a stacked reference came from: its box is the group's gating box */
-    int sp = 0;
-    uint32_t cur = s->finfo.wide_root_ref, cur_box = 0xffffffffu; /* (a one-Node scene: the root box) */
-    for (;;) {
-        if ((cur >> 30) == REF_KIND_INTERIOR) {
-            uint32_t rec = cur & 0x3fffffffu;
-            if (cnt) cnt->interior_visits++;
-            const uint32_t* refs = s->wide_ref + (size_t)rec * 4;
-            int first = 1;
-            uint32_t pend[4], pbox[4];
-            int np = 0;
-            for (int c = 0; c < 4; c++) {
-                if ((refs[c] >> 30) == REF_KIND_NONE) continue;
-                if (!slab32_may_enter(s->wide_box + ((size_t)rec * 4 + c) * 6, &sl, t0_lo, t1_hi)) continue;
-                pend[np] = refs[c], pbox[np] = rec * 4 + (uint32_t)c, np++;
-            }
-            (void)first;
-            if (np > 0) { /* slot order: the first goes next, the others are stacked so that they pop in slot order */
-                for (int a = np - 1; a >= 1; a--) stack[sp] = pend[a], bstack[sp] = pbox[a], sp++;
-                cur = pend[0], cur_box = pbox[0];
-                continue;
-            }
-        } else {
-            uint32_t first = (cur & 0x3fffffffu) >> 2;
-            uint32_t count = (cur & 3u) + 1u;
-            const double* gate = cur_box == 0xffffffffu ? s->finfo.root_box : s->wide_box + (size_t)cur_box * 6;
-            double entry;
-            if (aabb_intersect_entry(gate, ray, inv, tmin, tmax, &entry)) {
-                for (uint32_t k = 0; k < count; k++) {
-                    uint32_t p = first + k;
-                    int obj = (int)s->prim_object[p];
-                    const shape_t* g = &s->objs[obj].geom;
-                    if (cnt) {
-                        if (g->kind == ORC_SHAPE_TRIANGLE) cnt->tri_tests++;
-                        else if (g->kind == ORC_SHAPE_SPHERE) cnt->sphere_tests++;
-                        else cnt->plane_tests++;
-                    }
-                    double t;
-                    if (shape_intersect(g, ray, &t) && t > tmin && t < tmax) {
-                        if (!best.hit || t < best.t || (t == best.t && p < best_prim)) {
-                            best.hit = 1;
-                            best.t = t;
-                            best.obj = obj;
-                            best_prim = p;
-                        }
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp], cur_box = bstack[sp];
-    }
-    free(stack);
-    return best;
-}
-
 static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
-    if (s->have_wide && s->gate32) return isect_wide_gate32(s, ray, tmin, tmax, cnt);
     if (!s->have_wide) {
         fprintf(stderr, "oracle: traversal 2 needs the product's walk tree (orc_set_wide)\n");
         abort();

@@ -91,7 +91,7 @@ class LabTuning(C.Structure):
     _fields_ = [("refill_min", C.c_uint32), ("leaf_min", C.c_uint32), ("static_pct", C.c_uint32),
                 ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32),
                 ("eager_light", C.c_uint32), ("local_reserve", C.c_uint32), ("local_segment_items", C.c_uint32),
-                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("walk_list_refs", C.c_uint32)]
+                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32)]
 
 
 # the order rayrs_abi_layout() reports the public structs in

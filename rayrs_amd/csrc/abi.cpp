@@ -26,8 +26,6 @@ namespace {
 thread_local std::string g_last_error;
 constexpr uint32_t TRAV_STACK_LDS = 12;
 constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
-constexpr uint32_t WALK_STACK_LDS = 8;
-constexpr uint32_t WALK_HOT_BYTES = 7u * 1024u;
 }  // namespace
 
 namespace rayrs {
@@ -199,7 +197,6 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     for (auto& w : s->trav)
         if (w.d_nodes) (void)hipFree(w.d_nodes);
     if (s->d_prims) (void)hipFree(s->d_prims);
-    if (s->d_leaf_box) (void)hipFree(s->d_leaf_box);
     if (s->d_surfaces) (void)hipFree(s->d_surfaces);
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -209,7 +206,6 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
         if (pl.block) (void)hipFree(pl.block);
         if (pl.d_wave_items) (void)hipFree(pl.d_wave_items);
         if (pl.d_stack_spill) (void)hipFree(pl.d_stack_spill);
-        if (pl.d_walk_list) (void)hipFree(pl.d_walk_list);
         if (pl.wf.ctl) (void)hipFree(pl.wf.ctl);
         if (pl.h_live) (void)hipHostFree(pl.h_live);
         for (auto& e : pl.ev_batch)
@@ -243,21 +239,16 @@ static int scene_configure_traversal(rayrs_scene* s) {
         const WalkTree& t = s->tree(x != 0);
         rayrs_scene::Walk& w = s->trav[x];
         const uint32_t depth = t.depth ? t.depth : 1;
-        // (the default walk on compact records is wf_walk_kernel, which fits eight workgroups on a CU by its registers:
-        // 20 KiB of LDS each)
-        const bool walk = x == 1 && f.compact;
-        uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : (walk ? WALK_STACK_LDS : TRAV_STACK_LDS);
+        uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
         w.stack_lds = want < depth ? want : depth;
         const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
-        uint32_t hot = (walk ? WALK_HOT_BYTES : TRAV_HOT_BYTES) / rec_bytes;
+        uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
         if (s->lab.hot_records == 0xffffffffu) hot = 0;
         else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
         w.hot_records = hot < t.n() ? hot : t.n();
-        HIP_TRY(wf_trav_occupancy(f.compact, x == 1, w.stack_lds, w.hot_records, &w.blocks_per_cu));
+        HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.hot_records, &w.blocks_per_cu));
         if (w.blocks_per_cu < 1) w.blocks_per_cu = 1;
     }
-    HIP_TRY(wf_leaf_occupancy(&s->leaf_blocks_per_cu));
-    if (s->leaf_blocks_per_cu < 1) s->leaf_blocks_per_cu = 1;
     return RAYRS_OK;
 }
 
@@ -311,10 +302,6 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     }
     HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
     HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
-    if (!f.gate.leaf_box.empty()) {
-        HIP_TRY(hipMalloc((void**)&s->d_leaf_box, f.gate.leaf_box.size() * sizeof(float)));
-        HIP_TRY(hipMemcpy(s->d_leaf_box, f.gate.leaf_box.data(), f.gate.leaf_box.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
     HIP_TRY(hipMemcpy(s->d_surfaces, s->surfaces.data(), s->surfaces.size() * sizeof(SurfaceDev),
                       hipMemcpyHostToDevice));
@@ -322,7 +309,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.gate.leaf_box.size() * sizeof(float) + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -508,8 +495,7 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
-    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u ||
-        (lab->walk_list_refs != 0u && (lab->walk_list_refs < 3u || lab->walk_list_refs > wf_walk_list_refs())))
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
@@ -616,15 +602,6 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
     sc.exact = exact ? 1u : 0u;
-    // the default walk's f32 box test (device_path.h GATE32): t range rounded outwards (_lo, _hi) and inwards
-    sc.leaf_box = s->d_leaf_box;
-    sc.gate_bound = s->flat.gate.bound;
-    const float inf = std::numeric_limits<float>::infinity();
-    const float f0 = (float)sc.t0, f1 = (float)sc.t1;
-    sc.t0_lo = (double)f0 > sc.t0 ? std::nextafterf(f0, -inf) : f0;
-    sc.t0_hi = (double)f0 < sc.t0 ? std::nextafterf(f0, inf) : f0;
-    sc.t1_lo = (double)f1 > sc.t1 ? std::nextafterf(f1, -inf) : f1;
-    sc.t1_hi = (double)f1 < sc.t1 ? std::nextafterf(f1, inf) : f1;
     return sc;
 }
 
@@ -744,7 +721,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool exact = params->fast_traversal == 0u || camera_is_far(scene, camera);
     scene->last_exact = exact;
-    rp.walk_list_refs = lab.walk_list_refs ? lab.walk_list_refs : wf_walk_list_refs();
     rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
     const SceneDev sc = make_scene_dev(scene, exact);
     const CameraDev cam = make_camera_dev(camera);
@@ -837,19 +813,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
                 pl.stack_spill_words = words;
             }
             wf.stack_spill = pl.d_stack_spill;
-        }
-        wf.walk_list = nullptr;
-        wf.leaf_blocks = (uint32_t)scene->cu_count * (uint32_t)scene->leaf_blocks_per_cu;
-        if (exact && compact) {  // the default walk on compact records: wf_walk_kernel's lists
-            const size_t words = (size_t)np * wf_walk_list_words();
-            if (words > pl.walk_list_words) {
-                if (pl.d_walk_list) HIP_TRY(hipFree(pl.d_walk_list));
-                pl.d_walk_list = nullptr;
-                pl.walk_list_words = 0;
-                HIP_TRY(hipMalloc((void**)&pl.d_walk_list, words * sizeof(uint32_t)));
-                pl.walk_list_words = words;
-            }
-            wf.walk_list = pl.d_walk_list;
         }
     }
     rp.next_item = scene->d_next_item;

@@ -285,8 +285,9 @@ constexpr uint32_t TRAV_DONE = 0xffffffffu;
 // AND another accepted hit falls in between.  Moeller-Trumbore's t has a relative error of about eps * (distance / size)
 // / (grazing angle) -- unbounded as the ray approaches the triangle's plane -- and which triangles lie behind a box is
 // not known without reading them, so NO margin computed from the ray and the box alone is sound: culling is either off
-// (EXACT: the margin is +infinity, rayrs_render_params.exact_traversal: the reference's visit set by construction;
-// headline frame: 6.33 instead of 4.47 records per query, traversal +59 %, profiles/r04_exact_traversal.txt) or a bet.  The default margin is the bet measured with scripts/fuzz_traversal.py
+// (EXACT, the default walk: the margin is +infinity, the reference's visit set by construction) or a bet
+// (rayrs_render_params.fast_traversal; headline frame: 4.72 instead of 6.32 records per query on its own tree,
+// profiles/r05_walks.txt).  The fast walk's margin is the bet measured with scripts/fuzz_traversal.py
 // (profiles/r03_fuzz_traversal.txt: 10^8 rays on sliver meshes and nearly flat sheets, origins up to 10^6 scene sizes
 // away): rays at 10^-7 rad and more off a triangle's plane put t at most 2^-11.1 in front of a box; between 10^-9 and
 // 10^-7 rad one ray in 10^7 loses its hit, closer to the plane one in 10^7 again (tests/test_walk_tree.py pins one: 2 % in
@@ -311,18 +312,8 @@ struct LaneStack {
     }
 };
 
-// Per-ray constants of the conservative f32 box test of the default walk on compact records (GATE32 below):
-// per axis 1/d rounded to f32 (0 on an axis the test ignores) and the two addends c_near = -(o/d) - e,
-// c_far = e - (o/d), where e bounds everything f32 rounding can do to (bound - o) / d.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct Slab32 {
-    float vx, vy, vz;
-    f32x2 cx, cy, cz;  // (c_near, c_far): the addend of one packed fma over (near, far)
-};
-
 struct Trav {
-    V3 inv;      // (dead in GATE32 walks after trav_init: their leaf step divides again in the rare case it needs 1/d)
-    Slab32 s32;  // (dead in all others)
+    V3 inv;
     double best_t;
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
@@ -340,63 +331,12 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// ---- GATE32: the box test of the default walk (EXACT) on compact records.
-//
-// By construction the default walk has to test the primitives of exactly those leaf groups whose gating box the
-// reference's own slab test (f64, geometry.rs:458-513) lets the ray into -- and that is ALL it has to get bit-right:
-// which records it reads on the way is its own business, as long as it never skips a record with such a group below
-// it.  So the boxes of a record are tested in f32 with every rounding pushed outwards ("may enter" / "surely not"),
-// at half the instructions of the exact test and in packed arithmetic, and the exact f64 test is made once per leaf
-// group that passed, in the leaf step, on the group's own gating box (SceneDev::leaf_box) -- and even there only for
-// the lanes whose f32 interval does not already prove the answer.
-//
-// The f32 test, per axis (o, v = fl64(1/d) the ray's f64 values; n, f the near and far bound of the box, f32-exact;
-// all f32 operations rounded to nearest, fma with one rounding):
-//      ok   = |v| < 2^40 and |o| < 2^80                      (else the axis is ignored: v32 = 0, e = +inf)
-//      v32  = fl(v), o32 = fl(o), oi = fl(o32 * v32)
-//      e    = fl(fl(|o32| + B) * fl(|v32| * 2^-20))            B = SceneDev::gate_bound >= every |bound|, 2^-60 <= B < 2^80
-//      L    = fma(n, v32, fl(-oi - e))       U = fma(f, v32, fl(e - oi))
-//      miss = min(Ux, Uy, Uz, t1_hi) < max(Lx, Ly, Lz, t0_lo)                (NaN operands dropped: maxnum / minnum)
-// Claim: miss implies that the reference's test fails on this box and on every box inside it.  The reference computes
-// T = fl64(fl64(n - o) * v), within 2^-51 |v| (|n| + |o|) of R = (n - o) v.  On an ok axis nothing overflows (every
-// product is below 2^121) and L = S (1 + 2^-24 g) with S = n v32 + fl(-oi - e), |oi - o v| <= 0.76 * 2^-22 |o v|,
-// |n v32 - n v| <= 2^-24 |n v|, so S - R <= -e (1 - 2^-24) + 2^-22 |v| (0.25 |n| + 1.01 |o|) and
-// L - T <= -0.9999 e + 1.27 * 2^-22 |v| (B + |o|) < 0, because e >= 0.9999 * 2^-20 |v| (B + |o|): L <= T_near, and
-// U >= T_far in the same way (underflow moves any of this by less than 2^-107, e is at least 2^-80 |v|).  On an
-// ignored axis L is -inf or NaN and U is +inf or NaN: no constraint.  Hence max(L.., t0_lo) <= tmin and
-// min(U.., t1_hi) >= tmax of the reference's test (which drops NaN the same way, and has none on an ok axis), and
-// miss means tmax < tmin there; a box inside this one has T_near no smaller and T_far no larger (every operation
-// above is monotone), so it fails as well.  The same L and U with the addends swapped bound T from the other side:
-// sure = min(fma(f, v32, c_near).., t1_lo) > max(fma(n, v32, c_far).., t0_hi) implies the reference's test passes
-// (an ignored axis makes it +inf > ... false, never sure).  The oracle restates both in C (fmaf) and the counters
-// of the two must agree ray for ray.
-RR_DEV void slab32_axis(double o, double v, float bound, float& v32, f32x2& c) {
-    const bool ok = __builtin_fabs(v) < 0x1p40 && __builtin_fabs(o) < 0x1p80;  // (not-a-number: not ok)
-    v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * v32;
-    const float e = ok ? (__builtin_fabsf(o32) + bound) * (__builtin_fabsf(v32) * 0x1p-20f) : __builtin_inff();
-    c.x = -oi - e;
-    c.y = e - oi;
-}
-
-template <bool GATE32 = false>
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
-    if (GATE32) {
-        // (no test of the root Node's box: every gating box lies inside it, so a ray that the reference turns away
-        // there (bvh.rs:394) fails every gating box's test as well, and the walk finds that out by itself -- the
-        // kernels that make rays answer such rays themselves, next_sample(), so hardly any arrives here)
-        tv.cur = sc.root_ref;
-        slab32_axis(o.x, tv.inv.x, sc.gate_bound, tv.s32.vx, tv.s32.cx);
-        slab32_axis(o.y, tv.inv.y, sc.gate_bound, tv.s32.vy, tv.s32.cy);
-        slab32_axis(o.z, tv.inv.z, sc.gate_bound, tv.s32.vz, tv.s32.cz);
-    } else {
-        tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
-    }
+    tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
 RR_DEV void trav_pop(const LaneStack& stack, Trav& tv) {
@@ -549,206 +489,6 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// ---- GATE32 steps (see trav_init)
-#ifndef RAYRS_GATE32_PREFETCH
-#define RAYRS_GATE32_PREFETCH 1
-#endif
-// (near, far) of one axis -> (L, U): one packed fma
-RR_DEV f32x2 slab32_lu(uint32_t lo, uint32_t hi, bool neg, float v, f32x2 c) {
-    f32x2 b, vv;
-    b.x = __uint_as_float(neg ? hi : lo), b.y = __uint_as_float(neg ? lo : hi);
-    vv.x = v, vv.y = v;
-    return __builtin_elementwise_fma(b, vv, c);
-}
-
-RR_DEV bool slab32_may_enter(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, bool nx,
-                             bool ny, bool nz, const Slab32& s, float t0_lo, float t1_hi) {
-    const f32x2 x = slab32_lu(x0, x1, nx, s.vx, s.cx);
-    const f32x2 y = slab32_lu(y0, y1, ny, s.vy, s.cy);
-    const f32x2 z = slab32_lu(z0, z1, nz, s.vz, s.cz);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), t0_lo);
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), t1_hi);
-    return !(hi < lo);
-}
-
-// the same products with the addends swapped: bounds of T_near from above and of T_far from below
-RR_DEV bool slab32_surely_enters(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, bool nx,
-                                 bool ny, bool nz, const Slab32& s, float t0_hi, float t1_lo) {
-    const f32x2 x = slab32_lu(x0, x1, nx, s.vx, s.cx.yx);
-    const f32x2 y = slab32_lu(y0, y1, ny, s.vy, s.cy.yx);
-    const f32x2 z = slab32_lu(z0, z1, nz, s.vz, s.cz.yx);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), t0_hi);
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), t1_lo);
-    return hi > lo;
-}
-
-// One compact record of the gate tree: every slot the ray may enter is visited, in slot order (nothing is culled, so
-// the order buys nothing: the closest hit is the smallest accepted t, ties by primitive index, in any order).
-template <bool COUNT>
-RR_DEV void trav_interior_step_gate32(const SceneDev& sc, const LaneStack& stack, const HotNodes& hot, Trav& tv,
-                                      WorkCount& wc) {
-    const Slab32& s = tv.s32;
-    const bool nx = s.vx < 0.0f, ny = s.vy < 0.0f, nz = s.vz < 0.0f;
-    const uint32_t rec = tv.cur & 0x3fffffffu;
-    if (COUNT) wc.interior++;
-    uint4 a, b, c, d, f, g, r;
-    if (rec < hot.count) {
-        const uint4* src = hot.lds + rec * HotNodes::stride<true>();
-        a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
-    } else {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
-        a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
-    }
-    uint32_t r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
-    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));  // (loaded with the boxes: trav_interior_step)
-    const float t0 = sc.t0_lo, t1 = sc.t1_hi;
-    const bool h0 = slab32_may_enter(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, s, t0, t1);
-    const bool h1 = slab32_may_enter(b.z, b.w, c.x, c.y, c.z, c.w, nx, ny, nz, s, t0, t1);
-    const bool h2 = slab32_may_enter(d.x, d.y, d.z, d.w, f.x, f.y, nx, ny, nz, s, t0, t1);
-    const bool h3 = slab32_may_enter(f.z, f.w, g.x, g.y, g.z, g.w, nx, ny, nz, s, t0, t1);
-    const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-    if (n == 0) {
-        trav_pop(stack, tv);
-        return;
-    }
-    const int k_1 = (int)h0, k_2 = (int)h0 + (int)h1, k_3 = (int)h0 + (int)h1 + (int)h2;
-    tv.cur = h0 ? r0 : h1 ? r1 : h2 ? r2 : r3;
-    const int top = tv.sp + n - 1;
-    tv.sp = top;
-    if (__ballot((uint32_t)top > stack.cap) == 0ull) {  // (as trav_interior_step)
-        const int spare = (int)stack.cap;
-        stack.lds[(h0 ? top : spare) * 64] = r0;
-        stack.lds[(h1 ? top - k_1 : spare) * 64] = r1;
-        stack.lds[(h2 ? top - k_2 : spare) * 64] = r2;
-        stack.lds[(h3 ? top - k_3 : spare) * 64] = r3;
-    } else {
-        if (h1 && k_1 > 0) stack.put(top - k_1, r1);
-        if (h2 && k_2 > 0) stack.put(top - k_2, r2);
-        if (h3 && k_3 > 0) stack.put(top - k_3, r3);
-    }
-}
-
-// One leaf group that the f32 test let through: the reference's own test of its gating box decides (made in f64 only
-// for lanes whose f32 interval does not already prove that it passes), then the group's primitives, then pop.
-template <bool COUNT>
-RR_DEV void trav_leaf_step_gate32(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
-    const double tmin = sc.t0, tmax = sc.t1;
-    const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
-    const uint32_t count = (tv.cur & 3u) + 1u;
-    if (COUNT) wc.leaf_prims = count;
-    const uint4* bp = reinterpret_cast<const uint4*>(sc.leaf_box) + (size_t)first * 2;
-    const uint4 b0 = bp[0], b1 = bp[1];  // xmin xmax ymin ymax | zmin zmax - -
-#if RAYRS_GATE32_PREFETCH >= 1
-    PrimRec<true> r = load_prim<true>(sc.prims, first);  // (requested with the box, not behind its test)
-#endif
-#if RAYRS_GATE32_PREFETCH == 3
-    asm volatile("" : "+v"(r.q[0].x), "+v"(r.q[1].x), "+v"(r.q[2].x));  // (... and kept there)
-#endif
-    const Slab32& s = tv.s32;
-    const bool nx = s.vx < 0.0f, ny = s.vy < 0.0f, nz = s.vz < 0.0f;
-    bool enter = slab32_surely_enters(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, nx, ny, nz, s, sc.t0_hi, sc.t1_lo);
-    if (__ballot(!enter) != 0ull) {  // about one wave in a thousand
-        const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        double entry;
-        const bool gate = slab_f32(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, inv.x < 0.0, inv.y < 0.0, inv.z < 0.0, o, inv,
-                                   tmin, tmax, entry);
-        enter = enter || gate;
-    }
-#if RAYRS_GATE32_PREFETCH == 3
-    // (one loop, the record of primitive k + 1 requested at the end of primitive k's turn; the first with the box)
-    uint32_t k = 0;
-    const uint32_t n = enter ? count : 0u;
-    while (k < n) {
-        const uint32_t p = first + k;
-        if (COUNT) {
-            const uint32_t kind = r.tag() & 3u;
-            if (kind == PRIM_TRIANGLE) wc.tri++;
-            else if (kind == PRIM_SPHERE) wc.sphere++;
-            else wc.plane++;
-        }
-        double t;
-        if (prim_intersect<true>(r, o, d, t) && t > tmin && t < tmax) {   // bvh.rs:406
-            if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {  // bvh.rs:62
-                tv.best_t = t;
-                tv.best_prim = p;
-            }
-        }
-        k++;
-        if (k < n) r = load_prim<true>(sc.prims, first + k);
-    }
-#else
-    if (enter) {
-        for (uint32_t k = 0; k < count; k++) {
-            const uint32_t p = first + k;
-#if RAYRS_GATE32_PREFETCH >= 2
-            PrimRec<true> nxt = r;
-            if (k + 1u < count) nxt = load_prim<true>(sc.prims, p + 1u);  // the next one travels while this one is tested
-#elif RAYRS_GATE32_PREFETCH == 1
-            if (k > 0u) r = load_prim<true>(sc.prims, p);
-#else
-            const PrimRec<true> r = load_prim<true>(sc.prims, p);
-#endif
-            if (COUNT) {
-                const uint32_t kind = r.tag() & 3u;
-                if (kind == PRIM_TRIANGLE) wc.tri++;
-                else if (kind == PRIM_SPHERE) wc.sphere++;
-                else wc.plane++;
-            }
-            double t;
-            if (prim_intersect<true>(r, o, d, t) && t > tmin && t < tmax) {   // bvh.rs:406
-                if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {  // bvh.rs:62
-                    tv.best_t = t;
-                    tv.best_prim = p;
-                }
-            }
-#if RAYRS_GATE32_PREFETCH >= 2
-            r = nxt;
-#endif
-        }
-    }
-#endif
-    trav_pop(stack, tv);
-}
-
-// One leaf group for one ray, on its own (wavefront.hip wf_walk_kernel): the reference's test of the group's gating
-// box, then its primitives in DFS order; returns the group's closest accepted hit (prim = 0xffffffff: none).
-template <bool COUNT>
-RR_DEV void group_closest_hit(const SceneDev& sc, V3 o, V3 d, V3 inv, uint32_t ref, double& best_t, uint32_t& best_prim,
-                              WorkCount& wc) {
-    const double tmin = sc.t0, tmax = sc.t1;
-    const uint32_t first = (ref & 0x3fffffffu) >> 2;
-    const uint32_t count = (ref & 3u) + 1u;
-    const uint4* bp = reinterpret_cast<const uint4*>(sc.leaf_box) + (size_t)first * 2;
-    const uint4 b0 = bp[0], b1 = bp[1];  // xmin xmax ymin ymax | zmin zmax - -
-    PrimRec<true> r = load_prim<true>(sc.prims, first);  // (requested with the box, not behind its test)
-    asm volatile("" : "+v"(r.q[0].x), "+v"(r.q[1].x), "+v"(r.q[2].x));
-    best_t = tmax;
-    best_prim = 0xffffffffu;
-    double entry;
-    const bool enter = slab_f32(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, inv.x < 0.0, inv.y < 0.0, inv.z < 0.0, o, inv, tmin,
-                                tmax, entry);
-    const uint32_t n = enter ? count : 0u;
-    uint32_t k = 0;
-    while (k < n) {  // (the record of primitive k + 1 requested at the end of primitive k's turn)
-        const uint32_t p = first + k;
-        if (COUNT) {
-            const uint32_t kind = r.tag() & 3u;
-            if (kind == PRIM_TRIANGLE) wc.tri++;
-            else if (kind == PRIM_SPHERE) wc.sphere++;
-            else wc.plane++;
-        }
-        double t;
-        if (prim_intersect<true>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
-            if (t < best_t || (t == best_t && p < best_prim)) {          // bvh.rs:62
-                best_t = t;
-                best_prim = p;
-            }
-        }
-        k++;
-        if (k < n) r = load_prim<true>(sc.prims, first + k);
-    }
-}
-
 // One leaf reference: its 1..4 primitives in DFS order, then pop.
 template <bool COMPACT, bool COUNT>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
@@ -782,17 +522,13 @@ template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
-    constexpr bool GATE32 = COMPACT && EXACT;
-    trav_init<GATE32>(sc, o, d, tv);
+    trav_init(sc, o, d, tv);
     const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
-        if (trav_at_interior(tv)) {
-            if constexpr (GATE32) trav_interior_step_gate32<COUNT>(sc, stack, hot, tv, wc);
-            else trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
-        } else {
-            if constexpr (GATE32) trav_leaf_step_gate32<COUNT>(sc, o, d, stack, tv, wc);
-            else trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-        }
+        if (trav_at_interior(tv))
+            trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
+        else
+            trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
     }
     t_hit = tv.best_t;
     prim_hit = tv.best_prim;

@@ -6,9 +6,9 @@
 //   wide record      four boxes + four references              128 B (compact) / 256 B (full)
 //   primitive record triangle | sphere | plane + tag, DFS order  48 B (compact) /  80 B (full)
 //
-// The wide records are the product's own trees (scene_host.cpp build_walk_trees): the default
-// tree over the reference's primitives, each behind a box of its own inside its gating box, and
-// the gate tree over the reference's leaf groups behind exactly their gating boxes; the two-child
+// The wide records are the product's own trees (scene_host.cpp build_walk_trees): the gate tree
+// over the reference's leaf groups behind exactly their gating boxes (the default walk), and the fast
+// walk's tree over the reference's primitives, each behind a box of its own inside its gating box; the two-child
 // records of the reference's tree exist on the host only (rayrs_scene_export_bvh).
 //
 // "compact" = every box bound and every triangle vertex is exactly
@@ -104,14 +104,9 @@ struct SceneDev {
     double t0, t1;  // Scene::t_range, lib.rs:218
     double hdri_wm1, hdri_hm1;  // (hdri_w - 1) as f64 and (hdri_h - 1) as f64, lib.rs:262-263 (converted on the host: a kernel
                                 // that converts them hoists the results into vector registers for its whole run)
-    // rayrs_render_params.exact_traversal: the walk culls nothing by the closest hit so far, as BvhTree::intersect
+    // the default walk (rayrs_render_params.fast_traversal == 0): nothing is culled by the closest hit so far, as BvhTree::intersect
     // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
     uint32_t exact, pad1;
-    // the default walk on compact records (device_path.h GATE32): the gating box of the leaf group that starts at
-    // primitive p, as 8 f32 (xmin xmax ymin ymax zmin zmax - -) at leaf_box + 8 p; a bound on every |box bound| of the
-    // gate tree; the scene's t range rounded outwards and inwards to f32
-    const float* leaf_box;
-    float gate_bound, t0_lo, t1_hi, t0_hi, t1_lo, pad2;
 };
 
 struct CameraDev {
@@ -145,7 +140,6 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
-    uint32_t walk_list_refs, pad_walk;  // wf_walk_kernel: leaf groups a ray's list may hold before the ray is left to wf_trav_kernel
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)

@@ -32,11 +32,9 @@ typedef struct {
                                as far as needed to keep a frame within 64 segments */
     uint32_t force_rccl;    /* rayrs_render_multi: run the RCCL reduce even when every handle sits on one device
                                (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
-    uint32_t gate_tree;     /* 1 = the default walk (with closest-hit culling) over the gate tree instead of the tree
+    uint32_t gate_tree;     /* 1 = the fast walk (with closest-hit culling) over the gate tree instead of the tree
                                of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
                                profiles/r04_tight_leaves.txt */
-    uint32_t walk_list_refs; /* default walk on compact records: leaf groups a ray's list holds before the ray is left to
-                               the one-kernel walk, 3 .. the built-in limit (34); small values exercise that path */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

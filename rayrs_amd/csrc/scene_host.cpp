@@ -352,10 +352,10 @@ void front_largest(WalkTree& f) {
 // their exact gating boxes, and its interior boxes are unions of those, i.e. supersets -- a ray
 // that misses a superset misses every gating box inside it, so skipping the subtree skips
 // nothing the reference reaches: this tree reaches exactly what the reference reaches
-// (rayrs_render_params.exact_traversal, and the local-pool route's gates).  On the benchmark
+// (the default walk, and the local-pool route's gates).  On the benchmark
 // scenes it removes the chain of sixteen levels down which the reference carries the 50 x 50
 // floor (every query used to read all eight folded records of it) and halves the records a
-// query visits.  The DEFAULT tree's leaf slots are single primitives behind boxes of their own
+// query visits.  The FAST walk's tree's leaf slots are single primitives behind boxes of their own
 // inside the gating box (tight_box below): a subset of what the reference reaches.
 
 struct WalkGroup {
@@ -597,7 +597,7 @@ uint32_t emit_wide(WalkTree& f, const WideCollapse& wc, int32_t n, uint32_t* sta
     return (REF_INTERIOR << 30) | rec;
 }
 
-// The default tree's leaf slots: every primitive alone behind a box of its own -- its bounding box (the one
+// The fast walk's tree's leaf slots: every primitive alone behind a box of its own -- its bounding box (the one
 // Bvh::build computes for it, geometry.rs bbox) widened on every side by LEAF_MARGIN of its largest extent,
 // rounded outwards to f32 and clipped to its group's gating box.
 //   Nothing is tested that the reference does not reach: the box lies inside the gating box, and the slab test is
@@ -609,7 +609,7 @@ uint32_t emit_wide(WalkTree& f, const WideCollapse& wc, int32_t n, uint32_t* sta
 // primitive's plane: from 20 units away it takes a ray within 1e-11 rad of the plane of a primitive 0.02 across
 // that it passes beside (1e-8 rad from 1e4 scene sizes away, and so on) -- like closest-hit culling a bet on the
 // reference's arithmetic, measured (profiles/r04_tight_leaves.txt), not a construction;
-// rayrs_render_params.exact_traversal walks the gate tree, which makes neither bet.
+// the default walk is over the gate tree, which makes neither bet (rayrs_render_params.fast_traversal asks for this one).
 constexpr double LEAF_MARGIN = 0x1p-6;
 
 void tight_box(const Aabb& b, const double* gate, double* out) {
@@ -694,37 +694,6 @@ void fill_nodes(WalkTree& t) {
         }
 }
 
-// What the default walk needs beside the compact gate records (device_path.h GATE32): the gating box of every leaf
-// group where the leaf step finds it, the bound B of the f32 test's error term, and something harmless behind the
-// unused slots -- that test lets a ray into the inverted box if it ignores all three axes (an origin beyond 2^80 on
-// each), so such a slot refers to the tree's first leaf group: visiting a group twice changes nothing.
-void gate32_tables(FlatScene& f) {
-    WalkTree& t = f.gate;
-    t.leaf_box.assign((size_t)f.n_prims() * 8, 0.0f);
-    double bound = 0x1p-60;
-    for (int k = 0; k < 6; k++) bound = std::max(bound, std::fabs(f.root_box[k]));
-    if ((t.root_ref >> 30) == REF_RANGE)  // one bottom Node: its gating box is the root box
-        for (int k = 0; k < 6; k++) t.leaf_box[(size_t)((t.root_ref & 0x3fffffffu) >> 2) * 8 + k] = (float)f.root_box[k];
-    uint32_t first_leaf = REF_NONE << 30;
-    for (size_t r = 0; r < t.ref.size(); r++) {
-        const uint32_t ref = t.ref[r];
-        if ((ref >> 30) == REF_NONE) continue;
-        for (int k = 0; k < 6; k++) bound = std::max(bound, std::fabs(t.box[r * 6 + k]));
-        if ((ref >> 30) != REF_RANGE) continue;
-        if ((first_leaf >> 30) == REF_NONE) first_leaf = ref;
-        const size_t first = (ref & 0x3fffffffu) >> 2;
-        for (int k = 0; k < 6; k++) t.leaf_box[first * 8 + k] = (float)t.box[r * 6 + k];
-    }
-    float bf = (float)bound;
-    if ((double)bf < bound) bf = std::nextafterf(bf, std::numeric_limits<float>::infinity());
-    t.bound = bf;
-    if (t.n() == 0) return;  // one bottom Node: no records, nothing walks them
-    Node4F32* nodes = reinterpret_cast<Node4F32*>(t.node_bytes.data());
-    for (uint32_t r = 0; r < t.n(); r++)
-        for (int ch = 0; ch < 4; ch++)
-            if ((t.ref[(size_t)r * 4 + ch] >> 30) == REF_NONE) nodes[r].ref[ch] = first_leaf;
-}
-
 void put_f64(uint32_t* dst, double v) { std::memcpy(dst, &v, 8); }
 void put_f32(uint32_t* dst, float v) { std::memcpy(dst, &v, 4); }
 
@@ -787,16 +756,11 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
                 break;
             }
     }
-    // (the default walk's f32 box test on compact records assumes bounds below 2^80: device_path.h GATE32)
-    // (and, for a scene of one bottom Node, that Node's box in f32 like every other gating box)
-    for (int k = 0; k < 6 && compact; k++)
-        compact = std::fabs(f.root_box[k]) < 0x1p80 && ((f.root_ref >> 30) == REF_INTERIOR || f32_exact(f.root_box[k]));
     f.compact = compact;
     for (WalkTree* t : {&f.gate, &f.walk}) {
         if (compact) fill_nodes<Node4F32, float>(*t);
         else fill_nodes<Node4F64, double>(*t);
     }
-    if (compact) gate32_tables(f);
 
     // ---- primitive records in DFS order
     const uint32_t dw = compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL;

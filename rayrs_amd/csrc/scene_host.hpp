@@ -51,10 +51,6 @@ struct WalkTree {
     uint32_t root_ref = 0;
     uint32_t depth = 0;         // stack entries the traversal can need
     std::vector<uint8_t> node_bytes;  // the records as the kernels read them (Node4F32 / Node4F64)
-    // compact gate tree only (device_path.h GATE32): per primitive record p 8 floats, the gating box of the leaf group
-    // that starts at p (zeros elsewhere), and a bound on every |box bound| in the tree (at least 2^-60)
-    std::vector<float> leaf_box;
-    float bound = 0.0f;
     uint32_t n() const { return (uint32_t)(ref.size() / 4); }
 };
 
@@ -67,8 +63,8 @@ struct FlatScene {
     uint32_t depth = 0;
     // The trees the kernels traverse (scene_host.cpp "the walk trees"): four-slot records whose leaf slots are
     //   gate  the reference's leaf groups behind their exact gating boxes -- reaches exactly what the reference
-    //         reaches; walked when rayrs_render_params.exact_traversal is set, and by the local-pool route;
-    //   walk  single primitives behind their own widened boxes inside the gating box -- the default.
+    //         reaches; the default walk's tree, and where the local-pool route's gates come from;
+    //   walk  single primitives behind their own widened boxes inside the gating box (rayrs_render_params.fast_traversal).
     WalkTree walk, gate;
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;

@@ -22,7 +22,6 @@ struct rayrs_scene {
     uint64_t n_objects = 0;
     int device = -1;
     void* d_prims = nullptr;
-    float* d_leaf_box = nullptr;  // FlatScene::gate.leaf_box (compact scenes)
     rayrs::SurfaceDev* d_surfaces = nullptr;
     float* d_hdri = nullptr;
     rayrs::Counters* d_counters = nullptr;
@@ -33,8 +32,8 @@ struct rayrs_scene {
     bool pending = false;
     bool last_count = false;
     int cu_count = 0;
-    // How the traversal kernel walks each of the scene's two trees: [0] FlatScene::walk (the default),
-    // [1] FlatScene::gate (rayrs_render_params.exact_traversal).
+    // How the traversal kernel walks each of the scene's two trees: [0] FlatScene::walk (rayrs_render_params.fast_traversal),
+    // [1] FlatScene::gate (the default walk).
     struct Walk {
         void* d_nodes = nullptr;
         int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
@@ -42,7 +41,6 @@ struct rayrs_scene {
         uint32_t hot_records = 0;    // leading records kept in LDS
     };
     Walk trav[2];
-    int leaf_blocks_per_cu = 0;      // wf_leaf_kernel, from the occupancy query
     const rayrs::WalkTree& tree(bool exact) const { return exact ? flat.gate : flat.walk; }
     uint64_t device_bytes = 0;
     // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,
@@ -55,8 +53,6 @@ struct rayrs_scene {
         uint32_t wave_items_cap = 0;
         uint32_t* d_stack_spill = nullptr;
         size_t stack_spill_words = 0;
-        uint32_t* d_walk_list = nullptr;  // wf_walk_kernel's lists of leaf groups (compact scenes, default walk)
-        size_t walk_list_words = 0;
         uint32_t* h_live = nullptr;  // pinned: live_slots read-backs
         hipEvent_t ev_batch[2] = {nullptr, nullptr};
         std::vector<hipEvent_t> ev_round;  // four per round: around the traversal, hit and miss launches

@@ -56,8 +56,6 @@ constexpr uint8_t WF_READY = 1;  // ray written, waiting for the traversal kerne
 constexpr uint8_t WF_HIT = 2;    // closest hit found: hit_kernel's input
 constexpr uint8_t WF_MISS = 3;   // no hit: miss_kernel's input
 constexpr uint8_t WF_DEAD = 4;   // out of work (or padding of the pool)
-constexpr uint8_t WF_LISTED = 5;    // wf_walk_kernel's output, wf_leaf_kernel's input; | number of leaf groups (15: in WfDev::walk_list) << 4
-constexpr uint8_t WF_FALLBACK = 6;  // a ray with more leaf groups than its list holds: left to wf_trav_kernel
 
 // Two 128-byte lines, by who writes them: the window cursor takes the traversal kernel's atomics, live_slots the hit and
 // miss kernels'.  A scalar load from a line that atomics are hammering pays the trip to memory every time: live_slots
@@ -84,10 +82,6 @@ struct WfDev {
     // grid per entry beyond SceneDev::stack_lds
     uint32_t trav_threads;
     uint32_t* stack_spill;
-    // the default walk on compact records (wf_walk_kernel / wf_leaf_kernel): per slot wf_walk_list_words() words,
-    // and the second kernel's grid
-    uint32_t* walk_list;
-    uint32_t leaf_blocks;
 };
 
 uint32_t wf_window_slots();  // slots per window (a divisor of 1024)
@@ -96,11 +90,7 @@ hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
-// exact: the kernel of the default walk (on compact records wf_walk_kernel)
-hipError_t wf_trav_occupancy(bool compact, bool exact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
-hipError_t wf_leaf_occupancy(int* blocks_per_cu);
-uint32_t wf_walk_list_words();  // words per slot of WfDev::walk_list
-uint32_t wf_walk_list_refs();   // leaf groups a ray's list holds (RenderDev::walk_list_refs: at most that)
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
 // eager_light: request the side array's entry together with the slot (scenes in which a surface emits)
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);

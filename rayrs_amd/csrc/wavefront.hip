@@ -430,8 +430,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-// LEFT: the rays wf_walk_kernel left behind (WF_FALLBACK) instead of the READY ones
-template <bool COMPACT, bool COUNT, bool EXACT, bool LEFT = false>
+template <bool COMPACT, bool COUNT, bool EXACT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -513,7 +512,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                         break;
                     }
                     list_base = w * WINDOW;
-                    list_len = LEFT ? compact_window(wf, w, WF_FALLBACK, list) : compact_window_ready(wf, w, list);
+                    list_len = compact_window_ready(wf, w, list);
                     list_pos = 0;
                     continue;
                 }
@@ -524,7 +523,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                     const RaySlot* rs = ray_slot(wf, slot);
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
-                    if (!LEFT) n_rays++;  // (a ray that was left behind has been counted by the kernel that left it)
+                    n_rays++;
                     trav_init(sc, o, d, tv);
                     if (tv.cur == TRAV_DONE)
                         pending = true;  // missed the root box: retired at the next refill
@@ -581,278 +580,6 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
             atomicAdd(&c->refill_ticks, tk_refill);
         }
-    }
-}
-
-// ------------------------------------------------------------------- walk
-//
-// The default walk on compact records (device_path.h GATE32) as two kernels.  Nothing is culled by the closest hit, so
-// WHICH records and leaf groups a ray reaches does not depend on what it hits:
-//   wf_walk_kernel   a lane only walks -- f32 box tests, a dozen registers of state, no primitive in sight -- and
-//                    writes down the leaf groups it arrives at: the first three into the slot's own (still unused)
-//                    t / prim words, further ones into the slot's entry of WfDev::walk_list; how many, into the
-//                    high half of the slot's state byte (WF_LISTED).  A ray that arrives nowhere is a MISS at once;
-//   wf_leaf_kernel   a lane takes a listed ray and works through its groups: the reference's own test of the
-//                    group's gating box, then of its primitives (f64), closest hit kept in registers.
-// Both are persistent and refill finished lanes like wf_trav_kernel, but each does one kind of step only: no vote
-// between "interior" and "leaf" turns with 40 % of the lanes standing by in either, and the walk's few registers
-// leave room for more waves to hide its record fetches behind.  A ray with more groups than its list holds
-// (WALK_LIST_REFS) is left to wf_trav_kernel (WF_FALLBACK), launched behind the two and normally finding nothing.
-constexpr uint32_t WALK_LIST_WORDS = 32;                      // per slot: [0] the count when it exceeds 14, [1..] references
-constexpr uint32_t WALK_LIST_REFS = 3 + WALK_LIST_WORDS - 1;  // three of them in the slot itself
-
-RR_DEV uint32_t compact_window_low(const WfDev& wf, uint32_t win, uint8_t want_low, uint16_t* list) {
-    const StateWords sw = load_state_words(wf, win);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    uint32_t count = 0;
-#pragma unroll
-    for (int j = 0; j < (int)SPL; j++) {
-        const uint32_t s = (sw.w[j >> 2] >> ((j & 3) * 8)) & 0x0fu;
-        const bool m = s == (uint32_t)want_low;
-        const unsigned long long mask = __ballot(m);
-        if (m) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = (uint16_t)(lane * SPL + (uint32_t)j);
-        count += (uint32_t)__popcll(mask);
-    }
-    return count;
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(256, 8) wf_walk_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
-    extern __shared__ uint32_t lds_dyn[];
-    WfCtl* ctl = wf.ctl;
-    if (ctl->live_slots == 0u) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane,
-                          wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u) + wave * WINDOW;
-    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u + 4u * WINDOW / 2u);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
-        for (uint32_t i = threadIdx.x; i < sc.hot_records * 8u; i += 256u)
-            hot_lds[(i / 8u) * HotNodes::stride<true>() + i % 8u] = src[i];
-        __syncthreads();
-    }
-    const HotNodes hot{hot_lds, sc.hot_records};
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-
-    const uint32_t n_windows = wf.np / WINDOW;
-    const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t static_windows = ctl->live_slots < wf.np / 4u ? n_windows : rp.static_windows;  // (wf_trav_kernel)
-    uint32_t static_next = blockIdx.x * 4u + wave;
-    uint32_t list_pos = 0, list_len = 0, list_base = 0;
-    bool no_more = false;
-
-    bool has_ray = false;
-    uint32_t slot = 0, n_groups = 0, g0 = 0, g1 = 0, g2 = 0;
-    Trav tv;
-    tv.inv = mk(0, 0, 0), tv.best_t = 0, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
-    tv.s32.vx = tv.s32.vy = tv.s32.vz = 0.0f;
-    tv.s32.cx = tv.s32.cy = tv.s32.cz = f32x2{0.0f, 0.0f};
-    WorkCount wc{0, 0, 0, 0, 0};
-    unsigned long long n_rays = 0, u_int_wave = 0, u_int_lane = 0;
-    unsigned long long tk_int = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
-
-    for (;;) {
-        const bool walking = has_ray && tv.cur != TRAV_DONE;
-        const int n_walk = __popcll(__ballot(walking));
-        if ((n_walk < (int)rp.refill_min && !no_more) || n_walk == 0) {
-            // ---- rays whose walk is over: their list goes to the slot
-            if (has_ray && !walking) {
-                uint8_t st = WF_MISS;  // arrived nowhere: nothing to test, no hit
-                if (n_groups > rp.walk_list_refs) {
-                    st = WF_FALLBACK;
-                } else if (n_groups > 0u) {
-                    uint32_t* w = reinterpret_cast<uint32_t*>(&ray_slot(wf, slot)->t);
-                    w[0] = g0, w[1] = g1, w[2] = g2;
-                    if (n_groups > 14u) wf.walk_list[(size_t)slot * WALK_LIST_WORDS] = n_groups;
-                    st = (uint8_t)(WF_LISTED | ((n_groups > 14u ? 15u : n_groups) << 4));
-                }
-                wf.state[slot] = st;
-                has_ray = false;
-            }
-            if (no_more) break;  // only reached with no walk in flight
-            // ---- idle lanes take rays from the wave's window list (as wf_trav_kernel)
-            bool need = !has_ray;
-            unsigned long long need_mask = __ballot(need);
-            while (need_mask != 0ull) {
-                if (list_pos >= list_len) {
-                    uint32_t w = static_next;
-                    if (w < static_windows) {
-                        static_next += n_waves;
-                    } else {
-                        if (lane == 0) w = static_windows + atomicAdd(&ctl->next_window, 1u);
-                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-                    }
-                    if (w >= n_windows) {
-                        no_more = true;
-                        break;
-                    }
-                    list_base = w * WINDOW;
-                    list_len = compact_window_ready(wf, w, list);
-                    list_pos = 0;
-                    continue;
-                }
-                const uint32_t avail = list_len - list_pos;
-                const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
-                if (need && rank < avail) {
-                    slot = list_base + (uint32_t)list[list_pos + rank];
-                    const RaySlot* rs = ray_slot(wf, slot);
-                    const V3 o = mk(rs->o[0], rs->o[1], rs->o[2]), d = mk(rs->d[0], rs->d[1], rs->d[2]);
-                    n_rays++;
-                    trav_init<true>(sc, o, d, tv);
-                    n_groups = 0;
-                    has_ray = true;
-                    need = false;
-                }
-                const uint32_t wanted = (uint32_t)__popcll(need_mask);
-                list_pos += wanted < avail ? wanted : avail;
-                need_mask = __ballot(need);
-            }
-            if (COUNT) {
-                const unsigned long long now = clock64();
-                tk_refill += now - tk_last, tk_last = now;
-            }
-            if (__ballot(has_ray) == 0ull && no_more) break;
-            continue;
-        }
-        // ---- a lane that has arrived at a leaf group writes it down and goes on with what its stack holds
-        if (walking && !trav_at_interior(tv)) {
-            const uint32_t ref = tv.cur;
-            g0 = n_groups == 0u ? ref : g0, g1 = n_groups == 1u ? ref : g1, g2 = n_groups == 2u ? ref : g2;
-            if (n_groups >= 3u && n_groups < rp.walk_list_refs)
-                wf.walk_list[(size_t)slot * WALK_LIST_WORDS + (n_groups - 2u)] = ref;
-            n_groups++;
-            trav_pop(stack, tv);
-        }
-        // ---- one record for every lane standing on one
-        {
-            const bool at_int = has_ray && tv.cur != TRAV_DONE && trav_at_interior(tv);
-            if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
-            if (at_int) trav_interior_step_gate32<COUNT>(sc, stack, hot, tv, wc);
-        }
-        if (COUNT) {
-            const unsigned long long now = clock64();
-            tk_int += now - tk_last, tk_last = now;
-        }
-    }
-
-    Counters* c = rp.counters;
-    wave_atomic_add(&c->rays, n_rays);
-    if (COUNT) {
-        wave_atomic_add(&c->interior_visits, wc.interior);
-        wave_atomic_add(&c->step_wave, u_int_wave), wave_atomic_add(&c->step_lane, u_int_lane);
-        if (lane == 0) atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->refill_ticks, tk_refill);
-    }
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(256, 5) wf_leaf_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
-    __shared__ uint16_t lists[4 * WINDOW];
-    WfCtl* ctl = wf.ctl;
-    if (ctl->live_slots == 0u) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint16_t* list = lists + wave * WINDOW;
-    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
-    const uint32_t n_windows = wf.np / WINDOW;
-    const uint32_t n_waves = gridDim.x * 4u;
-    uint32_t next_win = blockIdx.x * 4u + wave;  // dealt round robin (the kernel's work is even across windows)
-    uint32_t list_pos = 0, list_len = 0, list_base = 0;
-    bool no_more = false;
-
-    bool has_ray = false;
-    uint32_t slot = 0, n_groups = 0, k = 0, g0 = 0, g1 = 0, g2 = 0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0);
-    double best_t = 0.0;
-    uint32_t best_prim = 0xffffffffu;
-    WorkCount wc{0, 0, 0, 0, 0};
-    unsigned long long u_leaf_wave = 0, u_leaf_lane = 0;
-    unsigned long long tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
-
-    for (;;) {
-        const bool busy = has_ray && k < n_groups;
-        const int n_busy = __popcll(__ballot(busy));
-        if ((n_busy < (int)rp.leaf_min && !no_more) || n_busy == 0) {
-            if (has_ray && !busy) {
-                const bool hit = best_prim != 0xffffffffu;
-                if (hit) {
-                    RaySlot* rs = ray_slot(wf, slot);
-                    rs->t = best_t;
-                    rs->prim = best_prim;
-                }
-                wf.state[slot] = hit ? WF_HIT : WF_MISS;
-                has_ray = false;
-            }
-            if (no_more) break;
-            bool need = !has_ray;
-            unsigned long long need_mask = __ballot(need);
-            while (need_mask != 0ull) {
-                if (list_pos >= list_len) {
-                    const uint32_t w = next_win;
-                    if (w >= n_windows) {
-                        no_more = true;
-                        break;
-                    }
-                    next_win += n_waves;
-                    list_base = w * WINDOW;
-                    list_len = compact_window_low(wf, w, WF_LISTED, list);
-                    list_pos = 0;
-                    continue;
-                }
-                const uint32_t avail = list_len - list_pos;
-                const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
-                if (need && rank < avail) {
-                    slot = list_base + (uint32_t)list[list_pos + rank];
-                    const RaySlot* rs = ray_slot(wf, slot);
-                    o = mk(rs->o[0], rs->o[1], rs->o[2]);
-                    d = mk(rs->d[0], rs->d[1], rs->d[2]);
-                    const uint32_t* w = reinterpret_cast<const uint32_t*>(&rs->t);
-                    g0 = w[0], g1 = w[1], g2 = w[2];
-                    n_groups = (uint32_t)wf.state[slot] >> 4;
-                    if (n_groups == 15u) n_groups = wf.walk_list[(size_t)slot * WALK_LIST_WORDS];
-                    inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    best_t = sc.t1, best_prim = 0xffffffffu;
-                    k = 0;
-                    has_ray = true;
-                    need = false;
-                }
-                const uint32_t wanted = (uint32_t)__popcll(need_mask);
-                list_pos += wanted < avail ? wanted : avail;
-                need_mask = __ballot(need);
-            }
-            if (COUNT) {
-                const unsigned long long now = clock64();
-                tk_refill += now - tk_last, tk_last = now;
-            }
-            if (__ballot(has_ray) == 0ull && no_more) break;
-            continue;
-        }
-        // ---- one leaf group for every lane that has one left
-        if (COUNT) u_leaf_wave += 1, u_leaf_lane += busy ? 1 : 0;
-        if (busy) {
-            uint32_t ref = k == 0u ? g0 : k == 1u ? g1 : g2;
-            if (k >= 3u) ref = wf.walk_list[(size_t)slot * WALK_LIST_WORDS + (k - 2u)];
-            double t;
-            uint32_t prim;
-            group_closest_hit<COUNT>(sc, o, d, inv, ref, t, prim, wc);
-            if (prim != 0xffffffffu && (t < best_t || (t == best_t && prim < best_prim))) best_t = t, best_prim = prim;
-            k++;
-        }
-        if (COUNT) {
-            const unsigned long long now = clock64();
-            tk_leaf += now - tk_last, tk_last = now;
-        }
-    }
-
-    if (COUNT) {
-        Counters* c = rp.counters;
-        wave_atomic_add(&c->tri_tests, wc.tri);
-        wave_atomic_add(&c->sphere_tests, wc.sphere);
-        wave_atomic_add(&c->plane_tests, wc.plane);
-        wave_atomic_add(&c->inner_wave, u_leaf_lane), wave_atomic_add(&c->leaf_wave, u_leaf_wave);
-        if (lane == 0) atomicAdd(&c->leaf_ticks, tk_leaf), atomicAdd(&c->refill_ticks, tk_refill);
     }
 }
 
@@ -1130,8 +857,6 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
 static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
     return 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
 }
-uint32_t wf_walk_list_words() { return WALK_LIST_WORDS; }
-uint32_t wf_walk_list_refs() { return WALK_LIST_REFS; }
 
 uint32_t wf_window_slots() { return WINDOW; }
 
@@ -1151,15 +876,8 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (!sc.exact) {
-        hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    } else if constexpr (COMPACT) {  // the default walk on compact records: walk, then leaf groups, then what was left
-        hipLaunchKernelGGL((wf_walk_kernel<COUNT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-        hipLaunchKernelGGL((wf_leaf_kernel<COUNT>), dim3(wf.leaf_blocks), dim3(256), 0, stream, sc, rp, wf);
-        hipLaunchKernelGGL((wf_trav_kernel<true, COUNT, true, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    } else {
-        hipLaunchKernelGGL((wf_trav_kernel<false, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    }
+    if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -1176,22 +894,14 @@ template <bool COMPACT, bool COUNT>
 static hipError_t trav_set_lds(uint32_t lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess || COMPACT) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<false, COUNT, true>),
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t wf_trav_occupancy(bool compact, bool exact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
     const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
-    if (compact && exact) {  // wf_walk_kernel (and wf_trav_kernel for what it leaves behind, with the same LDS)
-        const void* ks[4] = {reinterpret_cast<const void*>(&wf_walk_kernel<false>), reinterpret_cast<const void*>(&wf_walk_kernel<true>),
-                             reinterpret_cast<const void*>(&wf_trav_kernel<true, false, true, true>),
-                             reinterpret_cast<const void*>(&wf_trav_kernel<true, true, true, true>)};
-        for (const void* k : ks)
-            if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_walk_kernel<false>, 256, lds);
-    }
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
@@ -1200,10 +910,6 @@ hipError_t wf_trav_occupancy(bool compact, bool exact, uint32_t stack_lds, uint3
     if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
     if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, false>, 256, lds);
-}
-
-hipError_t wf_leaf_occupancy(int* blocks_per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_leaf_kernel<false>, 256, 0);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,
