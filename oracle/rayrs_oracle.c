@@ -863,11 +863,6 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
-    int have_gate8;     /* orc_set_gate8: traversal 2 walks the product's eight-slot records (device_path.h GATE8) */
-    uint32_t g8_n, g8_root_ref, g8_depth;
-    float g8_bound;
-    uint8_t* g8_nodes;  /* g8_n records of 128 bytes (layout.h Node8Q) */
-    double* g8_leaf_box; /* per primitive record 6 doubles: the gating box of the leaf group that starts there */
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -884,8 +879,6 @@ void orc_scene_destroy(orc_scene* s) {
     free(s->prim_object);
     free(s->wide_box);
     free(s->wide_ref);
-    free(s->g8_nodes);
-    free(s->g8_leaf_box);
     free(s);
 }
 
@@ -1318,30 +1311,6 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
-    s->have_gate8 = 0;
-    return 0;
-}
-
-/* Hands the oracle the records the product's default walk reads on a compact scene (rayrs_test_gate8_export): n
- * eight-slot records with quantised boxes, and the slots' exact boxes and references (box: n * 48, ref: n * 8), from
- * which the leaf groups' gating boxes are taken.  Traversal 2 then makes that walk (isect_gate8 below). */
-int orc_set_gate8(orc_scene* s, uint32_t n, uint32_t root_ref, uint32_t depth, float bound, const void* nodes,
-                  const double* box, const uint32_t* ref) {
-    if (!s || !s->built) return -1;
-    free(s->g8_nodes);
-    free(s->g8_leaf_box);
-    s->g8_nodes = (uint8_t*)malloc((size_t)n * 128 + 1);
-    memcpy(s->g8_nodes, nodes, (size_t)n * 128);
-    const size_t np = (size_t)s->finfo.n_prims;
-    s->g8_leaf_box = (double*)calloc(np * 6 + 1, sizeof(double));
-    for (size_t k = 0; k < (size_t)n * 8; k++) {
-        if ((ref[k] >> 30) != REF_KIND_RANGE) continue;
-        const size_t first = (ref[k] & 0x3fffffffu) >> 2;
-        if (first >= np) return -2;
-        for (int q = 0; q < 6; q++) s->g8_leaf_box[first * 6 + q] = box[k * 6 + q];
-    }
-    s->g8_n = n, s->g8_root_ref = root_ref, s->g8_depth = depth, s->g8_bound = bound;
-    s->have_gate8 = 1;
     return 0;
 }
 
@@ -1582,119 +1551,7 @@ void orc_set_visit_histogram(uint64_t* hist) { g_visit_hist = hist; }
  * slot), the rest pushed farthest first.  Every leaf slot is a group of the reference's tree
  * behind its gating box, so the primitives tested are a subset of those the reference reaches
  * that contains the closest hit. */
-/* ---- device_path.h GATE8, operation for operation (f32, round to nearest, fmaf with one rounding) */
-typedef struct {
-    float v[3], cn[3], cf[3];
-} slab32_t;
-
-static void slab32_axis(double o, double v, float bound, float* v32, float* cn, float* cf) {
-    const int ok = fabs(v) < 0x1p40 && fabs(o) < 0x1p80;
-    *v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * *v32;
-    const float e = ok ? (fabsf(o32) + bound) * (fabsf(*v32) * 0x1p-20f) : INFINITY;
-    *cn = -oi - e;
-    *cf = e - oi;
-}
-
-static void f32_around(double x, float* below, float* above) {
-    const float f = (float)x;
-    *below = (double)f > x ? nextafterf(f, -INFINITY) : f;
-    *above = (double)f < x ? nextafterf(f, INFINITY) : f;
-}
-
-static isect_t isect_gate8(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
-    isect_t best = {0, 0.0, -1};
-    uint32_t best_prim = 0xffffffffu;
-    v3 inv = V(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-    {   /* rays that miss the root Node's box never reach the walk: the kernels that make them answer them */
-        double entry;
-        if (!aabb_intersect_entry(s->finfo.root_box, ray, inv, tmin, tmax, &entry)) return best;
-    }
-    slab32_t sl;
-    slab32_axis(ray.o.x, inv.x, s->g8_bound, &sl.v[0], &sl.cn[0], &sl.cf[0]);
-    slab32_axis(ray.o.y, inv.y, s->g8_bound, &sl.v[1], &sl.cn[1], &sl.cf[1]);
-    slab32_axis(ray.o.z, inv.z, s->g8_bound, &sl.v[2], &sl.cn[2], &sl.cf[2]);
-    float t0_lo, t0_hi, t1_lo, t1_hi;
-    f32_around(tmin, &t0_lo, &t0_hi);
-    f32_around(tmax, &t1_lo, &t1_hi);
-    (void)t0_hi, (void)t1_lo;
-    const size_t cap = (size_t)s->g8_depth + 16u;
-    uint32_t* stack = (uint32_t*)malloc(cap * sizeof(uint32_t));
-    int sp = 0;
-    uint32_t cur = s->g8_root_ref;
-    for (;;) {
-        if ((cur >> 30) == REF_KIND_INTERIOR) {
-            const uint8_t* nd = s->g8_nodes + (size_t)(cur & 0x3fffffffu) * 128;
-            if (cnt) cnt->interior_visits++;
-            float origin[3];
-            uint32_t refs[8];
-            memcpy(origin, nd, 12);
-            memcpy(refs, nd + 64, 32);
-            float a[3], bn[3], bf[3];
-            for (int k = 0; k < 3; k++) {
-                uint32_t sb = (uint32_t)nd[12 + k] << 23;
-                float scale;
-                memcpy(&scale, &sb, 4);
-                a[k] = sl.v[k] * scale;
-                bn[k] = fmaf(origin[k], sl.v[k], sl.cn[k]);
-                bf[k] = fmaf(origin[k], sl.v[k], sl.cf[k]);
-            }
-            uint32_t pend[8];
-            int np = 0;
-            for (int c = 0; c < 8; c++) {
-                float l[3], u[3];
-                for (int k = 0; k < 3; k++) {
-                    const int neg = sl.v[k] < 0.0f;
-                    const uint8_t* q = nd + 16 + k * 16; /* [0..7] low bounds, [8..15] high bounds */
-                    const float qn = (float)q[(neg ? 8 : 0) + c], qf = (float)q[(neg ? 0 : 8) + c];
-                    l[k] = fmaf(qn, a[k], bn[k]);
-                    u[k] = fmaf(qf, a[k], bf[k]);
-                }
-                const float lo = fmaxf(fmaxf(fmaxf(l[0], l[1]), l[2]), t0_lo);
-                const float hi = fminf(fminf(fminf(u[0], u[1]), u[2]), t1_hi);
-                if (!(hi < lo)) pend[np++] = refs[c];
-            }
-            if (np > 0) { /* slot order: the first goes next, the others are stacked so that they pop in slot order */
-                for (int k = np - 1; k >= 1; k--) stack[sp++] = pend[k];
-                cur = pend[0];
-                continue;
-            }
-        } else {
-            uint32_t first = (cur & 0x3fffffffu) >> 2;
-            uint32_t count = (cur & 3u) + 1u;
-            double entry;
-            if (aabb_intersect_entry(s->g8_leaf_box + (size_t)first * 6, ray, inv, tmin, tmax, &entry)) {
-                for (uint32_t k = 0; k < count; k++) {
-                    uint32_t p = first + k;
-                    int obj = (int)s->prim_object[p];
-                    const shape_t* g = &s->objs[obj].geom;
-                    if (cnt) {
-                        if (g->kind == ORC_SHAPE_TRIANGLE) cnt->tri_tests++;
-                        else if (g->kind == ORC_SHAPE_SPHERE) cnt->sphere_tests++;
-                        else cnt->plane_tests++;
-                    }
-                    double t;
-                    if (shape_intersect(g, ray, &t) && t > tmin && t < tmax) {
-                        if (!best.hit || t < best.t || (t == best.t && p < best_prim)) {
-                            best.hit = 1;
-                            best.t = t;
-                            best.obj = obj;
-                            best_prim = p;
-                        }
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        cur = stack[--sp];
-    }
-    free(stack);
-    return best;
-}
-
 static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
-    if (s->have_gate8) return isect_gate8(s, ray, tmin, tmax, cnt);
     if (!s->have_wide) {
         fprintf(stderr, "oracle: traversal 2 needs the product's walk tree (orc_set_wide)\n");
         abort();

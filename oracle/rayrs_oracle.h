@@ -205,12 +205,6 @@ int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide
  * traversal 2 walks them.  The oracle does not build that tree itself. */
 int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
                  const uint32_t* wide_ref);
-/* The records the product's default walk reads on a compact scene (rayrs_selftest.h rayrs_test_gate8_export): n
- * eight-slot records of 128 bytes with quantised boxes, tested in f32 with every rounding pushed outwards; box (n * 48)
- * and ref (n * 8) are the slots' exact boxes and references, whose leaf slots give the groups' gating boxes, tested
- * exactly before a group's primitives.  Traversal 2 makes that walk until orc_set_wide is called again. */
-int orc_set_gate8(orc_scene* s, uint32_t n, uint32_t root_ref, uint32_t depth, float bound, const void* nodes,
-                  const double* box, const uint32_t* ref);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

@@ -28,7 +28,7 @@ SYMBOLS = [
 
 # rayrs_amd/csrc/rayrs_selftest.h and rayrs_lab.h: private hooks of the library (tests/ and scripts/ only)
 PRIVATE_SYMBOLS = ["rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_path_trace", "rayrs_test_material", "rayrs_test_background",
-                   "rayrs_test_gate8_info", "rayrs_test_gate8_export", "rayrs_lab_set", "rayrs_lab_round_ms"]
+                   "rayrs_lab_set", "rayrs_lab_round_ms"]
 
 
 class MaterialDesc(C.Structure):
@@ -136,8 +136,6 @@ def lib():
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
     L.rayrs_scene_export_gate_tree.argtypes = [vp, vp, vp]
-    L.rayrs_test_gate8_info.argtypes = [vp, vp]
-    L.rayrs_test_gate8_export.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]

@@ -357,20 +357,6 @@ class Scene:
                    "rayrs_scene_export_gate_tree")
         return box[:i["gate_n_wide"]], ref[:i["gate_n_wide"]]
 
-    def export_gate8(self):
-        """The eight-slot records the default walk reads on a compact scene (rayrs_selftest.h; tests only):
-        dict(n, root_ref, depth, bound, nodes[n,128] u8, box[n,8,6], ref[n,8]); n = 0: the scene has none."""
-        out = np.zeros(4, dtype=np.uint32)
-        _ffi.check(self._L.rayrs_test_gate8_info(self._h, out.ctypes.data), "rayrs_test_gate8_info")
-        n = int(out[0])
-        nodes = np.zeros((max(n, 1), 128), dtype=np.uint8)
-        box = np.zeros((max(n, 1), 8, 6), dtype=np.float64)
-        ref = np.zeros((max(n, 1), 8), dtype=np.uint32)
-        _ffi.check(self._L.rayrs_test_gate8_export(self._h, nodes.ctypes.data, box.ctypes.data, ref.ctypes.data),
-                   "rayrs_test_gate8_export")
-        return {"n": n, "root_ref": int(out[1]), "depth": int(out[2]), "bound": float(out[3:4].view(np.float32)[0]),
-                "nodes": nodes[:n], "box": box[:n], "ref": ref[:n]}
-
     def close(self):
         if self._h is not None:
             self._L.rayrs_scene_destroy(self._h)

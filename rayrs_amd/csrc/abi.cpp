@@ -5,7 +5,6 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
-#include <limits>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -198,7 +197,6 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     for (auto& w : s->trav)
         if (w.d_nodes) (void)hipFree(w.d_nodes);
     if (s->d_prims) (void)hipFree(s->d_prims);
-    if (s->d_leaf_box) (void)hipFree(s->d_leaf_box);
     if (s->d_surfaces) (void)hipFree(s->d_surfaces);
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -237,19 +235,17 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 // five workgroups (the kernel's launch bound) share a CU's 160 KiB.
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;
-    for (int x = 0; x < 3; x++) {
-        if (x == 2 && f.gate8.n() == 0) continue;
-        const uint32_t t_depth = x == 2 ? f.gate8.depth : s->tree(x != 0).depth;
-        const uint32_t t_n = x == 2 ? f.gate8.n() : s->tree(x != 0).n();
+    for (int x = 0; x < 2; x++) {
+        const WalkTree& t = s->tree(x != 0);
         rayrs_scene::Walk& w = s->trav[x];
-        const uint32_t depth = t_depth ? t_depth : 1;
+        const uint32_t depth = t.depth ? t.depth : 1;
         uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
         w.stack_lds = want < depth ? want : depth;
         const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
         uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
         if (s->lab.hot_records == 0xffffffffu) hot = 0;
         else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
-        w.hot_records = hot < t_n ? hot : t_n;
+        w.hot_records = hot < t.n() ? hot : t.n();
         HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.hot_records, &w.blocks_per_cu));
         if (w.blocks_per_cu < 1) w.blocks_per_cu = 1;
     }
@@ -304,12 +300,6 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
         HIP_TRY(hipMalloc(&s->trav[x].d_nodes, t.node_bytes.size()));
         HIP_TRY(hipMemcpy(s->trav[x].d_nodes, t.node_bytes.data(), t.node_bytes.size(), hipMemcpyHostToDevice));
     }
-    if (f.gate8.n() > 0) {
-        HIP_TRY(hipMalloc(&s->trav[2].d_nodes, f.gate8.node_bytes.size()));
-        HIP_TRY(hipMemcpy(s->trav[2].d_nodes, f.gate8.node_bytes.data(), f.gate8.node_bytes.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&s->d_leaf_box, f.gate8.leaf_box.size() * sizeof(float)));
-        HIP_TRY(hipMemcpy(s->d_leaf_box, f.gate8.leaf_box.data(), f.gate8.leaf_box.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
     HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_surfaces, s->surfaces.size() * sizeof(SurfaceDev)));
@@ -319,7 +309,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.gate8.node_bytes.size() + f.gate8.leaf_box.size() * sizeof(float) + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -418,24 +408,6 @@ int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t
     return RAYRS_OK;
 }
 
-int rayrs_test_gate8_info(const rayrs_scene* scene, uint32_t out[4]) {
-    if (!scene || !out) return RAYRS_INVALID_ARG;
-    const Gate8Tree& t = scene->flat.gate8;
-    out[0] = t.n(), out[1] = t.root_ref, out[2] = t.depth;
-    std::memcpy(&out[3], &t.bound, 4);
-    return RAYRS_OK;
-}
-
-int rayrs_test_gate8_export(const rayrs_scene* scene, void* nodes, double* box, uint32_t* ref) {
-    if (!scene || !nodes || !box || !ref) return RAYRS_INVALID_ARG;
-    const Gate8Tree& t = scene->flat.gate8;
-    if (t.n() == 0) return RAYRS_OK;
-    std::memcpy(nodes, t.node_bytes.data(), (size_t)t.n() * sizeof(Node8Q));
-    std::memcpy(box, t.box.data(), t.box.size() * sizeof(double));
-    std::memcpy(ref, t.ref.data(), t.ref.size() * sizeof(uint32_t));
-    return RAYRS_OK;
-}
-
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
     if (!scene) return RAYRS_INVALID_ARG;
     const WalkTree& t = scene->flat.gate;
@@ -523,7 +495,7 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
-    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 2u)
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
@@ -611,9 +583,8 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
     const bool gate = exact || s->lab.gate_tree != 0u;
-    const bool gate8 = exact && s->flat.gate8.n() > 0 && s->lab.gate_tree != 2u;  // (gate_tree = 2: the four-slot records)
     const WalkTree& t = s->tree(gate);
-    const rayrs_scene::Walk& w = s->trav[gate8 ? 2 : gate ? 1 : 0];
+    const rayrs_scene::Walk& w = s->trav[gate ? 1 : 0];
     sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
     sc.surfaces = s->d_surfaces;
@@ -622,8 +593,8 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.hdri_h = s->flat.hdri_h;
     sc.hdri_wm1 = (double)(s->flat.hdri_w - 1u);
     sc.hdri_hm1 = (double)(s->flat.hdri_h - 1u);
-    sc.root_ref = gate8 ? s->flat.gate8.root_ref : t.root_ref;
-    sc.stack_depth = gate8 ? s->flat.gate8.depth : (t.depth ? t.depth : 1);
+    sc.root_ref = t.root_ref;
+    sc.stack_depth = t.depth ? t.depth : 1;
     sc.stack_lds = w.stack_lds;
     sc.hot_records = w.hot_records;
     sc.n_surfaces = (uint32_t)s->surfaces.size();
@@ -631,17 +602,6 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
     sc.exact = exact ? 1u : 0u;
-    if (gate8) {  // device_path.h GATE8: the t range rounded outwards (_lo of t0, _hi of t1) and inwards
-        sc.gate8 = 1u;
-        sc.leaf_box = s->d_leaf_box;
-        sc.gate_bound = s->flat.gate8.bound;
-        const float inf = std::numeric_limits<float>::infinity();
-        const float f0 = (float)sc.t0, f1 = (float)sc.t1;
-        sc.t0_lo = (double)f0 > sc.t0 ? std::nextafterf(f0, -inf) : f0;
-        sc.t0_hi = (double)f0 < sc.t0 ? std::nextafterf(f0, inf) : f0;
-        sc.t1_lo = (double)f1 > sc.t1 ? std::nextafterf(f1, -inf) : f1;
-        sc.t1_hi = (double)f1 < sc.t1 ? std::nextafterf(f1, inf) : f1;
-    }
     return sc;
 }
 
@@ -789,7 +749,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->trav[sc.gate8 ? 2 : (exact || lab.gate_tree) ? 1 : 0].blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[(exact || lab.gate_tree) ? 1 : 0].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;

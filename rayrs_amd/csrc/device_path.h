@@ -312,18 +312,8 @@ struct LaneStack {
     }
 };
 
-// Per-ray constants of the conservative f32 box test of the default walk on compact scenes (GATE8 below): per axis
-// 1/d rounded to f32 (0 on an axis the test ignores) and the pair of addends (c_near, c_far) = (-(o/d) - e, e - (o/d)),
-// where e bounds everything f32 rounding can do to (bound - o) / d.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct Slab32 {
-    float vx, vy, vz;
-    f32x2 cx, cy, cz;
-};
-
 struct Trav {
-    V3 inv;      // (dead in GATE8 walks after trav_init: their leaf step divides again in the rare case it needs 1/d)
-    Slab32 s32;  // (dead in all others)
+    V3 inv;
     double best_t;
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
@@ -341,66 +331,12 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// ---- GATE8: the box test of the default walk (EXACT) on compact scenes.
-//
-// By construction the default walk has to test the primitives of exactly those leaf groups whose gating box the
-// reference's own slab test (f64, geometry.rs:458-513) lets the ray into -- and that is ALL it has to get bit-right:
-// which records it reads on the way is its own business, as long as it never skips a record with such a group below
-// it.  So the boxes of a record may be larger than the boxes they stand for (layout.h Node8Q: one byte per bound,
-// rounded outwards) and are tested in f32 with every rounding pushed outwards as well ("may enter" / "surely not"),
-// and the exact f64 test is made once per leaf group that passed, in the leaf step, on the group's own gating box
-// (SceneDev::leaf_box) -- and even there only for the lanes whose f32 interval does not already prove the answer.
-// What this buys is not the arithmetic (profiles/r05_cheap_walks.txt: a cheaper test on four-slot records gained
-// nothing, the walk waits for its records) but the records: one 128-byte line for eight children.
-//
-// The f32 test, per axis (o, v = fl64(1/d) the ray's f64 values; n, f the near and far bound of the box, here
-// origin + q * 2^x with q a byte; all f32 operations rounded to nearest, fma with one rounding):
-//      ok   = |v| < 2^40 and |o| < 2^80                      (else the axis is ignored: v32 = 0, e = +inf)
-//      v32  = fl(v), o32 = fl(o), oi = fl(o32 * v32)
-//      e    = fl(fl(|o32| + B) * fl(|v32| * 2^-20))            B = SceneDev::gate_bound >= every |bound|, 2^-60 <= B < 2^80
-//      a    = v32 * 2^x (exact), bn = fma(origin, v32, fl(-oi - e)), bf = fma(origin, v32, fl(e - oi))
-//      L    = fma(q_near, a, bn)             U = fma(q_far, a, bf)
-//      miss = min(Ux, Uy, Uz, t1_hi) < max(Lx, Ly, Lz, t0_lo)                (NaN operands dropped: maxnum / minnum)
-// Claim: miss implies that the reference's test fails on every box inside the decoded one.  The reference computes
-// T = fl64(fl64(n - o) * v), within 2^-51 |v| (|n| + |o|) of R = (n - o) v.  On an ok axis nothing overflows (every
-// product is below 2^121); with n = origin + q 2^x: L = S (1 + 2^-24 g), S = q a + bn, bn = (origin v32 - oi - e')(1 +
-// 2^-24 g'), |oi - o v| <= 0.76 * 2^-22 |o v|, |n v32 - n v| <= 2^-24 |n v|, so L - T <= -0.9999 e + 1.8 * 2^-22 |v| (B + |o|)
-// < 0, because e >= 0.9999 * 2^-20 |v| (B + |o|): L <= T_near, and U >= T_far in the same way (underflow moves any of
-// this by less than 2^-107, e is at least 2^-80 |v|).  On an ignored axis L is -inf or NaN and U is +inf or NaN: no
-// constraint.  Hence max(L.., t0_lo) <= tmin and min(U.., t1_hi) >= tmax of the reference's test (which drops NaN the
-// same way, and has none on an ok axis), and miss means tmax < tmin there; a box inside has T_near no smaller and T_far
-// no larger (every operation is monotone).  With the exact f32 bounds of a gating box for n, f (no origin, no scale:
-// L = fma(n, v32, c_near)) and the addends swapped the same products bound T from the other side:
-// sure = min(fma(f, v32, c_near).., t1_lo) > max(fma(n, v32, c_far).., t0_hi) implies that the reference's test passes
-// (an ignored axis makes it +inf > ... false, never sure).  The oracle restates all of it in C (fmaf) and the
-// counters of the two must agree ray for ray.
-RR_DEV void slab32_axis(double o, double v, float bound, float& v32, f32x2& c) {
-    const bool ok = __builtin_fabs(v) < 0x1p40 && __builtin_fabs(o) < 0x1p80;  // (not-a-number: not ok)
-    v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * v32;
-    const float e = ok ? (__builtin_fabsf(o32) + bound) * (__builtin_fabsf(v32) * 0x1p-20f) : __builtin_inff();
-    c.x = -oi - e;
-    c.y = e - oi;
-}
-
-template <bool GATE8 = false>
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
-    if (GATE8) {
-        // (no test of the root Node's box: every gating box lies inside it, so a ray that the reference turns away
-        // there (bvh.rs:394) fails every gating box's test as well, and the walk finds that out by itself -- the
-        // kernels that make rays answer such rays themselves, next_sample(), so hardly any arrives here)
-        tv.cur = sc.root_ref;
-        slab32_axis(o.x, tv.inv.x, sc.gate_bound, tv.s32.vx, tv.s32.cx);
-        slab32_axis(o.y, tv.inv.y, sc.gate_bound, tv.s32.vy, tv.s32.cy);
-        slab32_axis(o.z, tv.inv.z, sc.gate_bound, tv.s32.vz, tv.s32.cz);
-    } else {
-        tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
-    }
+    tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
 }
 
 RR_DEV void trav_pop(const LaneStack& stack, Trav& tv) {
@@ -553,152 +489,6 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// ---- GATE8 steps (see trav_init)
-
-// (near, far) of one axis -> (L, U): one packed fma
-RR_DEV f32x2 slab32_lu(uint32_t lo, uint32_t hi, bool neg, float v, f32x2 c) {
-    f32x2 b, vv;
-    b.x = __uint_as_float(neg ? hi : lo), b.y = __uint_as_float(neg ? lo : hi);
-    vv.x = v, vv.y = v;
-    return __builtin_elementwise_fma(b, vv, c);
-}
-
-// the exact f32 bounds of a gating box, addends swapped: bounds of T_near from above and of T_far from below
-RR_DEV bool slab32_surely_enters(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, bool nx,
-                                 bool ny, bool nz, const Slab32& s, float t0_hi, float t1_lo) {
-    const f32x2 x = slab32_lu(x0, x1, nx, s.vx, s.cx.yx);
-    const f32x2 y = slab32_lu(y0, y1, ny, s.vy, s.cy.yx);
-    const f32x2 z = slab32_lu(z0, z1, nz, s.vz, s.cz.yx);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), t0_hi);
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), t1_lo);
-    return hi > lo;
-}
-
-RR_DEV float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyte<k>
-
-// One Node8Q record: every slot the ray may enter is visited, in slot order (nothing is culled, so the order buys
-// nothing: the closest hit is the smallest accepted t, ties by primitive index, in any order).
-template <bool COUNT>
-RR_DEV void trav_interior_step_gate8(const SceneDev& sc, const LaneStack& stack, const HotNodes& hot, Trav& tv,
-                                     WorkCount& wc) {
-    const Slab32& s = tv.s32;
-    const bool nx = s.vx < 0.0f, ny = s.vy < 0.0f, nz = s.vz < 0.0f;
-    const uint32_t rec = tv.cur & 0x3fffffffu;
-    if (COUNT) wc.interior++;
-    uint4 h, qx, qy, qz, ra, rb;
-    if (rec < hot.count) {
-        const uint4* src = hot.lds + rec * HotNodes::stride<true>();
-        h = src[0], qx = src[1], qy = src[2], qz = src[3], ra = src[4], rb = src[5];
-    } else {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
-        h = src[0], qx = src[1], qy = src[2], qz = src[3], ra = src[4], rb = src[5];
-    }
-    uint32_t r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
-    // the record's frame against the ray: a = v32 * 2^x (exact), (bn, bf) = origin * v32 + (c_near, c_far)
-    const float ax = s.vx * __uint_as_float((h.w & 0xffu) << 23);
-    const float ay = s.vy * __uint_as_float(((h.w >> 8) & 0xffu) << 23);
-    const float az = s.vz * __uint_as_float(((h.w >> 16) & 0xffu) << 23);
-    f32x2 t2;
-    t2.x = __uint_as_float(h.x), t2.y = t2.x;
-    const f32x2 bx = __builtin_elementwise_fma(t2, f32x2{s.vx, s.vx}, s.cx);
-    t2.x = __uint_as_float(h.y), t2.y = t2.x;
-    const f32x2 by = __builtin_elementwise_fma(t2, f32x2{s.vy, s.vy}, s.cy);
-    t2.x = __uint_as_float(h.z), t2.y = t2.x;
-    const f32x2 bz = __builtin_elementwise_fma(t2, f32x2{s.vz, s.vz}, s.cz);
-    // the bytes of the near and of the far bounds, slots 0..3 and 4..7 (one select per word serves four slots)
-    const uint32_t xn0 = nx ? qx.z : qx.x, xn1 = nx ? qx.w : qx.y, xf0 = nx ? qx.x : qx.z, xf1 = nx ? qx.y : qx.w;
-    const uint32_t yn0 = ny ? qy.z : qy.x, yn1 = ny ? qy.w : qy.y, yf0 = ny ? qy.x : qy.z, yf1 = ny ? qy.y : qy.w;
-    const uint32_t zn0 = nz ? qz.z : qz.x, zn1 = nz ? qz.w : qz.y, zf0 = nz ? qz.x : qz.z, zf1 = nz ? qz.y : qz.w;
-    const float t0 = sc.t0_lo, t1 = sc.t1_hi;
-    bool hit[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int k = c & 3;
-        f32x2 q;
-        q.x = ubyte_f32(c < 4 ? xn0 : xn1, k), q.y = ubyte_f32(c < 4 ? xf0 : xf1, k);
-        const f32x2 x = __builtin_elementwise_fma(q, f32x2{ax, ax}, bx);
-        q.x = ubyte_f32(c < 4 ? yn0 : yn1, k), q.y = ubyte_f32(c < 4 ? yf0 : yf1, k);
-        const f32x2 y = __builtin_elementwise_fma(q, f32x2{ay, ay}, by);
-        q.x = ubyte_f32(c < 4 ? zn0 : zn1, k), q.y = ubyte_f32(c < 4 ? zf0 : zf1, k);
-        const f32x2 z = __builtin_elementwise_fma(q, f32x2{az, az}, bz);
-        const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), t0);
-        const float hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), t1);
-        hit[c] = !(hi < lo);
-    }
-    int rank[8];  // of a slot the ray may enter: how many such slots come before it
-    int n = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) rank[c] = n, n += (int)hit[c];
-    if (n == 0) {
-        trav_pop(stack, tv);
-        return;
-    }
-    uint32_t first = r[7];
-#pragma unroll
-    for (int c = 6; c >= 0; c--) first = hit[c] ? r[c] : first;
-    tv.cur = first;
-    const int top = tv.sp + n - 1;
-    tv.sp = top;
-    if (__ballot((uint32_t)top > stack.cap) == 0ull) {  // all of the wave's entries are in LDS: no branches
-        // (rank 0 goes to entry `top`, the first free one above the new stack top, never read before it is overwritten;
-        // slots that are not entered go to the lane's spare entry)
-        const int spare = (int)stack.cap;
-#pragma unroll
-        for (int c = 0; c < 8; c++) stack.lds[(hit[c] ? top - rank[c] : spare) * 64] = r[c];
-    } else {
-#pragma unroll
-        for (int c = 1; c < 8; c++)
-            if (hit[c] && rank[c] > 0) stack.put(top - rank[c], r[c]);
-    }
-}
-
-// One leaf group that the f32 test let through: the reference's own test of its gating box decides (made in f64 only
-// for lanes whose f32 interval does not already prove that it passes), then the group's primitives, then pop.
-template <bool COUNT>
-RR_DEV void trav_leaf_step_gate8(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
-    const double tmin = sc.t0, tmax = sc.t1;
-    const uint32_t first = (tv.cur & 0x3fffffffu) >> 2;
-    const uint32_t count = (tv.cur & 3u) + 1u;
-    if (COUNT) wc.leaf_prims = count;
-    const uint4* bp = reinterpret_cast<const uint4*>(sc.leaf_box) + (size_t)first * 2;
-    const uint4 b0 = bp[0], b1 = bp[1];  // xmin xmax ymin ymax | zmin zmax - -
-    PrimRec<true> r = load_prim<true>(sc.prims, first);  // (requested with the box, not behind its test)
-    asm volatile("" : "+v"(r.q[0].x), "+v"(r.q[1].x), "+v"(r.q[2].x));  // (... and kept there)
-    const Slab32& s = tv.s32;
-    const bool nx = s.vx < 0.0f, ny = s.vy < 0.0f, nz = s.vz < 0.0f;
-    bool enter = slab32_surely_enters(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, nx, ny, nz, s, sc.t0_hi, sc.t1_lo);
-    if (__ballot(!enter) != 0ull) {  // (one lane in two hundred stands in the band between: about one wave in six)
-        const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        double entry;
-        const bool gate = slab_f32(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, inv.x < 0.0, inv.y < 0.0, inv.z < 0.0, o, inv,
-                                   tmin, tmax, entry);
-        enter = enter || gate;
-    }
-    // (one loop, the record of primitive k + 1 requested at the end of primitive k's turn; the first with the box)
-    uint32_t k = 0;
-    const uint32_t n = enter ? count : 0u;
-    while (k < n) {
-        const uint32_t p = first + k;
-        if (COUNT) {
-            const uint32_t kind = r.tag() & 3u;
-            if (kind == PRIM_TRIANGLE) wc.tri++;
-            else if (kind == PRIM_SPHERE) wc.sphere++;
-            else wc.plane++;
-        }
-        double t;
-        if (prim_intersect<true>(r, o, d, t) && t > tmin && t < tmax) {   // bvh.rs:406
-            if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {  // bvh.rs:62
-                tv.best_t = t;
-                tv.best_prim = p;
-            }
-        }
-        k++;
-        if (k < n) r = load_prim<true>(sc.prims, first + k);
-    }
-    trav_pop(stack, tv);
-}
-
 // One leaf reference: its 1..4 primitives in DFS order, then pop.
 template <bool COMPACT, bool COUNT>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
@@ -732,18 +522,8 @@ template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
-    const HotNodes hot{nullptr, 0u};
-    if (COMPACT && EXACT && sc.gate8) {  // the default walk on compact scenes: eight-slot records
-        trav_init<true>(sc, o, d, tv);
-        while (tv.cur != TRAV_DONE) {
-            if (trav_at_interior(tv)) trav_interior_step_gate8<COUNT>(sc, stack, hot, tv, wc);
-            else trav_leaf_step_gate8<COUNT>(sc, o, d, stack, tv, wc);
-        }
-        t_hit = tv.best_t;
-        prim_hit = tv.best_prim;
-        return tv.best_prim != 0xffffffffu;
-    }
     trav_init(sc, o, d, tv);
+    const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
             trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);

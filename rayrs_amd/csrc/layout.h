@@ -60,20 +60,6 @@ struct Node4F64 {  // 256 B
     uint32_t ref[4];
     uint32_t pad[12];
 };
-// The default walk on compact scenes reads EIGHT-slot records with quantised boxes (scene_host.cpp build_gate8,
-// device_path.h GATE8): a slot's box is origin + q * 2^e per axis with one byte q per bound, rounded outwards, so a
-// record is one 128-byte line for eight children.  Which records a ray reads need not be the reference's decision --
-// only which leaf groups' primitives it tests, and that is decided by the reference's own test on the group's exact
-// gating box (SceneDev::leaf_box) -- so a box that is a little too large costs a visit, never the answer.
-struct Node8Q {  // 128 B
-    float origin[3];
-    uint8_t exp[3];      // scale of axis k = the f32 with bits exp[k] << 23 = 2^(exp[k] - 127)
-    uint8_t pad0;
-    uint8_t q[3][2][8];  // [axis][0 = low, 1 = high bound][slot]; an unused slot: low 255, high 0
-    uint32_t ref[8];     // as Node4F32::ref; an unused slot refers to the tree's first leaf group (harmless: build_gate8)
-    uint32_t pad1[8];
-};
-static_assert(sizeof(Node8Q) == 128, "Node8Q");
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
@@ -121,12 +107,6 @@ struct SceneDev {
     // the default walk (rayrs_render_params.fast_traversal == 0): nothing is culled by the closest hit so far, as BvhTree::intersect
     // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
     uint32_t exact, pad1;
-    // the default walk on compact scenes (device_path.h GATE8; nodes = Node8Q records then): the gating box of the leaf
-    // group that starts at primitive p, as 8 f32 (xmin xmax ymin ymax zmin zmax - -) at leaf_box + 8 p; a bound on every
-    // |decoded box bound| of the tree; the scene's t range rounded outwards (_lo, _hi of t0, t1) and inwards
-    const float* leaf_box;
-    float gate_bound, t0_lo, t1_hi, t0_hi, t1_lo;
-    uint32_t gate8;  // 1 = nodes are Node8Q records
 };
 
 struct CameraDev {

@@ -34,9 +34,7 @@ typedef struct {
                                (a one-device communicator: the call path of a multi-GPU node on a one-GPU box) */
     uint32_t gate_tree;     /* 1 = the fast walk (with closest-hit culling) over the gate tree instead of the tree
                                of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
-                               profiles/r04_tight_leaves.txt;
-                               2 = the default walk on the four-slot gate records also where a compact scene has the
-                               eight-slot ones (same-box A/B of the two) */
+                               profiles/r04_tight_leaves.txt */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

@@ -38,13 +38,6 @@ int rayrs_test_material(int device, const rayrs_material* mat, const double* nor
                         uint32_t* draws);
 /* Scene::background for n directions. */
 int rayrs_test_background(rayrs_scene* scene, const double* dir, uint64_t n, double* rgb);
-/* The records the default walk reads on a compact scene (scene_host.cpp build of FlatScene::gate8; host-only scenes
- * have them too).  info: out[0] = number of eight-slot records (0: the scene has none and the walk reads the gate
- * tree), [1] = root reference, [2] = stack entries, [3] = the bits of the f32 bound of the box test's error term.
- * export: nodes = n * 128 bytes (layout.h Node8Q), box = n * 48 doubles and ref = n * 8: the slots' exact boxes and
- * references (kind 3 = unused).  The oracle restates the walk on these (orc_set_gate8). */
-int rayrs_test_gate8_info(const rayrs_scene* scene, uint32_t out[4]);
-int rayrs_test_gate8_export(const rayrs_scene* scene, void* nodes, double* box, uint32_t* ref);
 
 #ifdef __cplusplus
 }

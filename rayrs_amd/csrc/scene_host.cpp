@@ -12,7 +12,6 @@
 #include "scene_host.hpp"
 
 #include <algorithm>
-#include <cfenv>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -598,233 +597,6 @@ uint32_t emit_wide(WalkTree& f, const WideCollapse& wc, int32_t n, uint32_t* sta
     return (REF_INTERIOR << 30) | rec;
 }
 
-// ---- the eight-slot tree of the default walk on compact scenes (layout.h Node8Q)
-//
-// The same dynamic programme as WideCollapse with eight slots to spend, over the same binary tree.
-struct WideCollapse8 {
-    static constexpr int W = 8;
-    const std::vector<WalkNode>& nodes;
-    std::vector<float> cost;    // [n * W + (j - 1)]: subtree n in at most j slots
-    std::vector<uint8_t> used;  // slots it actually takes (1 = a record of its own)
-    std::vector<uint8_t> argk;  // of `used` slots, how many go to the left child
-
-    explicit WideCollapse8(const std::vector<WalkNode>& nd) : nodes(nd) {
-        const size_t n = nd.size();
-        cost.assign(n * W, 0.f), used.assign(n * W, 1), argk.assign(n * W, 0);
-        for (const int32_t ni : post_order(nd)) {
-            const size_t i = (size_t)ni;
-            const WalkNode& w = nd[i];
-            if (w.left < 0) continue;  // a group: no record, no cost
-            float d[W + 1];
-            uint8_t dk[W + 1];
-            for (int j = 2; j <= W; j++) {
-                d[j] = std::numeric_limits<float>::infinity(), dk[j] = 1;
-                for (int k = 1; k < j; k++) {
-                    const float c = cost[(size_t)w.left * W + (k - 1)] + cost[(size_t)w.right * W + (j - k - 1)];
-                    if (c < d[j]) d[j] = c, dk[j] = (uint8_t)k;
-                }
-            }
-            cost[i * W] = (float)box_area(w.box) + d[W];
-            used[i * W] = 1, argk[i * W] = dk[W];
-            for (int j = 2; j <= W; j++) {
-                if (d[j] < cost[i * W + (j - 2)]) cost[i * W + (j - 1)] = d[j], used[i * W + (j - 1)] = (uint8_t)j, argk[i * W + (j - 1)] = dk[j];
-                else cost[i * W + (j - 1)] = cost[i * W + (j - 2)], used[i * W + (j - 1)] = used[i * W + (j - 2)], argk[i * W + (j - 1)] = argk[i * W + (j - 2)];
-            }
-        }
-    }
-
-    void expand(int32_t n, int j, int32_t* slots, int& ns) const {
-        const WalkNode& w = nodes[n];
-        if (w.left < 0 || used[(size_t)n * W + (j - 1)] == 1) {
-            slots[ns++] = n;
-            return;
-        }
-        const int u = used[(size_t)n * W + (j - 1)], k = argk[(size_t)n * W + (j - 1)];
-        expand(w.left, k, slots, ns);
-        expand(w.right, u - k, slots, ns);
-    }
-};
-
-uint32_t emit_wide8(Gate8Tree& f, const WideCollapse8& wc, int32_t n, uint32_t* stack_need) {
-    const std::vector<WalkNode>& nodes = wc.nodes;
-    const uint32_t rec = f.n();
-    f.ref.resize(f.ref.size() + 8, REF_NONE << 30);
-    f.box.resize(f.box.size() + 48, 0.0);
-    int32_t slots[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    int ns = 0;
-    const int k = wc.argk[(size_t)n * 8];
-    wc.expand(nodes[n].left, k, slots, ns);
-    wc.expand(nodes[n].right, 8 - k, slots, ns);
-    uint32_t below = 0;
-    for (int i = 0; i < ns; i++) {
-        const WalkNode& c = nodes[slots[i]];
-        uint32_t ref = c.ref;
-        if (c.left >= 0) {
-            uint32_t need = 0;
-            ref = emit_wide8(f, wc, slots[i], &need);
-            if (need > below) below = need;
-        }
-        f.ref[(size_t)rec * 8 + i] = ref;
-        for (int q = 0; q < 6; q++) f.box[((size_t)rec * 8 + i) * 6 + q] = c.box[q];
-    }
-    *stack_need = (uint32_t)(ns - 1) + below;
-    return (REF_INTERIOR << 30) | rec;
-}
-
-// (front_largest for eight slots)
-void front_largest8(Gate8Tree& f) {
-    const uint32_t n = f.n();
-    const uint32_t k = n < WIDE_FRONT ? n : WIDE_FRONT;
-    if (k == 0) return;
-    std::vector<double> area(n, 0.0);
-    for (uint32_t r = 0; r < n; r++) {
-        double b[6] = {0, 0, 0, 0, 0, 0};
-        bool any = false;
-        for (int c = 0; c < 8; c++) {
-            if ((f.ref[(size_t)r * 8 + c] >> 30) == REF_NONE) continue;
-            const double* cb = &f.box[((size_t)r * 8 + c) * 6];
-            if (!any) for (int q = 0; q < 6; q++) b[q] = cb[q];
-            else box_merge(b, cb);
-            any = true;
-        }
-        area[r] = any ? box_area(b) : 0.0;
-    }
-    std::vector<uint32_t> order(n);
-    for (uint32_t r = 0; r < n; r++) order[r] = r;
-    auto larger = [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
-    std::partial_sort(order.begin(), order.begin() + k, order.end(), larger);
-    std::vector<uint8_t> in_front(n, 0);
-    for (uint32_t i = 0; i < k; i++) in_front[order[i]] = 1;
-    uint32_t at = k;
-    for (uint32_t r = 0; r < n; r++)
-        if (!in_front[r]) order[at++] = r;  // order[new] = old
-    std::vector<uint32_t> new_of(n);
-    for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
-    std::vector<double> box(f.box.size());
-    std::vector<uint32_t> ref(f.ref.size());
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t old = order[i];
-        for (int c = 0; c < 8; c++) {
-            uint32_t r = f.ref[(size_t)old * 8 + c];
-            if ((r >> 30) == REF_INTERIOR) r = (REF_INTERIOR << 30) | new_of[r & 0x3fffffffu];
-            ref[(size_t)i * 8 + c] = r;
-        }
-        for (int c = 0; c < 48; c++) box[(size_t)i * 48 + c] = f.box[(size_t)old * 48 + c];
-    }
-    f.box.swap(box);
-    f.ref.swap(ref);
-    f.root_ref = (REF_INTERIOR << 30) | new_of[f.root_ref & 0x3fffffffu];
-}
-
-// a + b rounded towards +infinity / -infinity (volatile, not inlined: the compiler must not move the additions across the
-// changes of the rounding mode)
-__attribute__((noinline)) double sum_up(double a, double b) {
-    std::fesetround(FE_UPWARD);
-    volatile double x = a, y = b;
-    volatile double r = x + y;
-    std::fesetround(FE_TONEAREST);
-    return r;
-}
-__attribute__((noinline)) double sum_down(double a, double b) {
-    std::fesetround(FE_DOWNWARD);
-    volatile double x = a, y = b;
-    volatile double r = x + y;
-    std::fesetround(FE_TONEAREST);
-    return r;
-}
-
-// The records as the kernel reads them.  Per record and axis: origin = the smallest low bound (f32-exact like every
-// bound of a compact scene), scale 2^e the smallest power of two with 255 * 2^e >= the record's extent, and per slot
-// one byte per bound, the low one rounded down, the high one up -- checked with the sum origin + q * 2^e rounded
-// towards the inside, so that the decoded box (an exact real number per bound) contains the slot's box whatever the
-// magnitudes.  Returns false if a scale does not fit the format (the scene then keeps the four-slot gate tree).
-bool quantise8(Gate8Tree& t, const double* root_box, size_t n_prims) {
-    const uint32_t n = t.n();
-    t.node_bytes.assign((size_t)std::max(n, 1u) * sizeof(Node8Q), 0);
-    Node8Q* nodes = reinterpret_cast<Node8Q*>(t.node_bytes.data());
-    t.leaf_box.assign(n_prims * 8, 0.0f);
-    double bound = 0x1p-60;
-    for (int k = 0; k < 6; k++) bound = std::max(bound, std::fabs(root_box[k]));
-    uint32_t first_leaf = REF_NONE << 30;
-    for (size_t s = 0; s < t.ref.size() && (first_leaf >> 30) == REF_NONE; s++)
-        if ((t.ref[s] >> 30) == REF_RANGE) first_leaf = t.ref[s];
-    bool ok = true;
-    for (uint32_t r = 0; r < n && ok; r++) {
-        Node8Q& nd = nodes[r];
-        for (int a = 0; a < 3 && ok; a++) {
-            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-            for (int c = 0; c < 8; c++) {
-                if ((t.ref[(size_t)r * 8 + c] >> 30) == REF_NONE) continue;
-                const double* b = &t.box[((size_t)r * 8 + c) * 6];
-                lo = std::min(lo, b[2 * a]), hi = std::max(hi, b[2 * a + 1]);
-            }
-            if (!(lo <= hi) || !f32_exact(lo)) {  // (a bound that is not a number)
-                ok = false;
-                break;
-            }
-            nd.origin[a] = (float)lo;
-            // smallest e with 255 * 2^e >= hi - lo (rounded up), within the normal f32 exponents
-            int e = -126;
-            {
-                const double ext = sum_up(hi, -lo);
-                if (ext > 0.0) {
-                    int x;
-                    (void)std::frexp(ext / 255.0, &x);  // ext / 255 < 2^x
-                    e = std::max(x, -126);
-                }
-            }
-            for (;; e++) {
-                if (e > 127) {
-                    ok = false;
-                    break;
-                }
-                const double s = std::ldexp(1.0, e);
-                bool fits = true;
-                for (int c = 0; c < 8 && fits; c++) {
-                    if ((t.ref[(size_t)r * 8 + c] >> 30) == REF_NONE) {
-                        nd.q[a][0][c] = 255, nd.q[a][1][c] = 0;
-                        continue;
-                    }
-                    const double* b = &t.box[((size_t)r * 8 + c) * 6];
-                    double ql = std::floor((b[2 * a] - lo) / s), qh = std::ceil((b[2 * a + 1] - lo) / s);
-                    ql = std::min(std::max(ql, 0.0), 255.0), qh = std::min(std::max(qh, 0.0), 255.0);
-                    // decoded low bound <= the box's, decoded high bound >= the box's: the sums rounded towards the inside
-                    // (q * s is exact: an integer below 256 times a power of two)
-                    while (ql > 0.0 && sum_up(lo, ql * s) > b[2 * a]) ql -= 1.0;
-                    const bool lo_ok = sum_up(lo, ql * s) <= b[2 * a];
-                    while (qh < 255.0 && sum_down(lo, qh * s) < b[2 * a + 1]) qh += 1.0;
-                    const bool hi_ok = sum_down(lo, qh * s) >= b[2 * a + 1];
-                    if (!lo_ok || !hi_ok) fits = false;
-                    nd.q[a][0][c] = (uint8_t)ql, nd.q[a][1][c] = (uint8_t)qh;
-                }
-                if (fits) break;
-            }
-            if (!ok) break;
-            nd.exp[a] = (uint8_t)(e + 127);
-            bound = std::max(bound, std::fabs(lo) + 255.0 * std::ldexp(1.0, e));
-        }
-        for (int c = 0; c < 8; c++) {
-            const uint32_t ref = t.ref[(size_t)r * 8 + c];
-            // (an unused slot's inverted box cannot be missed for sure -- a record that is flat on an axis decodes
-            // both bounds to the origin there -- so such a slot refers to the tree's first leaf group: the group's own
-            // gating box decides, and visiting a group twice changes nothing)
-            nd.ref[c] = (ref >> 30) == REF_NONE ? first_leaf : ref;
-            if ((ref >> 30) != REF_RANGE) continue;
-            const size_t first = (ref & 0x3fffffffu) >> 2;
-            for (int k = 0; k < 6; k++) {
-                const double v = t.box[((size_t)r * 8 + c) * 6 + k];
-                t.leaf_box[first * 8 + k] = (float)v;
-                bound = std::max(bound, std::fabs(v));
-            }
-        }
-    }
-    if (!ok || !(bound < 0x1p80)) return false;
-    float bf = (float)bound;
-    if ((double)bf < bound) bf = std::nextafterf(bf, std::numeric_limits<float>::infinity());
-    t.bound = bf;
-    return true;
-}
-
 // The fast walk's tree's leaf slots: every primitive alone behind a box of its own -- its bounding box (the one
 // Bvh::build computes for it, geometry.rs bbox) widened on every side by LEAF_MARGIN of its largest extent,
 // rounded outwards to f32 and clipped to its group's gating box.
@@ -870,7 +642,7 @@ void split_groups(const std::vector<WalkGroup>& groups, const std::vector<Aabb>&
     }
 }
 
-void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t, Gate8Tree* t8 = nullptr) {
+void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
     WalkBuilder b(leaves);
     b.build();
     t.box.reserve(leaves.size() * 12);
@@ -878,25 +650,19 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t, Gate8Tre
     const WideCollapse wc(b.nodes);
     t.root_ref = emit_wide(t, wc, 0, &t.depth);
     front_largest(t);
-    if (t8) {  // the same binary tree, eight slots to a record
-        const WideCollapse8 wc8(b.nodes);
-        t8->root_ref = emit_wide8(*t8, wc8, 0, &t8->depth);
-        front_largest8(*t8);
-    }
 }
 
 // prim_box[p]: the reference's bounding box of the object behind primitive record p
 void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
     f.walk = WalkTree();
     f.gate = WalkTree();
-    f.gate8 = Gate8Tree();
     if ((f.root_ref >> 30) != REF_INTERIOR) {  // one bottom Node: its box is root_box, tested by trav_init
         f.walk.root_ref = f.gate.root_ref = f.root_ref;
         return;
     }
     std::vector<WalkGroup> groups;
     collect_groups(f, f.root_ref & 0x3fffffffu, f.root_box, groups);
-    build_tree_over(groups, f.gate, &f.gate8);
+    build_tree_over(groups, f.gate);
     std::vector<WalkGroup> singles;
     split_groups(groups, prim_box, singles);
     build_tree_over(singles, f.walk);
@@ -995,8 +761,6 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
         if (compact) fill_nodes<Node4F32, float>(*t);
         else fill_nodes<Node4F64, double>(*t);
     }
-    // the default walk's eight-slot records (compact scenes; the four-slot gate tree serves where they cannot be made)
-    if (!compact || f.gate8.n() == 0 || !quantise8(f.gate8, f.root_box, n)) f.gate8 = Gate8Tree();
 
     // ---- primitive records in DFS order
     const uint32_t dw = compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL;

@@ -54,19 +54,6 @@ struct WalkTree {
     uint32_t n() const { return (uint32_t)(ref.size() / 4); }
 };
 
-// The tree of the default walk on compact scenes: eight-slot records with quantised boxes (layout.h Node8Q) over the
-// same leaf groups as the gate tree, the groups' exact gating boxes beside them.
-struct Gate8Tree {
-    std::vector<double> box;    // n * 48: the slots' exact boxes (what was quantised)
-    std::vector<uint32_t> ref;  // n * 8 (REF_NONE for an unused slot)
-    uint32_t root_ref = 0;
-    uint32_t depth = 0;         // stack entries the traversal can need
-    std::vector<uint8_t> node_bytes;  // n Node8Q records
-    std::vector<float> leaf_box;      // per primitive record p 8 floats: the gating box of the group that starts at p
-    float bound = 0.0f;               // >= every |decoded bound| and every |leaf box bound|, at least 2^-60
-    uint32_t n() const { return (uint32_t)(ref.size() / 8); }
-};
-
 struct FlatScene {
     // logical tree (always f64, used for export and as the source of the device records)
     std::vector<double> child_box;  // n_interior * 12
@@ -79,7 +66,6 @@ struct FlatScene {
     //         reaches; the default walk's tree, and where the local-pool route's gates come from;
     //   walk  single primitives behind their own widened boxes inside the gating box (rayrs_render_params.fast_traversal).
     WalkTree walk, gate;
-    Gate8Tree gate8;  // compact scenes with more than one bottom Node only (else empty: the default walk reads `gate`)
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)

@@ -40,8 +40,7 @@ struct rayrs_scene {
         uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
         uint32_t hot_records = 0;    // leading records kept in LDS
     };
-    Walk trav[3];  // [2]: FlatScene::gate8, the default walk's records on compact scenes (none: d_nodes stays null)
-    float* d_leaf_box = nullptr;  // FlatScene::gate8.leaf_box
+    Walk trav[2];
     const rayrs::WalkTree& tree(bool exact) const { return exact ? flat.gate : flat.walk; }
     uint64_t device_bytes = 0;
     // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,

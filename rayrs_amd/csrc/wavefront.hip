@@ -430,8 +430,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-// GATE8: the default walk on a compact scene's eight-slot records (device_path.h; SceneDev::gate8)
-template <bool COMPACT, bool COUNT, bool EXACT, bool GATE8 = false>
+template <bool COMPACT, bool COUNT, bool EXACT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -525,8 +524,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
-                    if (GATE8) trav_init<true>(sc, o, d, tv);
-                    else trav_init(sc, o, d, tv);
+                    trav_init(sc, o, d, tv);
                     if (tv.cur == TRAV_DONE)
                         pending = true;  // missed the root box: retired at the next refill
                     else
@@ -548,15 +546,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- leaf phase: every lane standing on a leaf tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                if (GATE8) {
-                    // (the direction is read again from the slot, with the group's box and first primitive: six registers
-                    // that the interior steps, which do not use it, would otherwise push into scratch)
-                    const RaySlot* rs = ray_slot(wf, slot);
-                    const V3 ld = mk(rs->d[0], rs->d[1], rs->d[2]);
-                    trav_leaf_step_gate8<COUNT>(sc, o, ld, stack, tv, wc);
-                } else {
-                    trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-                }
+                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -567,8 +557,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                if (GATE8) trav_interior_step_gate8<COUNT>(sc, stack, hot, tv, wc);
-                else trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
+                trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {
@@ -887,8 +876,7 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (COMPACT && sc.exact && sc.gate8) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, COMPACT>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    else if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
@@ -907,10 +895,7 @@ static hipError_t trav_set_lds(uint32_t lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess || !COMPACT) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true, COMPACT>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 

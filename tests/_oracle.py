@@ -93,7 +93,6 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
-    L.orc_set_gate8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, vp, vp, vp]
     L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.orc_vec_op.restype = None
     L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
@@ -224,13 +223,6 @@ class OracleScene:
         closest-hit culling (rayrs_render_params.fast_traversal)."""
         self.use_walk_tree(product_scene, gate=not fast)
         self._walk_margin = 2.0 ** -10 if fast else float("inf")
-        g8 = None if fast else product_scene.export_gate8()
-        if g8 is not None and g8["n"] > 0:
-            # a compact scene: eight-slot records with quantised boxes tested in f32, roundings pushed outwards; a group's
-            # own gating box exactly before its primitives (device_path.h GATE8) -- the same primitives, other records
-            nodes, box, ref = (np.ascontiguousarray(g8[k]) for k in ("nodes", "box", "ref"))
-            assert self._L.orc_set_gate8(self._h, g8["n"], g8["root_ref"], g8["depth"], g8["bound"], nodes.ctypes.data,
-                                         box.ctypes.data, ref.ctypes.data) == 0
         return self
 
     def _with_margin(self, traversal, call):
