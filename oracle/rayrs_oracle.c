@@ -863,8 +863,6 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
-    int gate32;         /* orc_set_gate32: interior slots are tested in f32 (device_path.h GATE32) */
-    float gate_bound;   /* ... with this bound on every |box bound| */
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -1313,28 +1311,6 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
-    s->gate32 = 0;
-    return 0;
-}
-
-/* The default walk of the product on compact records (device_path.h GATE32): the box of an INTERIOR slot is tested in
- * f32 with every rounding pushed outwards (may enter / surely not); a leaf slot's by the reference's own f64 test -- the
- * product shortcuts that test where its f32 interval already settles it, the oracle does not, so a hole in the
- * product's argument would show as a difference in the counters.  The bound of the f32 test's error term is computed
- * as scene_host.cpp computes it: the largest |bound| among the root box and the used slots, at least 2^-60, rounded
- * up to f32. */
-int orc_set_gate32(orc_scene* s, int on) {
-    if (!s || !s->built || !s->have_wide) return -1;
-    double bound = 0x1p-60;
-    for (int k = 0; k < 6; k++) bound = fmax(bound, fabs(s->finfo.root_box[k]));
-    for (size_t r = 0; r < (size_t)s->finfo.n_wide * 4; r++) {
-        if ((s->wide_ref[r] >> 30) == REF_KIND_NONE) continue;
-        for (int k = 0; k < 6; k++) bound = fmax(bound, fabs(s->wide_box[r * 6 + k]));
-    }
-    float bf = (float)bound;
-    if ((double)bf < bound) bf = nextafterf(bf, INFINITY);
-    s->gate_bound = bf;
-    s->gate32 = on ? 1 : 0;
     return 0;
 }
 
@@ -1575,41 +1551,6 @@ void orc_set_visit_histogram(uint64_t* hist) { g_visit_hist = hist; }
  * slot), the rest pushed farthest first.  Every leaf slot is a group of the reference's tree
  * behind its gating box, so the primitives tested are a subset of those the reference reaches
  * that contains the closest hit. */
-/* ---- device_path.h GATE32, operation for operation (f32, round to nearest, fmaf with one rounding) */
-typedef struct {
-    float v[3], cn[3], cf[3];
-} slab32_t;
-
-static void slab32_axis(double o, double v, float bound, float* v32, float* cn, float* cf) {
-    const int ok = fabs(v) < 0x1p40 && fabs(o) < 0x1p80;
-    *v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * *v32;
-    const float e = ok ? (fabsf(o32) + bound) * (fabsf(*v32) * 0x1p-20f) : INFINITY;
-    *cn = -oi - e;
-    *cf = e - oi;
-}
-
-static int slab32_may_enter(const double* bx, const slab32_t* s, float t0_lo, float t1_hi) {
-    float lo = t0_lo, hi = t1_hi;
-    float l[3], u[3];
-    for (int a = 0; a < 3; a++) {
-        const int neg = s->v[a] < 0.0f;
-        const float n = (float)bx[2 * a + (neg ? 1 : 0)], f = (float)bx[2 * a + (neg ? 0 : 1)];
-        l[a] = fmaf(n, s->v[a], s->cn[a]);
-        u[a] = fmaf(f, s->v[a], s->cf[a]);
-    }
-    lo = fmaxf(fmaxf(fmaxf(l[0], l[1]), l[2]), lo);
-    hi = fminf(fminf(fminf(u[0], u[1]), u[2]), hi);
-    return !(hi < lo);
-}
-
-static void f32_around(double x, float* below, float* above) {
-    const float f = (float)x;
-    *below = (double)f > x ? nextafterf(f, -INFINITY) : f;
-    *above = (double)f < x ? nextafterf(f, INFINITY) : f;
-}
-
 static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tmax, trav_counters* cnt) {
     if (!s->have_wide) {
         fprintf(stderr, "oracle: traversal 2 needs the product's walk tree (orc_set_wide)\n");
@@ -1621,15 +1562,6 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     v3 inv = V(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
     double entry;
     if (!aabb_intersect_entry(s->finfo.root_box, ray, inv, tmin, tmax, &entry)) return best;
-    slab32_t sl;
-    float t0_lo = 0.0f, t0_hi, t1_lo, t1_hi = 0.0f;
-    if (s->gate32) {
-        slab32_axis(ray.o.x, inv.x, s->gate_bound, &sl.v[0], &sl.cn[0], &sl.cf[0]);
-        slab32_axis(ray.o.y, inv.y, s->gate_bound, &sl.v[1], &sl.cn[1], &sl.cf[1]);
-        slab32_axis(ray.o.z, inv.z, s->gate_bound, &sl.v[2], &sl.cn[2], &sl.cf[2]);
-        f32_around(tmin, &t0_lo, &t0_hi);
-        f32_around(tmax, &t1_lo, &t1_hi);
-    }
     uint32_t stack_fixed[512];
     uint32_t* stack = stack_fixed;
     if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
@@ -1653,8 +1585,6 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
                 if (kind == REF_KIND_SINGLE) {
                     hit[c] = 1;
                     ent[c] = tmin;
-                } else if (s->gate32 && kind == REF_KIND_INTERIOR) {
-                    hit[c] = slab32_may_enter(s->wide_box + ((size_t)rec * 4 + c) * 6, &sl, t0_lo, t1_hi);
                 } else if (kind != REF_KIND_NONE) {
                     hit[c] = aabb_intersect_entry(s->wide_box + ((size_t)rec * 4 + c) * 6, ray, inv, tmin, tmax, &ent[c]);
                     if (hit[c] && ent[c] > best_t * TRAV_CULL_MARGIN) hit[c] = 0;

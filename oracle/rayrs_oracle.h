@@ -205,9 +205,6 @@ int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide
  * traversal 2 walks them.  The oracle does not build that tree itself. */
 int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
                  const uint32_t* wide_ref);
-/* After orc_set_wide with the product's gate tree of a compact scene: traversal 2 tests the boxes of INTERIOR slots as the
- * product's default walk does (f32, roundings pushed outwards), those of leaf slots exactly. */
-int orc_set_gate32(orc_scene* s, int on);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

@@ -5,7 +5,6 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
-#include <limits>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -603,17 +602,6 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.t0 = s->flat.t0;
     sc.t1 = s->flat.t1;
     sc.exact = exact ? 1u : 0u;
-    {   // device_path.h GATE32: the t range rounded outwards to f32, and what the two roundings may cost a "sure"
-        const float inf = std::numeric_limits<float>::infinity();
-        const float f0 = (float)sc.t0, f1 = (float)sc.t1;
-        sc.t0_lo = (double)f0 > sc.t0 ? std::nextafterf(f0, -inf) : f0;
-        sc.t1_hi = (double)f1 < sc.t1 ? std::nextafterf(f1, inf) : f1;
-        sc.gate_bound = s->flat.gate_bound;
-        const double worst = std::max(sc.t0 - (double)sc.t0_lo, (double)sc.t1_hi - sc.t1);  // (inf - finite = inf: never sure)
-        float m = (float)(2.5 * worst);
-        if ((double)m < 2.5 * worst) m = std::nextafterf(m, inf);
-        sc.gate_sure_min = m;
-    }
     return sc;
 }
 

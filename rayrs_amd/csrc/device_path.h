@@ -312,20 +312,8 @@ struct LaneStack {
     }
 };
 
-// Per-ray constants of the conservative f32 box test of the default walk on compact records (GATE32 below): per axis
-// 1/d rounded to f32 (0 on an axis the test ignores) and the pair of addends (c_near, c_far) = (-(o/d) - e, e - (o/d)),
-// where e bounds everything f32 rounding can do to (bound - o) / d; `sure`: how much wider than nothing the f32 interval
-// of a box must be for the reference's f64 test to pass for certain (+inf if an axis is ignored).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct Slab32 {
-    float vx, vy, vz;
-    f32x2 cx, cy, cz;
-    float sure;
-};
-
 struct Trav {
-    V3 inv;      // (dead in GATE32 walks after trav_init: the rare lane that needs 1/d there divides again)
-    Slab32 s32;  // (dead in all others)
+    V3 inv;
     double best_t;
     uint32_t best_prim;  // 0xffffffff = no hit yet
     uint32_t cur;        // reference to visit next, TRAV_DONE when finished
@@ -343,65 +331,12 @@ RR_DEV bool root_box_hit(const SceneDev& sc, V3 o, V3 inv) {
                 entry);
 }
 
-// ---- GATE32: the box test of the default walk (EXACT) on compact records.
-//
-// By construction the default walk has to test the primitives of exactly those leaf groups whose gating box the
-// reference's own slab test (f64, geometry.rs:458-513) lets the ray into -- and that is ALL it has to get bit-right:
-// which records it reads on the way is its own business, as long as it never skips a record with such a group below
-// it.  So the four boxes of a record are first tested in f32 with every rounding pushed outwards, at a third of the
-// instructions of the exact test and in packed arithmetic.  For an INTERIOR slot "may enter" is all that is asked.
-// For a LEAF slot the same f32 interval usually settles the reference's answer as well: if it is empty the reference's
-// test fails, if it is wider than the rounding can account for (`sure`) the reference's test passes; only for the
-// lanes in between -- about one leaf slot in a hundred -- is the f64 test made, in a block of the step that most waves skip.
-// A leaf group is therefore visited iff the reference's test of its gating box passes, and the leaf step is unchanged.
-//
-// The f32 test, per axis (o, v = fl64(1/d) the ray's f64 values; n, f the near and far bound of the box, f32-exact;
-// all f32 operations rounded to nearest, fma with one rounding):
-//      ok   = |v| < 2^40 and |o| < 2^80                      (else the axis is ignored: v32 = 0, e = +inf)
-//      v32  = fl(v), o32 = fl(o), oi = fl(o32 * v32)
-//      e    = fl(fl(|o32| + B) * fl(|v32| * 2^-20))            B = SceneDev::gate_bound >= every |bound|, 2^-60 <= B < 2^80
-//      L    = fma(n, v32, fl(-oi - e))       U = fma(f, v32, fl(e - oi))
-//      lo   = max(Lx, Ly, Lz, t0_lo), hi = min(Ux, Uy, Uz, t1_hi)      (NaN operands dropped: maxnum / minnum)
-//      miss = hi < lo;      sure = fl(hi - lo) > E,  E = max(3 e_max, 2.5 max(t0 - t0_lo, t1_hi - t1))
-// Claim 1: miss implies that the reference's test fails on this box and on every box inside it.  The reference computes
-// T = fl64(fl64(n - o) * v), within 2^-51 |v| (|n| + |o|) of R = (n - o) v.  On an ok axis nothing overflows (every
-// product is below 2^121) and L = S (1 + 2^-24 g) with S = n v32 + fl(-oi - e), |oi - o v| <= 0.76 * 2^-22 |o v|,
-// |n v32 - n v| <= 2^-24 |n v|, so S - R lies within 0.253 e of -e (e >= 0.9999 * 2^-20 |v| (B + |o|)) and 2^-24 |S| <= 0.063 e:
-// L <= T_near <= L + 1.4 e, and likewise U - 1.4 e <= T_far <= U (underflow moves any of this by less than 2^-107,
-// e is at least 2^-80 |v|).  On an ignored axis L is -inf or NaN and U is +inf or NaN: no
-// constraint.  Hence lo <= tmin and hi >= tmax of the reference's test (which drops NaN the same way, and has none on
-// an ok axis), and miss means tmax < tmin there; a box inside this one has T_near no smaller and T_far no larger (every
-// operation above is monotone), so it fails as well.
-// Claim 2: sure implies that the reference's test passes on this box.  With all three axes ok (else E = +inf):
-// tmin <= lo + max(1.4 e_max, t0 - t0_lo) and tmax >= hi - max(1.4 e_max, t1_hi - t1), so tmax > tmin follows from
-// hi - lo > 2 max(1.4 e_max, the two roundings of the t range), which fl(hi - lo) > E guarantees with room for the
-// subtraction's own rounding.
-// The oracle does not restate the shortcut: it makes the reference's test on every leaf slot and the f32 test on
-// interior slots, and the counters of the two must agree ray for ray (so a hole in either claim would show).
-RR_DEV float slab32_axis(double o, double v, float bound, float& v32, f32x2& c) {
-    const bool ok = __builtin_fabs(v) < 0x1p40 && __builtin_fabs(o) < 0x1p80;  // (not-a-number: not ok)
-    v32 = ok ? (float)v : 0.0f;
-    const float o32 = ok ? (float)o : 0.0f;
-    const float oi = o32 * v32;
-    const float e = ok ? (__builtin_fabsf(o32) + bound) * (__builtin_fabsf(v32) * 0x1p-20f) : __builtin_inff();
-    c.x = -oi - e;
-    c.y = e - oi;
-    return e;
-}
-
-template <bool GATE32 = false>
 RR_DEV void trav_init(const SceneDev& sc, V3 o, V3 d, Trav& tv) {
     tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     tv.best_t = sc.t1;
     tv.best_prim = 0xffffffffu;
     tv.sp = 0;
     tv.cur = root_box_hit(sc, o, tv.inv) ? sc.root_ref : TRAV_DONE;
-    if (GATE32) {
-        const float ex = slab32_axis(o.x, tv.inv.x, sc.gate_bound, tv.s32.vx, tv.s32.cx);
-        const float ey = slab32_axis(o.y, tv.inv.y, sc.gate_bound, tv.s32.vy, tv.s32.cy);
-        const float ez = slab32_axis(o.z, tv.inv.z, sc.gate_bound, tv.s32.vz, tv.s32.cz);
-        tv.s32.sure = __builtin_fmaxf(3.0f * __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez), sc.gate_sure_min);
-    }
 }
 
 RR_DEV void trav_pop(const LaneStack& stack, Trav& tv) {
@@ -554,92 +489,6 @@ RR_DEV void trav_interior_step(const SceneDev& sc, V3 o, const LaneStack& stack,
     }
 }
 
-// ---- the GATE32 interior step (see trav_init)
-
-// (near, far) of one axis -> (L, U): one packed fma
-RR_DEV f32x2 slab32_lu(uint32_t lo, uint32_t hi, bool neg, float v, f32x2 c) {
-    f32x2 b, vv;
-    b.x = __uint_as_float(neg ? hi : lo), b.y = __uint_as_float(neg ? lo : hi);
-    vv.x = v, vv.y = v;
-    return __builtin_elementwise_fma(b, vv, c);
-}
-
-// the f32 interval of one box: width = fl(hi - lo); the ray may enter iff !(hi < lo)
-RR_DEV bool slab32_may_enter(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, bool nx,
-                             bool ny, bool nz, const Slab32& s, float t0_lo, float t1_hi, float& width) {
-    const f32x2 x = slab32_lu(x0, x1, nx, s.vx, s.cx);
-    const f32x2 y = slab32_lu(y0, y1, ny, s.vy, s.cy);
-    const f32x2 z = slab32_lu(z0, z1, nz, s.vz, s.cz);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x), t0_lo);
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(x.y, y.y), z.y), t1_hi);
-    width = hi - lo;
-    return !(hi < lo);
-}
-
-// One compact record of the gate tree.  `o`, `d`: the ray (used by the lanes whose f32 interval leaves a leaf slot open).
-// Every slot the ray may enter is visited, in slot order (nothing is culled, so the order buys nothing: the closest hit
-// is the smallest accepted t, ties by primitive index, in any order).
-template <bool COUNT>
-RR_DEV void trav_interior_step_gate32(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, const HotNodes& hot,
-                                      Trav& tv, WorkCount& wc) {
-    const Slab32& s = tv.s32;
-    const bool nx = s.vx < 0.0f, ny = s.vy < 0.0f, nz = s.vz < 0.0f;
-    const uint32_t rec = tv.cur & 0x3fffffffu;
-    if (COUNT) wc.interior++;
-    uint4 a, b, c, e, f, g, r;
-    if (rec < hot.count) {
-        const uint4* src = hot.lds + rec * HotNodes::stride<true>();
-        a = src[0], b = src[1], c = src[2], e = src[3], f = src[4], g = src[5], r = src[6];
-    } else {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
-        a = src[0], b = src[1], c = src[2], e = src[3], f = src[4], g = src[5], r = src[6];
-    }
-    uint32_t r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
-    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));  // (loaded with the boxes: trav_interior_step)
-    const float t0 = sc.t0_lo, t1 = sc.t1_hi;
-    float w0, w1, w2, w3;
-    // (a reference with its top bit set is an unused slot: its inverted box cannot be entered by a ray that tests at least
-    // one axis, and a ray that ignores all three must not be let into it either)
-    bool h0 = slab32_may_enter(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, s, t0, t1, w0) && (int32_t)r0 >= 0;
-    bool h1 = slab32_may_enter(b.z, b.w, c.x, c.y, c.z, c.w, nx, ny, nz, s, t0, t1, w1) && (int32_t)r1 >= 0;
-    bool h2 = slab32_may_enter(e.x, e.y, e.z, e.w, f.x, f.y, nx, ny, nz, s, t0, t1, w2) && (int32_t)r2 >= 0;
-    bool h3 = slab32_may_enter(f.z, f.w, g.x, g.y, g.z, g.w, nx, ny, nz, s, t0, t1, w3) && (int32_t)r3 >= 0;
-    // leaf slots whose f32 interval is neither empty nor surely wide enough: the reference's own test, here
-    const bool u0 = h0 && (r0 >> 30) == REF_RANGE && !(w0 > s.sure), u1 = h1 && (r1 >> 30) == REF_RANGE && !(w1 > s.sure);
-    const bool u2 = h2 && (r2 >> 30) == REF_RANGE && !(w2 > s.sure), u3 = h3 && (r3 >> 30) == REF_RANGE && !(w3 > s.sure);
-    if (__ballot(u0 || u1 || u2 || u3) != 0ull) {  // (most waves skip this)
-        const double tmin = sc.t0, tmax = sc.t1;
-        const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        const bool fx = inv.x < 0.0, fy = inv.y < 0.0, fz = inv.z < 0.0;
-        double en;
-        const bool g0 = slab_f32(a.x, a.y, a.z, a.w, b.x, b.y, fx, fy, fz, o, inv, tmin, tmax, en);
-        const bool g1 = slab_f32(b.z, b.w, c.x, c.y, c.z, c.w, fx, fy, fz, o, inv, tmin, tmax, en);
-        const bool g2 = slab_f32(e.x, e.y, e.z, e.w, f.x, f.y, fx, fy, fz, o, inv, tmin, tmax, en);
-        const bool g3 = slab_f32(f.z, f.w, g.x, g.y, g.z, g.w, fx, fy, fz, o, inv, tmin, tmax, en);
-        h0 = u0 ? g0 : h0, h1 = u1 ? g1 : h1, h2 = u2 ? g2 : h2, h3 = u3 ? g3 : h3;
-    }
-    const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-    if (n == 0) {
-        trav_pop(stack, tv);
-        return;
-    }
-    const int k_1 = (int)h0, k_2 = (int)h0 + (int)h1, k_3 = (int)h0 + (int)h1 + (int)h2;
-    tv.cur = h0 ? r0 : h1 ? r1 : h2 ? r2 : r3;
-    const int top = tv.sp + n - 1;
-    tv.sp = top;
-    if (__ballot((uint32_t)top > stack.cap) == 0ull) {  // (as trav_interior_step)
-        const int spare = (int)stack.cap;
-        stack.lds[(h0 ? top : spare) * 64] = r0;
-        stack.lds[(h1 ? top - k_1 : spare) * 64] = r1;
-        stack.lds[(h2 ? top - k_2 : spare) * 64] = r2;
-        stack.lds[(h3 ? top - k_3 : spare) * 64] = r3;
-    } else {
-        if (h1 && k_1 > 0) stack.put(top - k_1, r1);
-        if (h2 && k_2 > 0) stack.put(top - k_2, r2);
-        if (h3 && k_3 > 0) stack.put(top - k_3, r3);
-    }
-}
-
 // One leaf reference: its 1..4 primitives in DFS order, then pop.
 template <bool COMPACT, bool COUNT>
 RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
@@ -673,16 +522,13 @@ template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
-    constexpr bool GATE32 = COMPACT && EXACT;
-    trav_init<GATE32>(sc, o, d, tv);
+    trav_init(sc, o, d, tv);
     const HotNodes hot{nullptr, 0u};
     while (tv.cur != TRAV_DONE) {
-        if (trav_at_interior(tv)) {
-            if constexpr (GATE32) trav_interior_step_gate32<COUNT>(sc, o, d, stack, hot, tv, wc);
-            else trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
-        } else {
+        if (trav_at_interior(tv))
+            trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
+        else
             trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-        }
     }
     t_hit = tv.best_t;
     prim_hit = tv.best_prim;

@@ -107,9 +107,6 @@ struct SceneDev {
     // the default walk (rayrs_render_params.fast_traversal == 0): nothing is culled by the closest hit so far, as BvhTree::intersect
     // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
     uint32_t exact, pad1;
-    // the default walk on compact records (device_path.h GATE32): a bound on every |box bound| of the gate tree; the
-    // scene's t range rounded outwards to f32; 2.5 x the larger of the two roundings
-    float gate_bound, t0_lo, t1_hi, gate_sure_min;
 };
 
 struct CameraDev {

@@ -756,18 +756,6 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
                 break;
             }
     }
-    if (compact) {  // the bound of the default walk's f32 box test (device_path.h GATE32), which assumes it below 2^80
-        double bound = 0x1p-60;
-        for (int k = 0; k < 6; k++) bound = std::max(bound, std::fabs(f.root_box[k]));
-        for (size_t r = 0; r < f.gate.ref.size(); r++) {
-            if ((f.gate.ref[r] >> 30) == REF_NONE) continue;
-            for (int k = 0; k < 6; k++) bound = std::max(bound, std::fabs(f.gate.box[r * 6 + k]));
-        }
-        float bf = (float)bound;
-        if ((double)bf < bound) bf = std::nextafterf(bf, std::numeric_limits<float>::infinity());
-        f.gate_bound = bf;
-        if (!(bound < 0x1p80)) compact = false;
-    }
     f.compact = compact;
     for (WalkTree* t : {&f.gate, &f.walk}) {
         if (compact) fill_nodes<Node4F32, float>(*t);

@@ -74,7 +74,6 @@ struct FlatScene {
     uint32_t hdri_w = 0, hdri_h = 0;
     double t0 = 0, t1 = 0;
     double build_seconds = 0;
-    float gate_bound = 0.0f;  // compact scenes: >= every |box bound| of the gate tree and of the root box, >= 2^-60 (device_path.h GATE32)
     double small_extent = 0;  // 5th percentile of the primitives' largest bounding-box extents (abi.cpp camera_is_far)
     uint32_t n_interior() const { return (uint32_t)(child_ref.size() / 2); }
     uint32_t n_prims() const { return (uint32_t)prim_object.size(); }

@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
-                    trav_init<COMPACT && EXACT>(sc, o, d, tv);
+                    trav_init(sc, o, d, tv);
                     if (tv.cur == TRAV_DONE)
                         pending = true;  // missed the root box: retired at the next refill
                     else
@@ -557,8 +557,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                if constexpr (COMPACT && EXACT) trav_interior_step_gate32<COUNT>(sc, o, d, stack, hot, tv, wc);
-                else trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
+                trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
                 if (tv.cur == TRAV_DONE) active = false, pending = true;
             }
             if (COUNT) {

@@ -93,7 +93,6 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
-    L.orc_set_gate32.argtypes = [vp, C.c_int]
     L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.orc_vec_op.restype = None
     L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
@@ -224,10 +223,6 @@ class OracleScene:
         closest-hit culling (rayrs_render_params.fast_traversal)."""
         self.use_walk_tree(product_scene, gate=not fast)
         self._walk_margin = 2.0 ** -10 if fast else float("inf")
-        if not fast and product_scene.info()["compact"]:
-            # compact records: the boxes of interior slots are tested in f32 with the roundings pushed outwards
-            # (device_path.h GATE32) -- the same leaf groups and primitives, now and then a record more
-            assert self._L.orc_set_gate32(self._h, 1) == 0
         return self
 
     def _with_margin(self, traversal, call):
