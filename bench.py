@@ -592,8 +592,10 @@ def main():
     if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_fast
             and not args.no_roofline and not args.fast_traversal and not main_run["local_pool"]):
         fr = measure(cam_args, 3, 1, True, fast=True)
-        assert fr["sha"] == main_run["sha"], "the fast walk rendered another frame than the default walk"
-        assert fr["exact_walk"] == 0 and main_run["exact_walk"] == 1
+        # (reported, not asserted: the headline line must not be lost to its companion measurement; the tests pin it)
+        same = fr["sha"] == main_run["sha"] and fr["exact_walk"] == 0 and main_run["exact_walk"] == 1
+        if not same:
+            print("bench.py: the fast walk's frame or walk flags differ from the default walk's", file=sys.stderr)
         fast_block = {"workload": "the headline frame by rayrs_render_params.fast_traversal = 1: closest-hit culling and tight "
                                   "leaf boxes, two bets on the reference's arithmetic (measured, not proved: include/rayrs_hip.h); "
                                   "the headline itself is the default walk, the reference's visit set by construction",
@@ -603,7 +605,7 @@ def main():
                       "prim_tests_per_ray": fr["roofline"]["prim_tests_per_ray"],
                       "traversal_ms": fr["roofline"]["kernels"]["wf_trav_kernel"]["ms"],
                       "roofline_frac": fr["roofline"]["frac"], "lane_utilisation": fr["roofline"]["lane_utilisation"],
-                      "framebuffer_sha256": fr["sha"], "same_frame_as_headline": True}
+                      "framebuffer_sha256": fr["sha"], "same_frame_as_headline": bool(same)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
