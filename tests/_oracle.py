@@ -238,7 +238,7 @@ class OracleScene:
     def use_walk_tree(self, product_scene, gate=False):
         """Take the four-slot records the kernels walk from the product (a rayrs_amd.Scene, host-only
         or on a device): traversal=2 then makes the kernel's walk on the kernel's data.  gate=True: the
-        tree rayrs_render_params.exact_traversal walks (and the local-pool route's gates come from)."""
+        tree the default walk reads (and the local-pool route's gates come from)."""
         info = product_scene.info()
         box, ref = product_scene.export_gate_tree() if gate else product_scene.export_wide()
         box = np.ascontiguousarray(box)

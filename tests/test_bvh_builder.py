@@ -84,7 +84,7 @@ def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False):
     """What makes a walk tree legal (scene_host.cpp build_walk_trees), checked from the outside: every interior
     slot's box is the union of the boxes below it (so a ray that misses it misses every leaf box inside); unused
     slots are marked; every record is reached once; the stack bound holds; and
-      gate=True (the tree exact_traversal walks): every group of the reference's tree sits in exactly one leaf slot
+      gate=True (the tree the default walk reads): every group of the reference's tree sits in exactly one leaf slot
         behind exactly its gating box -- the tree reaches what the reference reaches;
       gate=False (the default tree): every primitive sits alone in exactly one leaf slot, behind its own bounding
         box (prim_boxes[p]: Object::bbox of the object behind primitive p) widened by LEAF_MARGIN and clipped to its

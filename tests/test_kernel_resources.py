@@ -39,7 +39,7 @@ def test_streaming_kernels_keep_their_occupancy(tmp_path):
     # the timed traversal kernels (COUNT = false, EXACT = false): five waves per SIMD, nothing in scratch
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb0EEE").items():
         assert vgpr <= 96 and scratch == 0, (name, vgpr, scratch)
-    # exact_traversal's instances (the walk without culling): the same occupancy; at most the stack strip's pointer
+    # the default walk's instances (EXACT: nothing culled): the same occupancy; at most the stack strip's pointer
     # parked in scratch for the deep-stack path, never a spill inside the walk
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb1EEE").items():
         assert vgpr <= 96 and scratch <= 16, (name, vgpr, scratch)
