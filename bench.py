@@ -60,13 +60,31 @@ OPS_TRIANGLE_F64 = 89
 OPS_SPHERE = 66            # geometry.rs:106-132: 3 sub, 3 dot, sqrt (10), 2 div x 11, 12 others
 OPS_PLANE = 26             # geometry.rs:229-271: 1 div x 11, 1 sub, 3 mul, 3 add, 8 compares
 OPS_RAY = 54               # 1/d (3 div x 11) + the root box test (21)
+# the hot-group phase (device_path.h hot_group_step): wave-uniform f64 data, e1 and e2 from the host
+OPS_HOT_GATE = 19          # the group's gating box: 6 sub + 6 mul + 6 min/max + 1 compare (its twelve 32-bit selects are not f64 work)
+OPS_HOT_TRIANGLE = 58      # 3 sub + 2 cross (18) + 4 dot (20) + the early rejection's 17 compares, xors and one multiply
+OPS_HOT_DIVISIONS = 42     # on top, for a triangle some lane of the wave was not settled on: 3 div x 11 + 1 add + 8 compares
+
+# REFERENCE ARITHMETIC ONLY (roofline.frac_ref_flops): the f64 additions, multiplications, divisions, square roots,
+# min/max and compares that BvhTree::intersect and the shapes' intersect functions perform on what the walk visits -- a
+# division or a square root counts ONE, nothing is charged for conversions, selects, the shortcut's tests or bookkeeping.
+# Holds against the datasheet's vector FP64 rate without FMA (39.3 T/s); by construction below `frac`.
+REF_BOX = 19               # geometry.rs:458-513 with 1 / d at hand: 6 sub, 6 mul, 6 min/max, 1 compare
+REF_RECORD = 4 * REF_BOX   # the walk's records hold four boxes (an unused slot's inverted box is tested like any other)
+REF_TRIANGLE = 51          # geometry.rs:359-375: t = o - p1 (3), two cross products (18), four dot products (20), 3 div, u + v, 4 compares; bvh.rs:406: 2
+REF_TRIANGLE_SETTLED = 41  # ... of a hot-group triangle rejected before the divisions: the subtraction, the cross and dot products
+REF_SPHERE = 33            # geometry.rs:106-132: 3 sub, three dot products (15), 2 mul, 4 for the discriminant, sqrt, 2 x (add, mul, div), 2 compares
+REF_PLANE = 14             # geometry.rs:229-271: 1 sub, 1 div, 3 mul + 3 add, 4 compares; bvh.rs:406: 2
+REF_RAY = 3 + REF_BOX      # 1 / d and the root Node's box
 
 
 # Vector instructions one evaluation of a shading unit costs when the unit is compiled alone and all 64 lanes work:
 # SQ_INSTS_VALU x 64 / evaluations of rayrs_test_material / rayrs_test_background on 2 M random tuples each, minus
-# the test kernel's own loads and stores (scripts/op_model.sh; profiles/r03_op_model.json).  The dielectrics are
-# evaluated with half of the hits from inside the medium; their arms branch (reflect / refract / total internal
-# reflection), and a wave runs every branch one of its lanes takes -- that is part of what the arm costs.
+# the test kernel's own loads and stores (scripts/op_model.sh -> profiles/rNN_op_model.json, stamped with the hash of
+# the shading sources it was measured on; load_op_model() below takes the newest one and says whether it is stale).
+# The dielectrics are evaluated with half of the hits from inside the medium; their arms branch (reflect / refract /
+# total internal reflection), and a wave runs every branch one of its lanes takes -- that is part of what the arm costs.
+# (These literals are round 3's measurement: the fallback when no profile is found, flagged as such in the line.)
 OPS_MATERIAL = {
     "lambertian": 317, "reflect": 30, "refract": 136, "glass": 248, "cook_torrance": 831,
     "cook_torrance_refract": 1120, "cook_torrance_glass": 2120, "plastic": 1187, "no_reflect": 0,
@@ -77,31 +95,116 @@ OPS_HIT_FIXED = 150        # position 6, view 32, normal ~32, emission and throu
 OPS_SAMPLE = 180           # a new sample: path key ~40, two draws ~60, primary ray ~25, 1/d and the root box test 54
 MATERIAL_UNIT = ["lambertian", "reflect", "refract", "glass", "cook_torrance", "cook_torrance_refract",
                  "cook_torrance_glass", "plastic", "no_reflect"]   # by RAYRS_MAT_*
+OP_MODEL_UNIT = {"lambertian": "lambertian", "reflect": "reflect", "refract": "refract", "glass": "glass",
+                 "cook_torrance": "cook_torrance_metal_rough", "cook_torrance_refract": "cook_torrance_refract",
+                 "cook_torrance_glass": "cook_torrance_glass", "plastic": "plastic"}
+OP_MODEL = {"file": None, "stale": True, "shading_source_hash": None,
+            "note": "no profiles/*_op_model.json found: round 3's literals (bench.py OPS_MATERIAL)"}
 
 
-def traversal_ops(stats, info):
+def shading_source_hash():
+    """sha256 over the sources the shading units are compiled from (what scripts/op_model.sh measures)."""
+    h = hashlib.sha256()
+    for f in ("include/rayrs_numeric.h", "rayrs_amd/csrc/device_path.h", "rayrs_amd/csrc/kernels.hip", "rayrs_amd/csrc/layout.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_op_model():
+    """The newest profiles/*_op_model.json becomes OPS_MATERIAL / OPS_BACKGROUND; OP_MODEL says which file and whether
+    it was measured on the shading sources of this tree (a two-rounds-old model went unnoticed)."""
+    global OPS_BACKGROUND
+    want = shading_source_hash()
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_op_model.json"))):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if "units" in j and (best is None or j.get("shading_source_hash") == want or best[1].get("shading_source_hash") != want):
+            best = (path, j)
+    if best is None:
+        return
+    path, j = best
+    u = j["units"]
+    for unit, key in OP_MODEL_UNIT.items():
+        if key in u:
+            OPS_MATERIAL[unit] = int(round(u[key]["valu_per_evaluation_net"]))
+    if "background" in u:  # (minus the test kernel's own loads and stores, like the material units)
+        OPS_BACKGROUND = int(round(u["background"]["valu_per_evaluation"] - u["none"]["valu_per_evaluation"]))
+    stale = j.get("shading_source_hash") != want
+    OP_MODEL.update({"file": os.path.relpath(path, ROOT), "stale": stale, "shading_source_hash": j.get("shading_source_hash"),
+                     "this_tree": want,
+                     "note": ("measured on other shading sources than this tree's: re-run scripts/op_model.sh" if stale
+                              else "measured on this tree's shading sources")})
+
+
+def hot_group_kinds(scene, info, objs):
+    """(triangles, spheres, rectangles) among the primitives of the scene's hot group."""
+    if not info["hot_count"]:
+        return 0, 0, 0
+    from rayrs_amd.api import flatten_objects
+    spans, at = [], 0   # (first object index, count, kind) in insertion order: a "mesh" is one object per triangle
+    for o in flatten_objects(objs):
+        n = len(o.idx) if o.kind == "mesh" else 1
+        spans.append((at, n, "triangle" if o.kind == "mesh" else o.kind))
+        at += n
+    pp = scene.export_bvh()[2]
+    kinds = []
+    for k in range(info["hot_count"]):
+        i = int(pp[info["hot_first"] + k])
+        kinds.append(next(kind for first, n, kind in spans if first <= i < first + n))
+    return kinds.count("triangle"), kinds.count("sphere"), kinds.count("plane")
+
+
+def traversal_ops(stats, info, hot_kinds=(0, 0, 0)):
     """Useful f64-rate lane operations of the frame's BVH walks (records entered, primitives tested)."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
     if stats.get("exact_walk"):  # (the local-pool kernel's loop over a record's gates neither culls nor ranks either)
         rec -= OPS_RECORD_NO_CULL
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
-    return (stats["interior_visits"] * rec + stats["tri_tests"] * tri + stats["sphere_tests"] * OPS_SPHERE
-            + stats["plane_tests"] * OPS_PLANE)
+    ops = stats["interior_visits"] * rec
+    n_tri, n_sph, n_pl = stats["tri_tests"], stats["sphere_tests"], stats["plane_tests"]
+    if stats.get("hot_group"):
+        # the hot-group phase: its gate per ray that owed the test, its primitives per ray that entered it, on uniform f64 data
+        entered = stats["hot_prim_tests"] // max(sum(hot_kinds), 1)
+        h_tri, h_sph, h_pl = (entered * k for k in hot_kinds)
+        ops += stats["hot_lane"] * OPS_HOT_GATE + h_tri * OPS_HOT_TRIANGLE + stats["hot_tri_divided"] * OPS_HOT_DIVISIONS
+        n_tri, n_sph, n_pl = n_tri - h_tri, n_sph - h_sph, n_pl - h_pl
+        ops += h_sph * OPS_SPHERE + h_pl * OPS_PLANE
+    return ops + n_tri * tri + n_sph * OPS_SPHERE + n_pl * OPS_PLANE
 
 
-def useful_f64_ops(stats, info):
+def reference_flops(stats, info, hot_kinds=(0, 0, 0)):
+    """roofline.frac_ref_flops' numerator for the traversal kernel: reference arithmetic only (REF_* above)."""
+    n_tri = stats["tri_tests"]
+    settled = 0
+    flops = stats["interior_visits"] * REF_RECORD
+    if stats.get("hot_group"):
+        entered = stats["hot_prim_tests"] // max(sum(hot_kinds), 1)
+        settled = entered * hot_kinds[0] - stats["hot_tri_divided"]
+        flops += stats["hot_lane"] * REF_BOX
+    return (flops + (n_tri - settled) * REF_TRIANGLE + settled * REF_TRIANGLE_SETTLED + stats["sphere_tests"] * REF_SPHERE
+            + stats["plane_tests"] * REF_PLANE + (stats["rays"] - stats.get("direct_rays", 0)) * REF_RAY)
+
+
+def useful_f64_ops(stats, info, hot_kinds=(0, 0, 0)):
     """Of the traversal kernel: the walks plus the setup of the rays it took.  Primary rays that miss the root box
     never reach it (direct_rays: the kernel that makes them finishes their sample)."""
-    return traversal_ops(stats, info) + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY
+    return traversal_ops(stats, info, hot_kinds) + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY
 
 
-def layout_conversion_ops(stats, info):
+def layout_conversion_ops(stats, info, hot_kinds=(0, 0, 0)):
     """The f32 -> f64 conversions of the compact layout among traversal_ops(): they exist because of the layout, not
-    because of the reference's arithmetic (24 per record, 9 per triangle)."""
+    because of the reference's arithmetic (24 per record, 9 per triangle read from its record)."""
     if not info["compact"]:
         return 0
+    n_tri = stats["tri_tests"]
+    if stats.get("hot_group"):
+        n_tri -= stats["hot_prim_tests"] // max(sum(hot_kinds), 1) * hot_kinds[0]
     return (stats["interior_visits"] * (OPS_RECORD_COMPACT - OPS_RECORD_F64)
-            + stats["tri_tests"] * (OPS_TRIANGLE_COMPACT - OPS_TRIANGLE_F64))
+            + n_tri * (OPS_TRIANGLE_COMPACT - OPS_TRIANGLE_F64))
 
 
 def surface_units(objs):
@@ -219,6 +322,7 @@ def main():
                     help="render the timed frames with rayrs_render_params.fast_traversal (the two bets) instead of the "
                          "default walk; the default line carries that figure in its `fast` block anyway")
     ap.add_argument("--no-fast", action="store_true", help="skip the `fast` block")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (configs[0..3] beside the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (host reduce) is for "
                     "rehearsing the N>1 path on a box with fewer GPUs than ranks")
@@ -244,6 +348,7 @@ def main():
     import numpy as np
     import torch
 
+    load_op_model()
     import __graft_entry__ as graft
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,48 +378,90 @@ def main():
     import rayrs_amd
     from rayrs_amd import procedural, scenes, tiles
 
-    # the mesh takes the route a scanned model would: written as a binary PLY, read back by the library's loader
     import tempfile
-    ply_path = os.path.join(tempfile.gettempdir(), f"rayrs_bench_mesh_rank{rank}.ply") if args.config in (3, 5) else None
-    cam_args, objs, heur, spp, max_bounces = scenes.config(args.config, ply_path=ply_path)
-    reduced = False
-    if args.share_of:
-        if world != 1:
-            raise SystemExit("--share-of is a one-GPU development option")
-        reduced = True
-    if args.spp:
-        spp, reduced = args.spp, True
-    W0 = H0 = {1: 256, 2: 1024, 3: 1024, 4: 2048, 5: 2048}[args.config]
-    if args.res:
-        W0 = H0 = args.res
-        reduced = True
-    if args.camera == "close":
-        if args.config not in (3, 5):
-            raise SystemExit("--camera close is for the mesh configurations (3, 5)")
-        cam_args = scenes.MESH_CLOSE_CAM
-    cam_args = scenes.camera_for_resolution(cam_args, W0, H0)
-    hdri = procedural.make_hdri(1024, 512)
-    t0 = time.time()
-    scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=local_rank)
-    build_s = time.time() - t0
-    info = scene.info()
+    import threading
+    import types
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream(dev)
-    # frames in flight: flight 0 is the scene itself on the current stream; the others are clones (same records, own
-    # pool) on streams of their own
-    import threading
+    hdri = procedural.make_hdri(1024, 512)
+    RES = {1: 256, 2: 1024, 3: 1024, 4: 2048, 5: 2048}
+
+    def make_context(config, n_flights_want, spp_override=0, res_override=0, camera="reference"):
+        """Scene, camera and flights of BASELINE.json configs[config - 1]."""
+        cx = types.SimpleNamespace(config=config)
+        # the mesh takes the route a scanned model would: written as a binary PLY (by rank 0 of the node; the other ranks
+        # wait for it), read back by every rank through the library's loader
+        ply_path = None
+        if config in (3, 5):
+            ply_path = os.path.join(tempfile.gettempdir(), f"rayrs_bench_mesh_config{config}_{os.environ.get('MASTER_PORT', 'solo')}_{os.getuid()}.ply")
+            if use_dist:
+                if rank == 0:
+                    scenes.write_config_ply(config, ply_path)
+                dist.barrier()
+                cam_args, objs, heur, spp, max_bounces = scenes.config(config, ply_path=ply_path, ply_exists=True)
+            else:
+                cam_args, objs, heur, spp, max_bounces = scenes.config(config, ply_path=ply_path)
+        else:
+            cam_args, objs, heur, spp, max_bounces = scenes.config(config)
+        cx.reduced = False
+        if spp_override:
+            spp, cx.reduced = spp_override, True
+        W0 = H0 = RES[config]
+        if res_override:
+            W0 = H0 = res_override
+            cx.reduced = True
+        if camera == "close":
+            if config not in (3, 5):
+                raise SystemExit("--camera close is for the mesh configurations (3, 5)")
+            cam_args = scenes.MESH_CLOSE_CAM
+        cx.cam_args = scenes.camera_for_resolution(cam_args, W0, H0)
+        cx.W0, cx.H0 = W0, H0
+        cx.objs, cx.heur, cx.spp, cx.max_bounces = objs, heur, spp, max_bounces
+        t0 = time.time()
+        cx.scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, hdri, device=local_rank)
+        cx.build_s = time.time() - t0
+        cx.info = cx.scene.info()
+        # frames in flight: flight 0 is the scene itself on the current stream; the others are clones (same records, own
+        # pool) on streams of their own
+        cx.n_flights = max(1, n_flights_want)
+        # what a rank is about to hold in HBM, before it allocates anything of it (an N-rank out-of-memory failure must be
+        # readable from the log): the scene + per flight a path pool and the item sums, as abi.cpp rayrs_render_launch sizes them
+        cam = rayrs_amd.Camera(*cx.cam_args)
+        chunk = rayrs_amd.frame_sample_chunk(cam.x_pixels(), cam.y_pixels(), spp, args.sample_chunk) or spp
+        n_ranks = args.share_of if args.share_of else world
+        tiles_total = ((cam.x_pixels() + 7) // 8) * ((cam.y_pixels() + 7) // 8)
+        local_tiles = (tiles_total - (0 if args.share_of else rank) + n_ranks - 1) // n_ranks
+        items = local_tiles * 64 * ((spp + chunk - 1) // chunk)
+        if cx.info["local_pool"]:
+            pool_b, sums_b = 0, min(items, 1 << 27) * 24
+        else:
+            slots = min(items, 7 << 24, max(local_tiles * 64 * spp // 12, 1 << 20))
+            pool_b, sums_b = ((slots + 1023) & ~1023) * (128 + 32 + 1), items * 24
+        cx.hbm_bytes = int(cx.info["device_bytes"] + cx.n_flights * (pool_b + sums_b))
+        print(f"bench.py rank {rank}/{world} config {config}: about to hold scene {cx.info['device_bytes'] / 1e6:.0f} MB + {cx.n_flights} "
+              f"flight(s) x (path pool {pool_b / 1e9:.2f} GB + item sums {sums_b / 1e9:.2f} GB) = {cx.hbm_bytes / 1e9:.2f} GB on HIP device "
+              f"{local_rank}", file=sys.stderr, flush=True)
+        # (with more than one flight none of them uses the null stream, whose launches order against every other stream's)
+        cx.flights = [{"scene": cx.scene, "stream": stream if cx.n_flights == 1 else torch.cuda.Stream(dev)}]
+        for _ in range(cx.n_flights - 1):
+            cx.flights.append({"scene": cx.scene.clone_to_device(local_rank), "stream": torch.cuda.Stream(dev)})
+        return cx
+
+    if args.share_of and world != 1:
+        raise SystemExit("--share-of is a one-GPU development option")
     n_flights = args.frames_in_flight if args.frames_in_flight > 0 else (3 if (world > 1 or args.share_of) else 1)
     n_flights = max(1, min(n_flights, args.steps))
-    # (with more than one flight none of them uses the null stream, whose launches order against every other stream's)
-    flights = [{"scene": scene, "stream": stream if n_flights == 1 else torch.cuda.Stream(dev)}]
-    for _ in range(n_flights - 1):
-        flights.append({"scene": scene.clone_to_device(local_rank), "stream": torch.cuda.Stream(dev)})
+    cx = make_context(args.config, n_flights, args.spp, args.res, args.camera)
+    reduced = cx.reduced or bool(args.share_of)
+    cam_args, objs, heur, spp, max_bounces, info, build_s = cx.cam_args, cx.objs, cx.heur, cx.spp, cx.max_bounces, cx.info, cx.build_s
+    W0, H0 = cx.W0, cx.H0
 
-    def workload_key(W, H, chunk, camera=None):
-        return f"config{args.config}_{camera or args.camera}_{W}x{H}_{spp}spp_chunk{chunk}_world{world}"
+    def workload_key(cx, W, H, chunk, camera=None):
+        return f"config{cx.config}_{camera or args.camera}_{W}x{H}_{cx.spp}spp_chunk{chunk}_world{world}"
 
-    def measure(cam_args, steps, warmup, want_roofline, fast=False):
-        """Times `steps` frames from this camera; returns the pieces of the JSON line."""
+    def measure(cx, cam_args, steps, warmup, want_roofline, fast=False):
+        """Times `steps` frames of the scene in `cx` from this camera; returns the pieces of the JSON line."""
+        scene, flights, n_flights, objs, info, spp, max_bounces = cx.scene, cx.flights, cx.n_flights, cx.objs, cx.info, cx.spp, cx.max_bounces
         cam = rayrs_amd.Camera(*cam_args)
         H, W = cam.y_pixels(), cam.x_pixels()
         # a pixel's samples are summed in chunks; the chunk comes from the WHOLE frame (rayrs_frame_sample_chunk:
@@ -462,12 +609,13 @@ def main():
             rayrs_amd.render_launch(scene, cam, pc, fb2.data_ptr(), stream.cuda_stream)
             cst = rayrs_amd.render_finish(scene)
             assert cst["rays"] == st["rays"], "counting launch traced a different frame"
-            shares = ray_shares(cst, args.config, info["n_surfaces"])
+            shares = ray_shares(cst, cx.config, info["n_surfaces"])
             launches = st["kernel_launches"]                          # traversal launches = path rounds (local pool: segments)
             step_ms = max_elapsed / steps * 1e3
             share_base_ms = alone_ms if alone_ms is not None else step_ms
             n_st = len(kernel_ms)
             units = surface_units(objs)
+            hot_kinds = hot_group_kinds(scene, info, objs)
             ops_hit, ops_miss, ops_gen = shading_ops(cst, units)
             paths_end_in_miss = cst["escaped_paths"]
             share_miss = paths_end_in_miss / max(cst["paths"], 1)
@@ -475,9 +623,9 @@ def main():
             # operations it is charged with; the roofline is the one with the largest share of the step
             if st["local_pool"]:
                 kern = {"lp_path_kernel": {"ms": sum(kernel_ms) / n_st,
-                                           "ops": traversal_ops(cst, info) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
+                                           "ops": traversal_ops(cst, info, hot_kinds) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
             else:
-                kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info)},
+                kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info, hot_kinds)},
                         "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)},
                         "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss}}
             for k in kern.values():
@@ -492,11 +640,15 @@ def main():
             ops = kern[dom]["ops"]
             achieved = ops / (dom_ms * 1e-3) / 1e12
             # the same without the f32 -> f64 conversions of the compact layout (they are in every traversal figure)
-            conv = layout_conversion_ops(cst, info)
+            conv = layout_conversion_ops(cst, info, hot_kinds)
+            # reference arithmetic only, a division = 1 (the traversal kernel; shading units are priced in instructions)
+            frac_ref = None
+            if dom == "wf_trav_kernel":
+                frac_ref = round(reference_flops(cst, info, hot_kinds) / (dom_ms * 1e-3) / 1e12 / F64_PEAK_TOPS, 4)
             frac_no_conv = (ops - conv) / (dom_ms * 1e-3) / 1e12 / F64_PEAK_TOPS
             abytes = algorithmic_bytes(cst, info)
             prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
-            pmc = find_pmc_profile(workload_key(W, H, chunk))
+            pmc = find_pmc_profile(workload_key(cx, W, H, chunk))
             traffic = fabric_gbs = valu_busy = valu_per_ray = pmc_src = None
             step_fabric = None
             if pmc is not None:
@@ -528,10 +680,13 @@ def main():
             else:
                 util = {"interior": round(cst["step_lane"] / max(cst["step_wave"], 1), 3),
                         "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)}
+                if cst.get("hot_group"):
+                    util["hot group"] = round(cst["hot_lane"] / max(cst["hot_wave"], 1), 3)
             roofline = {
                 "bound": "fp64_valu", "achieved": round(achieved, 3), "peak": round(F64_PEAK_TOPS, 2),
                 "unit": "Tlane-op/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
                 "frac_without_layout_conversions": round(frac_no_conv, 4),
+                "frac_ref_flops": frac_ref, "op_model": dict(OP_MODEL),
                 "step": whole_step,
                 "kernel": dom, "launches_per_step": int(launches), "kernel_ms": round(avg_ms, 4),
                 "kernel_times_from": "the timed steps" if F == 1 else
@@ -544,7 +699,7 @@ def main():
                               "primitive, ray) are f64 operations counted in device_path.h (plus the compact layout's f32 -> "
                               "f64 conversions: frac_without_layout_conversions leaves them out).  Shading units (material "
                               "arms, background, new sample) are VALU lane-INSTRUCTIONS of the unit compiled alone "
-                              "(profiles/r03_op_model.json): they include integer RNG hashing, moves and selects and both "
+                              "(roofline.op_model.file): they include integer RNG hashing, moves and selects and both "
                               "sides of divergent branches, so a shading kernel's frac is an instruction-issue share, not an "
                               "FP64 FLOP fraction, and is not comparable with the traversal kernel's",
                 "kernels": kern,
@@ -552,6 +707,11 @@ def main():
                 "records_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
                 "prim_tests_per_ray": round(prims / max(cst["rays"], 1), 2),
                 "lane_utilisation": util,
+                "hot_group": None if not cst.get("hot_group") else {
+                    "rays_that_owed_the_test_per_ray": round(cst["hot_lane"] / max(cst["rays"], 1), 3),
+                    "primitive_tests_per_ray": round(cst["hot_prim_tests"] / max(cst["rays"], 1), 3),
+                    "triangle_tests_that_went_on_to_divide_per_ray": round(cst["hot_tri_divided"] / max(cst["rays"], 1), 4),
+                    "lanes": round(cst["hot_lane"] / max(cst["hot_wave"], 1), 3)},
                 # SURVEY.md 8(d)'s figure: record fetches of an incoherent walk, served by LDS / L1 / L2 / Infinity
                 # Cache -- it can exceed the HBM peak and bounds nothing; kept for comparison
                 "algorithmic_bytes_per_launch": int(abytes / launches),
@@ -570,16 +730,16 @@ def main():
                 "frame_alone_ms": alone_ms,
                 "ms_per_step": max_elapsed / steps * 1e3, "rays_per_step": int(total_rays / steps),
                 "checksum": checksum, "sha": fb_sha, "roofline": roofline, "shares": shares,
-                "exact_walk": int(st["exact_walk"]), "local_pool": int(st["local_pool"])}
+                "exact_walk": int(st["exact_walk"]), "local_pool": int(st["local_pool"]), "hot_group": int(st["hot_group"])}
 
-    main_run = measure(cam_args, args.steps, args.warmup, not args.no_roofline, fast=args.fast_traversal)
+    main_run = measure(cx, cam_args, args.steps, args.warmup, not args.no_roofline, fast=args.fast_traversal)
     W, H, chunk = main_run["W"], main_run["H"], main_run["chunk"]
 
     secondary = None
     if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_secondary
             and not args.no_roofline):
         close = scenes.camera_for_resolution(scenes.MESH_CLOSE_CAM, W0, H0)
-        sec = measure(close, 3, 1, True)
+        sec = measure(cx, close, 3, 1, True)
         secondary = {"workload": "the same scene and settings from a camera the mesh fills (scenes.MESH_CLOSE_CAM)",
                      "steps": 3, "warmup": 1,
                      "value": round(sec["value"], 2), "unit": "Mray/s", "ms_per_step": round(sec["ms_per_step"], 2),
@@ -591,7 +751,7 @@ def main():
     fast_block = None
     if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_fast
             and not args.no_roofline and not args.fast_traversal and not main_run["local_pool"]):
-        fr = measure(cam_args, 3, 1, True, fast=True)
+        fr = measure(cx, cam_args, 3, 1, True, fast=True)
         # (reported, not asserted: the headline line must not be lost to its companion measurement; the tests pin it)
         same = fr["sha"] == main_run["sha"] and fr["exact_walk"] == 0 and main_run["exact_walk"] == 1
         if not same:
@@ -606,6 +766,28 @@ def main():
                       "traversal_ms": fr["roofline"]["kernels"]["wf_trav_kernel"]["ms"],
                       "roofline_frac": fr["roofline"]["frac"], "lane_utilisation": fr["roofline"]["lane_utilisation"],
                       "framebuffer_sha256": fr["sha"], "same_frame_as_headline": bool(same)}
+
+    # BASELINE.json configs[0..3] at full size beside the headline (on the driver's record, not only in
+    # profiles/): 1 untimed + 3 timed frames each, the kernel with the largest share of the step priced as the headline's is
+    configs_block = None
+    if (args.config == 5 and args.camera == "reference" and world == 1 and not reduced and not args.no_configs
+            and not args.no_roofline and not args.fast_traversal):
+        configs_block = []
+        for n in (1, 2, 3, 4):
+            c = make_context(n, 1)
+            r = measure(c, c.cam_args, 3, 1, True)
+            rf = r["roofline"]
+            configs_block.append({
+                "config": f"configs[{n - 1}]", "resolution": [r["W"], r["H"]], "spp": c.spp, "max_bounces": c.max_bounces,
+                "primitives": c.info["n_prims"], "steps": 3, "warmup": 1,
+                "value": round(r["value"], 2), "unit": "Mray/s", "ms_per_step": round(r["ms_per_step"], 3),
+                "rays_per_step": r["rays_per_step"],
+                "route": "local pool (one launch, paths resident in LDS)" if r["local_pool"] else
+                         ("streaming, default walk" + (" + hot group" if r["hot_group"] else "")),
+                "kernel": rf["kernel"], "kernel_share_of_step": rf["kernel_share_of_step"], "frac": rf["frac"],
+                "frac_ref_flops": rf.get("frac_ref_flops"),
+                "framebuffer_sha256": r["sha"], "scene_build_s": round(c.build_s, 2)})
+            del c, r
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -680,13 +862,16 @@ def main():
                 "unpipelined_ms_per_frame": None if main_run["unpipelined_ms"] is None else round(main_run["unpipelined_ms"], 2),
                 # which walk answered the timed frames' BVH queries (rayrs_render_stats.exact_walk)
                 "walk": ("local pool: the gate tree's groups, nothing culled (the reference's visit set)" if main_run["local_pool"] else
-                         "default: the gate tree, nothing culled -- the reference's visit set by construction" if main_run["exact_walk"]
+                         ("default: the gate tree, nothing culled -- the reference's visit set by construction"
+                          + (", its hot group (the floor's bottom Node) tested once per ray beside the walk" if main_run["hot_group"] else ""))
+                         if main_run["exact_walk"]
                          else "fast_traversal: closest-hit culling + tight leaf boxes (two bets)"),
                 "layout": "compact f32 records" if info["compact"] else "f64 records",
-                "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"] if args.fast_traversal else info["gate_n_wide"],
+                "bvh_depth": info["depth"], "walk_tree_records": info["n_wide"] if args.fast_traversal else (info["hot_n_wide"] if main_run["hot_group"] else info["gate_n_wide"]),
+                "hbm_bytes_per_rank": cx.hbm_bytes,
                 "scene_bytes": info["device_bytes"],
                 "scene_build_s": round(build_s, 2), "source_hash": source_hash(),
-                "workload_key": workload_key(W, H, chunk), "collective": collective,
+                "workload_key": workload_key(cx, W, H, chunk), "collective": collective,
             },
             "rays_per_step": main_run["rays_per_step"],
             "framebuffer_checksum": main_run["checksum"],
@@ -698,6 +883,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "secondary": secondary,
             "fast": fast_block,
+            "configs": configs_block,
         }
         print(json.dumps(line), flush=True)
 

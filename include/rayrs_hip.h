@@ -152,6 +152,21 @@ typedef struct {
     uint32_t gate_n_wide;   /* the same three for the gate tree (rayrs_scene_export_gate_tree), which */
     uint32_t gate_root_ref; /* the default walk reads */
     uint32_t gate_depth;
+    /* The default walk's HOT GROUP (hot_count = 0: the scene has none): one group of the gate tree -- the one whose
+     * gating box is the largest, if it covers at least a quarter of the root Node's box: on the reference's obj scenes the
+     * floor's bottom Node, which nine rays in ten enter -- is left out of the records the default walk reads
+     * (rayrs_scene_export_hot_tree: hot_n_wide records) and tested ONCE PER RAY beside the walk, by a wave's rays
+     * together: its gating box hot_box exactly as AxisAlignedBoundingBox::intersect tests it, then its hot_count
+     * primitives hot_first ... in depth-first order exactly as the reference tests them.  The groups of that tree and
+     * the hot group together are the groups of the gate tree, each behind its gating box: the primitives tested are
+     * still exactly those BvhTree::intersect tests (tests/test_bvh_builder.py checks it from the exports). */
+    uint32_t hot_n_wide;
+    uint32_t hot_root_ref;
+    uint32_t hot_depth;
+    uint32_t hot_first;
+    uint32_t hot_count;
+    uint32_t hot_pad;
+    double hot_box[6];
 } rayrs_scene_info_t;
 
 int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info);
@@ -182,6 +197,9 @@ int rayrs_scene_export_bvh(const rayrs_scene* scene, double* child_box, uint32_t
  * tests/test_bvh_builder.py checks all of this from the exports alone. */
 int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
+/* The gate tree without the hot group (rayrs_scene_info_t.hot_*; n = hot_n_wide): what the default walk reads on a scene
+ * that has one.  RAYRS_INVALID_ARG on a scene without a hot group. */
+int rayrs_scene_export_hot_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref);
 
 /* ---- Camera: lib.rs:54-211 ---- */
 
@@ -233,13 +251,23 @@ typedef struct {
      *     the reference's answer unless its own test accepts a hit on a primitive the ray passes beside by more
      *     than that.
      *   Both fail only for rays aimed nearly IN a primitive's plane, where Moeller-Trumbore's own result is rounding
-     *   noise: culling within about 1e-7 rad of it (one such ray in 10^6 from nearby), the leaf boxes only from
-     *   thousands of primitive sizes away (a few in 10^4 of such rays, up to 1e-5 rad off the plane) --
-     *   scripts/fuzz_traversal.py counts them, profiles/r04_tight_leaves.txt; tests/test_walk_tree.py pins one failing
-     *   ray of each kind, on which the default walk returns the reference's primitive; no rendered frame, of any size,
-     *   has differed in a bit.  For a camera that stands farther from the scene's bounding box than 8 times that box's
-     *   diagonal, or than 2^16 times the scene's smallest primitive extent (5th percentile), the library takes the
-     *   default walk all the same (rayrs_render_stats.exact_walk reports the walk a frame took).
+     *   noise, and the failure envelope below is MEASURED, not proven (scripts/fuzz_traversal.py, 4 * 10^7 rays on sliver
+     *   meshes and nearly flat sheets, profiles/r05_fuzz_traversal.txt; "near" = from within the camera rule below):
+     *   - in-plane rays at 1e-7 rad and MORE off the plane, from nearby: 17 wrong hits in 3.97 M such rays, all on finely
+     *     tessellated sheets of SLIVER quads (250-400 per side, aspect ratios up to 10^6: the culling bet fails there at
+     *     any distance; 1 of the 17 is lost by the leaf boxes alone); none on the coarser sheets;
+     *   - closer than 1e-7 rad to the plane, from nearby: 52 in 5.96 M (31 of them by the leaf boxes alone);
+     *   - from far away (beyond the camera rule) the leaf boxes fail for about one in-plane ray in 10^4 at 1e-9 rad and
+     *     more, seven in 10^4 closer to the plane.
+     *   tests/test_walk_tree.py pins one failing ray of each kind, on which the default walk returns the reference's
+     *   primitive.  No rendered frame, of any size, has differed in a bit -- pixels are not aimed along triangle planes.
+     *   The camera rule: a frame whose camera stands farther from the scene's bounding box than 8 times that box's
+     *   diagonal, or than 4096 times the scene's small-primitive extent (the 5th percentile of the primitives' largest
+     *   extents), takes the default walk whatever it asked for (rayrs_render_stats.exact_walk reports the walk a frame
+     *   took).  The rule looks at the camera, so it guards PRIMARY rays only: a bounced ray that travels from a large
+     *   surface to a finely tessellated one covers thousands of small-primitive sizes and makes the leaf-box bet in the
+     *   regime where it was seen to fail; and on a finely tessellated scene most real cameras count as far, so the field
+     *   is then ignored (visible only in exact_walk).
      * What a sound walk costs, and what certificates (a forward error bound of Moeller-Trumbore deciding where "box
      * missed" provably means "rejected") could and could not buy back: profiles/r05_certified_walks.txt, DESIGN.md 2.
      * Zero-initialise the struct: values above 1 are refused (RAYRS_INVALID_ARG).  (Until round 5 this field was
@@ -283,6 +311,14 @@ typedef struct {
     uint32_t exact_walk;    /* 1 = this frame's queries were answered by the reference's visit set (the default); 0 = by the
                                fast walk (rayrs_render_params.fast_traversal = 1, the camera near enough, the streaming
                                route: the local-pool route never makes the bets) */
+    uint32_t hot_group;     /* 1 = ... with the scene's hot group tested beside the walk (rayrs_scene_info_t.hot_count) */
+    uint32_t stats_pad;
+    uint64_t hot_wave;      /* count_work only: executions of the hot-group phase x 64, the lanes that owed the test in */
+    uint64_t hot_lane;      /* them, and its shader-clock ticks (like step_wave / step_lane / interior_ticks) */
+    uint64_t hot_ticks;
+    uint64_t hot_prim_tests;  /* count_work only: of tri_tests + sphere_tests + plane_tests, those made in the hot-group phase */
+    uint64_t hot_tri_divided; /* ... of its triangle tests, those that went on to the three divisions (the others were settled
+                                 before them by two exact facts about IEEE division: device_path.h hot_triangle_intersect) */
 } rayrs_render_stats;
 
 /* The sample chunk a frame is rendered with when the caller has no reason to choose another:
@@ -339,15 +375,18 @@ int rayrs_scene_set_tuning(rayrs_scene* scene, const rayrs_tuning* tuning);
 
 /* The boundary's version: bumped whenever a struct of this header changes the meaning of a field or an entry point
  * its behaviour.  5 = round 5: rayrs_render_params.exact_traversal became fast_traversal (opposite sense: zero is now
- * the reference's visit set), the device self-test hooks left this header.  Every struct a caller fills must be zero-initialised
+ * the reference's visit set), the device self-test hooks left this header.  6 = round 6: rayrs_scene_info_t.hot_*,
+ * rayrs_render_stats.hot_*, rayrs_scene_export_hot_tree, rayrs_obj_load_spheres; the layout table below begins with this
+ * number, so a binding that checks itself against the table fails on a version change as well.  A binding MUST compare
+ * rayrs_abi_version() with the RAYRS_ABI_VERSION it was written against when it loads the library.  Every struct a caller fills must be zero-initialised
  * first: fields are added where padding used to be, and values out of a field's range are refused. */
-#define RAYRS_ABI_VERSION 5
+#define RAYRS_ABI_VERSION 6
 uint32_t rayrs_abi_version(void);
 
 /* ---- layout of the structs above as THIS library was compiled, for bindings in other languages
  * to check theirs against (tests/test_abi.py does it for rayrs_amd/_ffi.py, and INTEGRATION.md's
  * #[repr(C)] structs carry the same numbers).  Writes up to `cap` words to `out` and returns the
- * number of words the full table has: for each struct, in the order rayrs_material,
+ * number of words the full table has: first RAYRS_ABI_VERSION, then for each struct, in the order rayrs_material,
  * rayrs_emission, rayrs_camera, rayrs_scene_info_t, rayrs_render_params, rayrs_render_stats,
  * rayrs_tuning: sizeof, number of fields, then offsetof of every field in declaration order. */
 uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap);

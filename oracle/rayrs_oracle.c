@@ -863,6 +863,9 @@ struct orc_scene {
     double* wide_box;   /* n_wide * 4 * 6 */
     uint32_t* wide_ref; /* n_wide * 4 */
     int have_wide;      /* orc_set_wide was called */
+    int have_hot;       /* orc_set_hot_group was called after it: the product's hot group (include/rayrs_hip.h hot_*) */
+    double hot_box[6];
+    uint32_t hot_first, hot_count;
 };
 
 orc_scene* orc_scene_create(void) { return (orc_scene*)calloc(1, sizeof(orc_scene)); }
@@ -1311,6 +1314,20 @@ int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t
     s->finfo.wide_root_ref = wide_root_ref;
     s->finfo.wide_depth = wide_depth;
     s->have_wide = 1;
+    s->have_hot = 0;
+    return 0;
+}
+
+/* The product's hot group (rayrs_scene_info_t.hot_box / hot_first / hot_count): a group of the gate tree that the
+ * records handed over with orc_set_wide (rayrs_scene_export_hot_tree) leave out and the default walk's kernels test
+ * once per ray beside the walk.  isect_wide then does the same: the gating box as the reference tests it, and the
+ * group's primitives if the ray enters it.  Call after orc_set_wide (which forgets the group). */
+int orc_set_hot_group(orc_scene* s, const double box[6], uint32_t first, uint32_t count) {
+    if (!s || !s->built || !s->have_wide || count < 1 || count > 4 || (size_t)first + count > s->finfo.n_prims) return -1;
+    memcpy(s->hot_box, box, 6 * sizeof(double));
+    s->hot_first = first;
+    s->hot_count = count;
+    s->have_hot = 1;
     return 0;
 }
 
@@ -1567,6 +1584,13 @@ static isect_t isect_wide(const orc_scene* s, ray_t ray, double tmin, double tma
     if (s->finfo.wide_depth + 4u > 512u) stack = (uint32_t*)malloc(((size_t)s->finfo.wide_depth + 4u) * sizeof(uint32_t));
     int sp = 0;
     uint32_t cur = s->finfo.wide_root_ref;
+    if (s->have_hot) {
+        /* the product's hot group: not in the records; behind its gating box, once per ray that enters the root box
+         * (the order of visits does not matter: smallest accepted t, lowest DFS index on exact ties) */
+        double e_hot;
+        if (aabb_intersect_entry(s->hot_box, ray, inv, tmin, tmax, &e_hot))
+            stack[sp++] = (REF_KIND_RANGE << 30) | (s->hot_first << 2) | (s->hot_count - 1u);
+    }
     for (;;) {
         if ((cur >> 30) == REF_KIND_INTERIOR) {
             uint32_t rec = cur & 0x3fffffffu;

@@ -205,6 +205,9 @@ int orc_flatten_export_wide(const orc_scene* s, double* wide_box, uint32_t* wide
  * traversal 2 walks them.  The oracle does not build that tree itself. */
 int orc_set_wide(orc_scene* s, uint32_t n_wide, uint32_t wide_root_ref, uint32_t wide_depth, const double* wide_box,
                  const uint32_t* wide_ref);
+/* The product's hot group (rayrs_scene_info_t.hot_*), which the records of rayrs_scene_export_hot_tree leave out:
+ * traversal 2 then tests it beside the walk, as the default walk's kernels do.  After orc_set_wide, which forgets it. */
+int orc_set_hot_group(orc_scene* s, const double box[6], uint32_t first, uint32_t count);
 /* child_box: n_interior*2*6 f64; child_ref: n_interior*2; prim_object: n_prims
  * (object index, insertion order, of the DFS-ordered primitives). */
 int orc_flatten_export(const orc_scene* s, double* child_box, uint32_t* child_ref, uint32_t* prim_object);

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librayrs_hip.so")
+# RAYRS_HIP_LIB: another build of the same library (same ABI), for the same-box A/B scripts of scripts/ubench/ -- they
+# used to copy their alternatives over the tree's library.  Read by this binding, not by the library.
+LIB_PATH = os.environ.get("RAYRS_HIP_LIB") or os.path.join(_HERE, "librayrs_hip.so")
 
 # every symbol include/rayrs_hip.h declares
 SYMBOLS = [
@@ -17,7 +19,7 @@ SYMBOLS = [
     "rayrs_object_from_triangles_f32", "rayrs_object_from_triangles_f64",
     "rayrs_object_from_spheres", "rayrs_object_box_geom",
     "rayrs_scene_new", "rayrs_scene_destroy", "rayrs_scene_info", "rayrs_scene_export_bvh",
-    "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
+    "rayrs_scene_export_wide", "rayrs_scene_export_gate_tree", "rayrs_scene_export_hot_tree", "rayrs_scene_clone_to_device", "rayrs_scene_device", "rayrs_scene_set_tuning",
     "rayrs_camera_new",
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout", "rayrs_abi_version",
@@ -55,7 +57,10 @@ class SceneInfo(C.Structure):
                 ("device_bytes", C.c_uint64), ("root_box", C.c_double * 6),
                 ("build_seconds", C.c_double), ("n_wide", C.c_uint32), ("wide_root_ref", C.c_uint32),
                 ("wide_depth", C.c_uint32), ("local_pool", C.c_uint32), ("gate_n_wide", C.c_uint32),
-                ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32)]
+                ("gate_root_ref", C.c_uint32), ("gate_depth", C.c_uint32),
+                ("hot_n_wide", C.c_uint32), ("hot_root_ref", C.c_uint32), ("hot_depth", C.c_uint32),
+                ("hot_first", C.c_uint32), ("hot_count", C.c_uint32), ("hot_pad", C.c_uint32),
+                ("hot_box", C.c_double * 6)]
 
 
 class RenderParams(C.Structure):
@@ -73,7 +78,9 @@ class RenderStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
-                ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32)]
+                ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32), ("hot_group", C.c_uint32),
+                ("stats_pad", C.c_uint32), ("hot_wave", C.c_uint64), ("hot_lane", C.c_uint64), ("hot_ticks", C.c_uint64),
+                ("hot_prim_tests", C.c_uint64), ("hot_tri_divided", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -91,8 +98,12 @@ class LabTuning(C.Structure):
     _fields_ = [("refill_min", C.c_uint32), ("leaf_min", C.c_uint32), ("static_pct", C.c_uint32),
                 ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32),
                 ("eager_light", C.c_uint32), ("local_reserve", C.c_uint32), ("local_segment_items", C.c_uint32),
-                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32)]
+                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("hot_group", C.c_uint32),
+                ("hot_min", C.c_uint32), ("hot_wait", C.c_uint32)]
 
+
+# RAYRS_ABI_VERSION these mirrors were written against: lib() refuses a library of another version
+ABI_VERSION = 6
 
 # the order rayrs_abi_layout() reports the public structs in
 ABI_STRUCTS = [MaterialDesc, EmissionDesc, CameraDesc, SceneInfo, RenderParams, RenderStats, Tuning]
@@ -110,6 +121,11 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C rayrs_amd/csrc). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    L.rayrs_abi_version.argtypes = []
+    L.rayrs_abi_version.restype = C.c_uint32
+    if L.rayrs_abi_version() != ABI_VERSION:  # (what INTEGRATION.md asks of every binding)
+        raise RuntimeError(f"{LIB_PATH} has RAYRS_ABI_VERSION {L.rayrs_abi_version()}, this binding was written against "
+                           f"{ABI_VERSION}: rebuild the library (make -C rayrs_amd/csrc)")
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
     L.rayrs_strerror.restype = C.c_char_p
@@ -136,6 +152,7 @@ def lib():
     L.rayrs_scene_export_bvh.argtypes = [vp, vp, vp, vp]
     L.rayrs_scene_export_wide.argtypes = [vp, vp, vp]
     L.rayrs_scene_export_gate_tree.argtypes = [vp, vp, vp]
+    L.rayrs_scene_export_hot_tree.argtypes = [vp, vp, vp]
     L.rayrs_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rayrs_scene_device.argtypes = [vp]
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]

@@ -325,8 +325,9 @@ class Scene:
     def info(self) -> dict:
         i = _ffi.SceneInfo()
         _ffi.check(self._L.rayrs_scene_info(self._h, C.byref(i)), "rayrs_scene_info")
-        d = {n: getattr(i, n) for n, _ in i._fields_ if n != "root_box"}
+        d = {n: getattr(i, n) for n, _ in i._fields_ if n not in ("root_box", "hot_box")}
         d["root_box"] = list(i.root_box)
+        d["hot_box"] = list(i.hot_box)
         return d
 
     def export_bvh(self):
@@ -356,6 +357,16 @@ class Scene:
         _ffi.check(self._L.rayrs_scene_export_gate_tree(self._h, box.ctypes.data, ref.ctypes.data),
                    "rayrs_scene_export_gate_tree")
         return box[:i["gate_n_wide"]], ref[:i["gate_n_wide"]]
+
+    def export_hot_tree(self):
+        """The gate tree without the scene's hot group (info()["hot_count"] > 0): what the default walk reads there:
+        (box[hot_n_wide,4,6], ref[hot_n_wide,4])."""
+        i = self.info()
+        box = np.zeros((max(i["hot_n_wide"], 1), 4, 6), dtype=np.float64)
+        ref = np.zeros((max(i["hot_n_wide"], 1), 4), dtype=np.uint32)
+        _ffi.check(self._L.rayrs_scene_export_hot_tree(self._h, box.ctypes.data, ref.ctypes.data),
+                   "rayrs_scene_export_hot_tree")
+        return box[:i["hot_n_wide"]], ref[:i["hot_n_wide"]]
 
     def close(self):
         if self._h is not None:

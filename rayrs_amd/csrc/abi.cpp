@@ -197,6 +197,7 @@ extern "C++" void rayrs::scene_free_device(rayrs_scene* s) {
     for (auto& w : s->trav)
         if (w.d_nodes) (void)hipFree(w.d_nodes);
     if (s->d_prims) (void)hipFree(s->d_prims);
+    if (s->d_hot) (void)hipFree(s->d_hot);
     if (s->d_surfaces) (void)hipFree(s->d_surfaces);
     if (s->d_hdri) (void)hipFree(s->d_hdri);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -235,8 +236,8 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 // five workgroups (the kernel's launch bound) share a CU's 160 KiB.
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;
-    for (int x = 0; x < 2; x++) {
-        const WalkTree& t = s->tree(x != 0);
+    for (int x = 0; x < 3; x++) {
+        const WalkTree& t = s->tree(x);
         rayrs_scene::Walk& w = s->trav[x];
         const uint32_t depth = t.depth ? t.depth : 1;
         uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
@@ -295,10 +296,15 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->cu_count = prop.multiProcessorCount;
     const FlatScene& f = s->flat;
-    for (int x = 0; x < 2; x++) {
-        const WalkTree& t = s->tree(x != 0);
+    for (int x = 0; x < 3; x++) {
+        const WalkTree& t = s->tree(x);
+        if (x == 2 && !f.has_hot) continue;
         HIP_TRY(hipMalloc(&s->trav[x].d_nodes, t.node_bytes.size()));
         HIP_TRY(hipMemcpy(s->trav[x].d_nodes, t.node_bytes.data(), t.node_bytes.size(), hipMemcpyHostToDevice));
+    }
+    if (f.has_hot) {
+        HIP_TRY(hipMalloc((void**)&s->d_hot, sizeof(HotGroupDev)));
+        HIP_TRY(hipMemcpy(s->d_hot, &f.hot, sizeof(HotGroupDev), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&s->d_prims, f.prim_bytes.size()));
     HIP_TRY(hipMemcpy(s->d_prims, f.prim_bytes.data(), f.prim_bytes.size(), hipMemcpyHostToDevice));
@@ -309,7 +315,7 @@ extern "C++" int rayrs::scene_upload(rayrs_scene* s) {
     HIP_TRY(hipMemcpy(s->d_hdri, f.hdri_quads.data(), f.hdri_quads.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&s->d_counters, sizeof(Counters)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
+    s->device_bytes = f.walk.node_bytes.size() + f.gate.node_bytes.size() + (f.has_hot ? f.gate_hot.node_bytes.size() : 0) + f.prim_bytes.size() + s->surfaces.size() * sizeof(SurfaceDev) +
                       f.hdri_quads.size() * sizeof(float);
     {
         const int st = scene_configure_traversal(s);
@@ -382,6 +388,14 @@ int rayrs_scene_info(const rayrs_scene* scene, rayrs_scene_info_t* info) {
     info->gate_n_wide = f.gate.n();
     info->gate_root_ref = f.gate.root_ref;
     info->gate_depth = f.gate.depth;
+    if (f.has_hot) {
+        info->hot_n_wide = f.gate_hot.n();
+        info->hot_root_ref = f.gate_hot.root_ref;
+        info->hot_depth = f.gate_hot.depth;
+        info->hot_first = f.hot.first;
+        info->hot_count = f.hot.count;
+        for (int i = 0; i < 6; i++) info->hot_box[i] = f.hot.box[i];
+    }
     info->local_pool = (scene->local_ok && scene->tuning.local_pool != 1u) ? 1u : 0u;
     info->prim_bytes = 4u * (f.compact ? PRIM_DWORDS_COMPACT : PRIM_DWORDS_FULL);
     info->device_bytes = scene->device_bytes;
@@ -411,6 +425,14 @@ int rayrs_scene_export_wide(const rayrs_scene* scene, double* wide_box, uint32_t
 int rayrs_scene_export_gate_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
     if (!scene) return RAYRS_INVALID_ARG;
     const WalkTree& t = scene->flat.gate;
+    if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
+    if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
+    return RAYRS_OK;
+}
+
+int rayrs_scene_export_hot_tree(const rayrs_scene* scene, double* wide_box, uint32_t* wide_ref) {
+    if (!scene || !scene->flat.has_hot) return RAYRS_INVALID_ARG;
+    const WalkTree& t = scene->flat.gate_hot;
     if (wide_box && !t.box.empty()) std::memcpy(wide_box, t.box.data(), t.box.size() * 8);
     if (wide_ref && !t.ref.empty()) std::memcpy(wide_ref, t.ref.data(), t.ref.size() * 4);
     return RAYRS_OK;
@@ -495,6 +517,7 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
+    if (lab->hot_min > 64u || lab->hot_wait > 64u || (lab->hot_group != 0u && lab->hot_group != 0xffffffffu)) return RAYRS_INVALID_ARG;
     if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
@@ -518,6 +541,7 @@ uint32_t rayrs_abi_version(void) { return RAYRS_ABI_VERSION; }
 
 uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     std::vector<uint32_t> t;
+    t.push_back(RAYRS_ABI_VERSION);  // (a binding that validates itself against this table fails on a version change too)
 #define RAYRS_STRUCT(T, N) t.push_back((uint32_t)sizeof(T)), t.push_back(N)
 #define RAYRS_FIELD(T, F) t.push_back((uint32_t)offsetof(T, F))
     RAYRS_STRUCT(rayrs_material, 7);
@@ -531,7 +555,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_camera, origin), RAYRS_FIELD(rayrs_camera, e_x), RAYRS_FIELD(rayrs_camera, e_y);
     RAYRS_FIELD(rayrs_camera, z), RAYRS_FIELD(rayrs_camera, width), RAYRS_FIELD(rayrs_camera, height);
     RAYRS_FIELD(rayrs_camera, ppc), RAYRS_FIELD(rayrs_camera, x_pixels), RAYRS_FIELD(rayrs_camera, y_pixels);
-    RAYRS_STRUCT(rayrs_scene_info_t, 19);
+    RAYRS_STRUCT(rayrs_scene_info_t, 26);
     RAYRS_FIELD(rayrs_scene_info_t, n_objects), RAYRS_FIELD(rayrs_scene_info_t, n_interior);
     RAYRS_FIELD(rayrs_scene_info_t, n_prims), RAYRS_FIELD(rayrs_scene_info_t, root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, depth), RAYRS_FIELD(rayrs_scene_info_t, compact);
@@ -542,13 +566,17 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_scene_info_t, wide_depth), RAYRS_FIELD(rayrs_scene_info_t, local_pool);
     RAYRS_FIELD(rayrs_scene_info_t, gate_n_wide), RAYRS_FIELD(rayrs_scene_info_t, gate_root_ref);
     RAYRS_FIELD(rayrs_scene_info_t, gate_depth);
+    RAYRS_FIELD(rayrs_scene_info_t, hot_n_wide), RAYRS_FIELD(rayrs_scene_info_t, hot_root_ref);
+    RAYRS_FIELD(rayrs_scene_info_t, hot_depth), RAYRS_FIELD(rayrs_scene_info_t, hot_first);
+    RAYRS_FIELD(rayrs_scene_info_t, hot_count), RAYRS_FIELD(rayrs_scene_info_t, hot_pad);
+    RAYRS_FIELD(rayrs_scene_info_t, hot_box);
     RAYRS_STRUCT(rayrs_render_params, 9);
     RAYRS_FIELD(rayrs_render_params, spp), RAYRS_FIELD(rayrs_render_params, max_bounces);
     RAYRS_FIELD(rayrs_render_params, seed), RAYRS_FIELD(rayrs_render_params, sample_chunk);
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
     RAYRS_FIELD(rayrs_render_params, fast_traversal);
-    RAYRS_STRUCT(rayrs_render_stats, 26);
+    RAYRS_STRUCT(rayrs_render_stats, 33);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -562,6 +590,10 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, surface_hits), RAYRS_FIELD(rayrs_render_stats, direct_rays);
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, exact_walk);
+    RAYRS_FIELD(rayrs_render_stats, hot_group), RAYRS_FIELD(rayrs_render_stats, stats_pad);
+    RAYRS_FIELD(rayrs_render_stats, hot_wave), RAYRS_FIELD(rayrs_render_stats, hot_lane);
+    RAYRS_FIELD(rayrs_render_stats, hot_ticks);
+    RAYRS_FIELD(rayrs_render_stats, hot_prim_tests), RAYRS_FIELD(rayrs_render_stats, hot_tri_divided);
     RAYRS_STRUCT(rayrs_tuning, 2);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
 #undef RAYRS_STRUCT
@@ -582,9 +614,10 @@ int rayrs_camera_new(const double origin[3], const double up[3], const double lo
 static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     SceneDev sc;
     std::memset(&sc, 0, sizeof(sc));
-    const bool gate = exact || s->lab.gate_tree != 0u;
-    const WalkTree& t = s->tree(gate);
-    const rayrs_scene::Walk& w = s->trav[gate ? 1 : 0];
+    const int which = s->walk_index(exact);
+    const WalkTree& t = s->tree(which);
+    const rayrs_scene::Walk& w = s->trav[which];
+    sc.hot = which == 2 ? s->d_hot : nullptr;
     sc.nodes = w.d_nodes;
     sc.prims = s->d_prims;
     sc.surfaces = s->d_surfaces;
@@ -610,10 +643,11 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
 // fast_traversal; profiles/r04_tight_leaves.txt).  What decides is the distance in PRIMITIVE sizes (the error of the
 // computed hit point is about eps * distance / angle against a widening of 1/64 of the primitive): failures were seen from
 // 6,000 primitive sizes up, none within 4,000 (sheets of 6 ... 400 quads per side: scripts/fuzz_traversal.py).
-// Bounce rays start on the scene's surfaces; only a camera can stand far out.  So the bet is only made where it was
-// measured: a frame whose camera is farther from the root Node's box than RAYRS_FAR_DIAGONALS times that box's diagonal,
-// or than RAYRS_FAR_PRIMITIVES times the scene's small primitives (the 5th percentile of their largest extents), takes
-// the default walk whatever was asked (rayrs_render_stats.exact_walk says which walk a frame took).
+// A frame whose camera is farther from the root Node's box than RAYRS_FAR_DIAGONALS times that box's diagonal, or than
+// RAYRS_FAR_PRIMITIVES times the scene's small primitives (the 5th percentile of their largest extents), takes the
+// default walk whatever was asked (rayrs_render_stats.exact_walk says which walk a frame took).  This guards PRIMARY
+// rays only: a bounced ray from a large surface to a finely tessellated one (the headline scene's floor to its mesh)
+// is thousands of small-primitive sizes long and makes the bet all the same -- the fast walk stays a bet.
 constexpr double RAYRS_FAR_DIAGONALS = 8.0;
 constexpr double RAYRS_FAR_PRIMITIVES = 4096.0;
 static bool camera_is_far(const rayrs_scene* s, const rayrs_camera* c) {
@@ -722,6 +756,8 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const bool exact = params->fast_traversal == 0u || camera_is_far(scene, camera);
     scene->last_exact = exact;
     rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
+    rp.hot_min = lab.hot_min ? lab.hot_min : 40u;
+    rp.hot_wait = lab.hot_wait ? lab.hot_wait : 8u;
     const SceneDev sc = make_scene_dev(scene, exact);
     const CameraDev cam = make_camera_dev(camera);
 
@@ -749,7 +785,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool compact = scene->flat.compact;
     const bool count = params->count_work != 0;
-    uint32_t trav_bpc = (uint32_t)scene->trav[(exact || lab.gate_tree) ? 1 : 0].blocks_per_cu;
+    uint32_t trav_bpc = (uint32_t)scene->trav[scene->walk_index(exact)].blocks_per_cu;
     if (lab.trav_blocks_per_cu && lab.trav_blocks_per_cu < trav_bpc) trav_bpc = lab.trav_blocks_per_cu;
     const uint32_t trav_blocks = (uint32_t)scene->cu_count * trav_bpc;
     uint32_t static_pct = lab.static_pct ? lab.static_pct : 50u;
@@ -956,6 +992,8 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         stats->direct_rays = c.direct_rays;
+        stats->hot_wave = c.hot_wave, stats->hot_lane = c.hot_lane, stats->hot_ticks = c.hot_ticks;
+        stats->hot_prim_tests = c.hot_prim_tests, stats->hot_tri_divided = c.hot_tri_divided;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));
         stats->trace_ms = ms;
@@ -981,6 +1019,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->hit_ms = h, stats->miss_ms = m;
         stats->local_pool = scene->last_local ? 1u : 0u;
         stats->exact_walk = (scene->last_exact || scene->last_local) ? 1u : 0u;
+        stats->hot_group = (!scene->last_local && scene->last_exact && scene->walk_index(true) == 2) ? 1u : 0u;
         stats->kernel_launches = (uint64_t)scene->rounds;
     }
     return RAYRS_OK;

@@ -266,6 +266,13 @@ struct WorkCount {
     uint32_t leaf_prims;  // primitives of the last leaf visited in a macro step
 };
 
+// What the hot-group step counts, per wave (scalar registers: ballots and popcounts, no lane counters).
+struct HotTally {
+    uint32_t owed;      // rays that were put to the group's gating box
+    uint32_t entered;   // ... and entered it: each tests every primitive of the group
+    uint32_t divided;   // triangle tests that went on to the three divisions (not settled before them)
+};
+
 RR_DEV double f32bits_to_f64(uint32_t u) { return (double)__uint_as_float(u); }
 
 // Bvh::intersect (bvh.rs:212-214, :391-415) as a resumable per-lane state
@@ -518,12 +525,151 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
+// ------------------------------------------------------- the hot group (layout.h HotGroupDev)
+
+// Read with scalar loads: the data is the same for every lane, and a load through the constant address space with a
+// wave-uniform address is one s_load for the wave -- its values are scalar operands of the vector arithmetic below,
+// no vector register holds them and nothing is converted.
+typedef const __attribute__((address_space(4))) HotGroupDev* HotPtr;
+RR_DEV HotPtr hot_ptr(const SceneDev& sc) { return (HotPtr)sc.hot; }
+
+// Triangle::intersect (geometry.rs:359-375) on a wave-uniform triangle -- p1 and the e1 = p2 - p1, e2 = p3 - p1 that
+// Triangle::new stores (geometry.rs:342-343) -- with the three divisions made only if some lane of the wave needs them.
+//
+// What the reference decides first is `d < 0. || u < 0. || v < 0. || u + v > 1.` on the three quotients
+// d = n0 / den, u = n1 / den, v = n2 / den.  IEEE-754 division is correctly rounded (on this chip too:
+// tests/test_gpu_functions.py), so two facts about a quotient q = fl(n / den) need no division:
+//   (S) q < 0 holds if n and den have opposite sign bits, |n| >= 2^-500 (which a NaN is not, and an infinity is) and
+//       |den| <= 2^500 (a zero is, a NaN or an infinity is not): for den = +-0 the quotient is the infinity of the
+//       product's sign, -inf; for an infinite n and such a den likewise; otherwise the exact quotient is negative and at
+//       least 2^-1000 in magnitude, and rounding to nearest keeps both;
+//   (B) q >= 2 holds if n and den have equal sign bits, 2^-500 <= |den| <= 2^500 and |n| >= 2 |den| (2 |den| is exact): the
+//       exact quotient is >= 2, 2 is a double, rounding is monotone (+inf included).
+// (S) for any of the three numerators rejects the ray.  (B) for u rejects it if v is a number -- |n2| <= 2^500 with
+// such a den makes it a finite one: either v < 0, or v >= 0 (a zero of either sign included) and then fl(u + v) >= 2 > 1
+// by monotonicity again -- and the same with u and v exchanged.  A ray that passes a small triangle at a distance
+// has barycentric coordinates far outside [0, 2), so whole waves leave here, after the two cross products and four
+// dot products that the reference computes as well; a wave in which some lane is not settled goes on to the
+// divisions with every lane, whose compares then reject the settled lanes again (same test, same verdict).
+// The numbers on the hot path are the reference's: same operands, same operations, same order.
+RR_DEV bool hot_triangle_intersect(V3 p1, V3 e1, V3 e2, V3 o, V3 d, bool live, double& t, HotTally& ht) {
+    const V3 tt = v_sub(o, p1);
+    const V3 p = v_cross(d, e2);
+    const V3 q = v_cross(tt, e1);
+    const double den = v_dot(p, e1);
+    const double n0 = v_dot(q, e2), n1 = v_dot(p, tt), n2 = v_dot(q, d);
+    {
+        const uint32_t dh = (uint32_t)(rr_f64_bits(den) >> 32);
+        const unsigned long long opp0 = __builtin_amdgcn_ballot_w64((int)((uint32_t)(rr_f64_bits(n0) >> 32) ^ dh) < 0);
+        const unsigned long long opp1 = __builtin_amdgcn_ballot_w64((int)((uint32_t)(rr_f64_bits(n1) >> 32) ^ dh) < 0);
+        const unsigned long long opp2 = __builtin_amdgcn_ballot_w64((int)((uint32_t)(rr_f64_bits(n2) >> 32) ^ dh) < 0);
+        const double aden = rr_fabs(den), a0 = rr_fabs(n0), a1 = rr_fabs(n1), a2 = rr_fabs(n2);
+        const unsigned long long den_le = __builtin_amdgcn_ballot_w64(aden <= 0x1p500);
+        const unsigned long long den_ge = __builtin_amdgcn_ballot_w64(aden >= 0x1p-500);
+        const unsigned long long big0 = __builtin_amdgcn_ballot_w64(a0 >= 0x1p-500);
+        const unsigned long long big1 = __builtin_amdgcn_ballot_w64(a1 >= 0x1p-500);
+        const unsigned long long big2 = __builtin_amdgcn_ballot_w64(a2 >= 0x1p-500);
+        const unsigned long long fin1 = __builtin_amdgcn_ballot_w64(a1 <= 0x1p500);
+        const unsigned long long fin2 = __builtin_amdgcn_ballot_w64(a2 <= 0x1p500);
+        const double two_den = aden * 2.0;
+        const unsigned long long two1 = __builtin_amdgcn_ballot_w64(a1 >= two_den);
+        const unsigned long long two2 = __builtin_amdgcn_ballot_w64(a2 >= two_den);
+        const unsigned long long settled = (den_le & ((opp0 & big0) | (opp1 & big1) | (opp2 & big2))) |
+                                           (den_le & den_ge & ((~opp1 & two1 & fin2) | (~opp2 & two2 & fin1)));
+        if ((__builtin_amdgcn_ballot_w64(live) & ~settled) == 0ull) return false;
+    }
+    ht.divided += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
+    double dd, u, v;
+    div3_by(n0, n1, n2, den, dd, u, v);
+    const unsigned long long out = __builtin_amdgcn_ballot_w64(dd < 0.0) | __builtin_amdgcn_ballot_w64(u < 0.0) |
+                                   __builtin_amdgcn_ballot_w64(v < 0.0) | __builtin_amdgcn_ballot_w64(u + v > 1.0);
+    if (__builtin_amdgcn_inverse_ballot_w64(out)) return false;
+    t = dd;
+    return true;
+}
+
+// What BvhTree::intersect does with the hot group (bvh.rs:396-410): the gating box, and if the ray enters it, the
+// group's primitives in depth-first order.  Every lane of the wave that owes the test runs it here, once per ray, at
+// whatever point of its walk: the closest hit is the smallest accepted t, the first primitive in depth-first order on
+// exact ties (bvh.rs:62), in any visiting order.  `owe` lanes only; the others idle.
+// AxisAlignedBoundingBox::intersect (geometry.rs:458-513) on a wave-uniform box, as slab() computes it: the near / far
+// bound is chosen by the sign of 1 / d -- here after the two products instead of before (the same two products either way).
+RR_DEV bool uniform_box_entered(double x0, double x1, double y0, double y1, double z0, double z1, V3 o, V3 inv, double tmin,
+                                double tmax) {
+    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+    const double ax = (x0 - o.x) * inv.x, bx = (x1 - o.x) * inv.x;
+    const double ay = (y0 - o.y) * inv.y, by = (y1 - o.y) * inv.y;
+    const double az = (z0 - o.z) * inv.z, bz = (z1 - o.z) * inv.z;
+    double lo = tmin, hi = tmax;
+    lo = rr_max(lo, nx ? bx : ax), hi = rr_min(hi, nx ? ax : bx);
+    lo = rr_max(lo, ny ? by : ay), hi = rr_min(hi, ny ? ay : by);
+    lo = rr_max(lo, nz ? bz : az), hi = rr_min(hi, nz ? az : bz);
+    return !(hi <= lo);
+}
+
+template <bool COUNT>
+RR_DEV void hot_group_step(const SceneDev& sc, V3 o, V3 d, bool owe, Trav& tv, WorkCount& wc, HotTally& ht) {
+    const HotPtr h = hot_ptr(sc);
+    const double tmin = sc.t0, tmax = sc.t1;
+    const V3 inv = tv.inv;
+    const bool entered = owe && uniform_box_entered(h->box[0], h->box[1], h->box[2], h->box[3], h->box[4], h->box[5], o, inv, tmin, tmax);
+    const unsigned long long entered_mask = __builtin_amdgcn_ballot_w64(entered);
+    ht.owed += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(owe));
+    ht.entered += (uint32_t)__popcll(entered_mask);
+    if (entered_mask == 0ull) return;
+    const uint32_t first = h->first, count = h->count;
+#pragma nounroll
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t tag = h->prim[k].tag;
+        const uint32_t kind = tag & 3u;
+        double t = 0.0;
+        bool hit;
+        if (kind == PRIM_TRIANGLE) {
+            if (COUNT && entered) wc.tri++;
+            hit = hot_triangle_intersect(mk(h->prim[k].v[0], h->prim[k].v[1], h->prim[k].v[2]),
+                                         mk(h->prim[k].v[3], h->prim[k].v[4], h->prim[k].v[5]),
+                                         mk(h->prim[k].v[6], h->prim[k].v[7], h->prim[k].v[8]), o, d, entered, t, ht);
+        } else if (kind == PRIM_SPHERE) {
+            if (COUNT && entered) wc.sphere++;
+            hit = sphere_intersect(h->prim[k].v[0], mk(h->prim[k].v[1], h->prim[k].v[2], h->prim[k].v[3]), o, d, t);
+        } else {
+            if (COUNT && entered) wc.plane++;
+            hit = plane_intersect((tag >> 2) & 7u, h->prim[k].v[0], h->prim[k].v[1], h->prim[k].v[2], h->prim[k].v[3],
+                                  h->prim[k].v[4], o, d, t);
+        }
+        const uint32_t p = first + k;
+        if (entered && hit && t > tmin && t < tmax) {                     // bvh.rs:406
+            if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {  // bvh.rs:62
+                tv.best_t = t;
+                tv.best_prim = p;
+            }
+        }
+    }
+}
+
+// The first record of the tree without the hot group (HotGroupDev::root_box, the f64 values its record holds): does the ray
+// enter any of its four slots?  The same test, on the same values, that trav_interior_step makes of that record.
+RR_DEV bool hot_root_record_entered(const SceneDev& sc, V3 o, V3 inv) {
+    const HotPtr h = hot_ptr(sc);
+    const double tmin = sc.t0, tmax = sc.t1;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        any |= uniform_box_entered(h->root_box[c][0], h->root_box[c][1], h->root_box[c][2], h->root_box[c][3], h->root_box[c][4],
+                                   h->root_box[c][5], o, inv, tmin, tmax);
+    return any;
+}
+
 template <bool COMPACT, bool COUNT, bool EXACT = false>
 RR_DEV bool bvh_intersect(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, double& t_hit, uint32_t& prim_hit,
                           WorkCount& wc) {
     Trav tv;
     trav_init(sc, o, d, tv);
     const HotNodes hot{nullptr, 0u};
+    // (the default walk on a scene with a hot group: every ray that enters the root box owes the group its test; the
+    // wave-level calls inside need every lane of the wave here, so the branch is on the wave-uniform pointer only)
+    HotTally ht{0, 0, 0};
+    if (EXACT && sc.hot != nullptr) hot_group_step<COUNT>(sc, o, d, tv.cur != TRAV_DONE, tv, wc, ht);
     while (tv.cur != TRAV_DONE) {
         if (trav_at_interior(tv))
             trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);

@@ -88,6 +88,33 @@ struct SurfaceDev {
     int32_t pad;
 };
 
+// The HOT GROUP of the default walk (scene_host.cpp pick_hot_group, device_path.h hot_group_step): one leaf group of the
+// reference's tree whose gating box covers most of the root Node's box -- on the benchmark scenes the 50 x 50 floor and
+// the three mesh triangles that share its bottom Node, which 89 % of all rays enter.  It is taken out of the tree the
+// default walk reads and tested once per ray, by all the lanes of a wave that owe the test together: the same gating-box
+// test and the same primitive tests on the same f64 values as BvhTree::intersect makes (bvh.rs:391-415), but on
+// wave-uniform data -- read with scalar loads, nothing converted, e1 = p2 - p1 and e2 = p3 - p1 formed on the host as
+// Triangle::new forms them (geometry.rs:342-343).
+struct HotPrim {       // 80 B
+    double v[9];       // triangle: p1, e1, e2 | sphere: radius^2, centre | rectangle: umin, umax, vmin, vmax, pos
+    uint32_t tag;      // the primitive record's tag (kind | axis << 2 | surface << 8)
+    uint32_t pad;
+};
+struct HotGroupDev {
+    double box[6];     // the group's gating box, as the reference tests it
+    uint32_t first;    // DFS index of the group's first primitive
+    uint32_t count;    // 1..4
+    uint32_t pad[2];
+    HotPrim prim[4];
+    // the root record of the tree without the group (FlatScene::gate_hot), as f64: the kernel that MAKES a ray tests the
+    // group and these four boxes for it (wavefront.hip finish_rays); a ray that enters none of them has its answer
+    // there and never travels through the traversal kernel.  Unused slots hold the inverted box.
+    double root_box[4][6];
+    uint32_t root_ref[4];
+    uint32_t n_tri, n_sphere, n_plane, pad1;  // kinds among the group's primitives (work counters)
+};
+static_assert(sizeof(HotPrim) == 80 && sizeof(HotGroupDev) == 384 + 192 + 32, "HotGroupDev");
+
 struct SceneDev {
     const void* nodes;
     const void* prims;
@@ -107,6 +134,8 @@ struct SceneDev {
     // the default walk (rayrs_render_params.fast_traversal == 0): nothing is culled by the closest hit so far, as BvhTree::intersect
     // (bvh.rs:391-415); selects the EXACT instances of the kernels (device_path.h trav_interior_step)
     uint32_t exact, pad1;
+    // the default walk's hot group, or null: then `nodes` is the whole gate tree (HotGroupDev above)
+    const HotGroupDev* hot;
 };
 
 struct CameraDev {
@@ -124,6 +153,8 @@ struct Counters {
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
+    unsigned long long hot_prim_tests, hot_tri_divided;  // of the primitive tests: made in the hot-group phase; of its triangle tests: with the divisions made
+    unsigned long long hot_wave, hot_lane, hot_ticks;  // the hot-group phase (count_work only): executions x 64, lanes that owed the test, shader clock
 #ifdef RAYRS_LAB_TICKS
     unsigned long long lab_ticks[16];  // development build only (make LAB=1): shader-clock shares of the hit / miss loops
 #endif
@@ -140,6 +171,7 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
+    uint32_t hot_min, hot_wait;     // ... of the hot-group phase: run it once hot_min lanes owe the test, or hot_wait of them have nothing else left to do
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)

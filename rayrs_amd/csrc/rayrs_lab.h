@@ -35,6 +35,10 @@ typedef struct {
     uint32_t gate_tree;     /* 1 = the fast walk (with closest-hit culling) over the gate tree instead of the tree
                                of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
                                profiles/r04_tight_leaves.txt */
+    uint32_t hot_group;     /* 0xffffffff = the default walk reads the whole gate tree also where the scene has a hot group
+                               (layout.h HotGroupDev): the walk of round 5, kept for the same-box A/B */
+    uint32_t hot_min;       /* traversal: run the hot-group phase once this many lanes owe the test (40) */
+    uint32_t hot_wait;      /* ... or once this many of them have finished their walk and wait for nothing else (8) */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

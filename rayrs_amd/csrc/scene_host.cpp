@@ -652,6 +652,41 @@ void build_tree_over(const std::vector<WalkGroup>& leaves, WalkTree& t) {
     front_largest(t);
 }
 
+// The hot group (layout.h HotGroupDev): the group whose gating box has the largest surface area, if that is at least
+// HOT_MIN_AREA of the root Node's box -- a ray that enters the root box enters a box inside it with probability about
+// the ratio of their areas, so such a group is one most rays test whatever else they meet, and its slot in the tree's
+// top record is a test every ray makes anyway.  Taken out of the tree, the rest is built as before (gate_hot): the
+// leaves of gate_hot and the hot group together are exactly the groups of the gate tree, each behind exactly its
+// gating box (tests/test_bvh_builder.py checks that from the exports).  Scenes of a handful of groups keep the one tree:
+// they take the local-pool route or walk two or three records.
+constexpr double HOT_MIN_AREA = 0.25;
+constexpr size_t HOT_MIN_GROUPS = 8;
+
+void pick_hot_group(FlatScene& f, const std::vector<WalkGroup>& groups) {
+    f.has_hot = false;
+    f.gate_hot = WalkTree();
+    std::memset(&f.hot, 0, sizeof(f.hot));
+    if (groups.size() < HOT_MIN_GROUPS) return;
+    size_t best = 0;
+    double best_area = -1.0;
+    for (size_t i = 0; i < groups.size(); i++) {
+        const double a = box_area(groups[i].box);
+        if (a > best_area) best_area = a, best = i;  // (not a number: never larger; ties: the first in depth-first order)
+    }
+    const double root_area = box_area(f.root_box);
+    if (!(best_area >= HOT_MIN_AREA * root_area) || !std::isfinite(best_area)) return;
+    std::vector<WalkGroup> rest;
+    rest.reserve(groups.size() - 1);
+    for (size_t i = 0; i < groups.size(); i++)
+        if (i != best) rest.push_back(groups[i]);
+    build_tree_over(rest, f.gate_hot);
+    const WalkGroup& g = groups[best];
+    for (int k = 0; k < 6; k++) f.hot.box[k] = g.box[k];
+    f.hot.first = (g.ref & 0x3fffffffu) >> 2;
+    f.hot.count = (g.ref & 3u) + 1u;
+    f.has_hot = true;  // (the primitives' values are filled in by build_flat_scene, which has the objects)
+}
+
 // prim_box[p]: the reference's bounding box of the object behind primitive record p
 void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
     f.walk = WalkTree();
@@ -663,6 +698,7 @@ void build_walk_trees(FlatScene& f, const std::vector<Aabb>& prim_box) {
     std::vector<WalkGroup> groups;
     collect_groups(f, f.root_ref & 0x3fffffffu, f.root_box, groups);
     build_tree_over(groups, f.gate);
+    pick_hot_group(f, groups);
     std::vector<WalkGroup> singles;
     split_groups(groups, prim_box, singles);
     build_tree_over(singles, f.walk);
@@ -745,7 +781,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
     }
 
     // ---- choose the layout
-    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk);
+    bool compact = boxes_f32_exact(f.gate) && boxes_f32_exact(f.walk) && boxes_f32_exact(f.gate_hot);
     for (size_t i = 0; i < n && compact; i++) {
         const Shape& s = objs.objs[i].geom;
         if (s.kind != PRIM_TRIANGLE) continue;
@@ -757,7 +793,7 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
             }
     }
     f.compact = compact;
-    for (WalkTree* t : {&f.gate, &f.walk}) {
+    for (WalkTree* t : {&f.gate, &f.walk, &f.gate_hot}) {
         if (compact) fill_nodes<Node4F32, float>(*t);
         else fill_nodes<Node4F64, double>(*t);
     }
@@ -791,6 +827,38 @@ int build_flat_scene(const ObjectList& objs, double z_near, double z_far, int he
             }
         }
         rec[dw - 1] = s.kind | (s.axis << 2) | (o.surface << 8);
+    }
+
+    // ---- the hot group's primitives as f64 values (Triangle::new's e1, e2: geometry.rs:342-343)
+    if (f.has_hot) {
+        for (uint32_t k = 0; k < f.hot.count; k++) {
+            const Object& o = objs.objs[f.prim_object[f.hot.first + k]];
+            const Shape& s = o.geom;
+            HotPrim& hp = f.hot.prim[k];
+            if (s.kind == PRIM_SPHERE) {
+                hp.v[0] = s.radius2, hp.v[1] = s.origin.x, hp.v[2] = s.origin.y, hp.v[3] = s.origin.z;
+            } else if (s.kind == PRIM_PLANE) {
+                hp.v[0] = s.u0, hp.v[1] = s.u1, hp.v[2] = s.v0, hp.v[3] = s.v1, hp.v[4] = s.pos;
+            } else {
+                hp.v[0] = s.p1.x, hp.v[1] = s.p1.y, hp.v[2] = s.p1.z;
+                hp.v[3] = s.p2.x - s.p1.x, hp.v[4] = s.p2.y - s.p1.y, hp.v[5] = s.p2.z - s.p1.z;
+                hp.v[6] = s.p3.x - s.p1.x, hp.v[7] = s.p3.y - s.p1.y, hp.v[8] = s.p3.z - s.p1.z;
+            }
+            hp.tag = s.kind | (s.axis << 2) | (o.surface << 8);
+            if (s.kind == PRIM_SPHERE) f.hot.n_sphere++;
+            else if (s.kind == PRIM_PLANE) f.hot.n_plane++;
+            else f.hot.n_tri++;
+        }
+        // the root record of the tree without the group, as the kernels' records hold it (fill_nodes)
+        const WalkTree& t = f.gate_hot;
+        const uint32_t r = t.root_ref & 0x3fffffffu;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (int ch = 0; ch < 4; ch++) {
+            const uint32_t ref = t.ref[(size_t)r * 4 + ch];
+            f.hot.root_ref[ch] = ref;
+            for (int k = 0; k < 6; k++)
+                f.hot.root_box[ch][k] = (ref >> 30) == REF_NONE ? ((k & 1) ? -inf : inf) : t.box[((size_t)r * 4 + ch) * 6 + k];
+        }
     }
 
     // ---- HDRI: clip(0, 3) (main.rs:43; clip = min(max).max(min), vecmath.rs:388-396), then one record per

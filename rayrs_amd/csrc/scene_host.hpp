@@ -65,7 +65,11 @@ struct FlatScene {
     //   gate  the reference's leaf groups behind their exact gating boxes -- reaches exactly what the reference
     //         reaches; the default walk's tree, and where the local-pool route's gates come from;
     //   walk  single primitives behind their own widened boxes inside the gating box (rayrs_render_params.fast_traversal).
-    WalkTree walk, gate;
+    //   gate_hot  the gate tree without the scene's HOT GROUP (layout.h HotGroupDev; has_hot), which the default walk's
+    //         kernels test once per ray outside the tree -- gate_hot's groups + the hot group = gate's groups.
+    WalkTree walk, gate, gate_hot;
+    bool has_hot = false;
+    HotGroupDev hot = {};
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     bool compact = false;
     // device images (the trees' records are in WalkTree::node_bytes)

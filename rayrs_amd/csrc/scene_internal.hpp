@@ -40,8 +40,16 @@ struct rayrs_scene {
         uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
         uint32_t hot_records = 0;    // leading records kept in LDS
     };
-    Walk trav[2];
-    const rayrs::WalkTree& tree(bool exact) const { return exact ? flat.gate : flat.walk; }
+    // [2] FlatScene::gate_hot (the default walk on a scene with a hot group: layout.h HotGroupDev).
+    Walk trav[3];
+    const rayrs::WalkTree& tree(int which) const { return which == 2 ? flat.gate_hot : which == 1 ? flat.gate : flat.walk; }
+    rayrs::HotGroupDev* d_hot = nullptr;
+    // which of the three a frame walks: the fast walk [0] (or [1] with rayrs_lab_tuning.gate_tree), the default walk [2] if the
+    // scene has a hot group and the lab has not switched it off, else [1]
+    int walk_index(bool exact) const {
+        if (!exact) return lab.gate_tree ? 1 : 0;
+        return (flat.has_hot && lab.hot_group != 0xffffffffu) ? 2 : 1;
+    }
     uint64_t device_bytes = 0;
     // The path pool of the streaming route (abi.cpp rayrs_render_launch): slots, state bytes, control words,
     // per-wave item ranges and traversal-stack overflow strips, kept between renders.

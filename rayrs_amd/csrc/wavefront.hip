@@ -430,7 +430,12 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-template <bool COMPACT, bool COUNT, bool EXACT>
+// HOT (the default walk on a scene with a hot group, layout.h HotGroupDev): a third phase kind.  Every ray that enters
+// the root box OWES the hot group its test -- gating box, then the group's primitives (device_path.h hot_group_step) -- once,
+// at any point of its walk; the lane walks the tree meanwhile.  The phase runs for all the lanes that owe it together:
+// once rp.hot_min of them do, or once rp.hot_wait of them have finished their walk and wait for nothing else (a lane is
+// retired only when it owes nothing), or when the wave has nothing else to do.
+template <bool COMPACT, bool COUNT, bool EXACT, bool HOT>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -468,6 +473,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
     bool active = false, pending = false;
+    bool owe = false;  // HOT: the lane's ray has not been through the hot group yet
     uint32_t slot = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     Trav tv;
@@ -475,16 +481,38 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
-    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
+    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_hot = 0, tk_last = COUNT ? clock64() : 0ull;
+    unsigned long long u_hot_wave = 0, u_hot_lane = 0;
+    HotTally ht{0, 0, 0};
 
     for (;;) {
         const bool at_int = active && trav_at_interior(tv);
         const bool at_leaf = active && !trav_at_interior(tv);
         const int n_int = __popcll(__ballot(at_int));
         const int n_leaf = __popcll(__ballot(at_leaf));
-        if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
-            // ---- retire finished queries: result and new state to the slot
-            if (pending) {
+        int n_wait = 0;  // HOT: lanes whose walk has ended but which still owe the hot group its test: neither retired nor refilled
+        if (HOT) {
+            const unsigned long long owe_mask = __ballot(owe);
+            if (owe_mask != 0ull) {
+                const int n_owe = __popcll(owe_mask);
+                n_wait = __popcll(__ballot(owe && !active));
+                if (n_owe >= (int)rp.hot_min || n_wait >= (int)rp.hot_wait || n_int + n_leaf == 0) {
+                    // ---- hot-group phase: every lane that owes the test
+                    if (COUNT) u_hot_wave += 1, u_hot_lane += owe ? 1 : 0;
+                    hot_group_step<COUNT>(sc, o, d, owe, tv, wc, ht);
+                    owe = false;
+                    if (COUNT) {
+                        const unsigned long long now = clock64();
+                        tk_hot += now - tk_last, tk_last = now;
+                    }
+                    continue;
+                }
+            }
+        }
+        // (waiting lanes count as occupied: a refill must find lanes to fill, or the wave would come back here for ever)
+        if ((n_int + n_leaf + n_wait < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
+            // ---- retire finished queries: result and new state to the slot (HOT: of lanes that owe nothing)
+            if (pending && !(HOT && owe)) {
                 const bool hit = tv.best_prim != 0xffffffffu;
                 if (hit) {  // (a MISS says it all: nothing reads t or prim of such a slot, and its line stays clean)
                     RaySlot* rs = ray_slot(wf, slot);
@@ -496,7 +524,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             }
             if (no_more) break;  // only reached with no query in flight
             // ---- idle lanes take rays from the wave's window list
-            bool need = !active;
+            bool need = !active && !pending;
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
@@ -528,7 +556,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                     if (tv.cur == TRAV_DONE)
                         pending = true;  // missed the root box: retired at the next refill
                     else
-                        active = true;
+                        active = true, owe = HOT;
                     need = false;
                 }
                 const uint32_t wanted = (uint32_t)__popcll(need_mask);
@@ -579,6 +607,11 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         if (lane == 0) {
             atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
             atomicAdd(&c->refill_ticks, tk_refill);
+            if (HOT) atomicAdd(&c->hot_ticks, tk_hot);
+        }
+        if (HOT) {
+            wave_atomic_add(&c->hot_wave, u_hot_wave), wave_atomic_add(&c->hot_lane, u_hot_lane);
+            if (lane == 0) atomicAdd(&c->hot_prim_tests, (unsigned long long)ht.entered * hot_ptr(sc)->count), atomicAdd(&c->hot_tri_divided, (unsigned long long)ht.divided);
         }
     }
 }
@@ -876,8 +909,9 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
-    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (sc.exact && sc.hot) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();
 }
 
@@ -892,10 +926,13 @@ hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const Re
 
 template <bool COMPACT, bool COUNT>
 static hipError_t trav_set_lds(uint32_t lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel<COMPACT, COUNT, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -905,11 +942,11 @@ hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_reco
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, false>, 256, lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<true, false, false, false>, 256, lds);
     }
     if ((e = trav_set_lds<false, false>(lds)) != hipSuccess) return e;
     if ((e = trav_set_lds<false, true>(lds)) != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, false>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, wf_trav_kernel<false, false, false, false>, 256, lds);
 }
 
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp,

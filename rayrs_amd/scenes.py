@@ -8,6 +8,8 @@ Resolutions: the reference derives pixels from (width cm, height cm, ppi)
 (lib.rs:113, :153-177); `camera_for_resolution` picks ppi = 100 (ppc 254) and
 width = W/254 cm, height = H/254 cm so that x_pixels = W and y_pixels = H.
 """
+import os
+
 from . import procedural
 from .api import Axis, BvhHeuristic, Emission, Fresnel, Material, Object
 
@@ -102,19 +104,33 @@ def material_test():  # :276-331
 
 # ---- mesh scenes (obj_scene, test_scenes.rs:70-109, with a generated mesh)
 
-def mesh_scene(level: int, mat=None, area_light: bool = False, ply_path=None):
+def write_mesh_ply(level: int, ply_path):
+    """The mesh of mesh_scene(level) as a binary PLY file (written to a temporary name and renamed: a reader never
+    sees half a file)."""
+    from . import io
+    verts, idx = procedural.blob_mesh(level)
+    tmp = f"{ply_path}.{os.getpid()}.tmp"
+    io.save_ply(tmp, verts, idx, binary=True)
+    os.replace(tmp, ply_path)
+
+
+def mesh_scene(level: int, mat=None, area_light: bool = False, ply_path=None, ply_exists: bool = False):
     """Floor + one closed mesh of 20 * 4**level triangles (+ an emissive
     rectangle).  The light is a Lambertian plane with Emission::Emissive: an
     emitter whose material does not scatter contributes nothing (lib.rs:550).
     With ply_path the mesh is written to that PLY file and read back through the
-    library's PLY loader, which is how a real scanned model would arrive."""
+    library's PLY loader, which is how a real scanned model would arrive
+    (ply_exists: somebody has written it -- write_mesh_ply -- and it is only read:
+    the ranks of a node share one file)."""
     if mat is None:
         mat = Material.CookTorrance((1, 1, 1), 0.05, Fresnel.SchlickMetallic((0.722, 0.451, 0.2)))  # copper_suzanne
-    verts, idx = procedural.blob_mesh(level)
     if ply_path is not None:
         from . import io
-        io.save_ply(ply_path, verts, idx, binary=True)
+        if not ply_exists:
+            write_mesh_ply(level, ply_path)
         verts, idx = io.load_ply(ply_path)
+    else:
+        verts, idx = procedural.blob_mesh(level)
     objs = [_floor()]
     objs += Object.from_triangles(verts, idx, mat, Emission.Dark())
     if area_light:
@@ -130,7 +146,15 @@ MESH_CLOSE_CAM = ((0.0, 2.1, 3.3), (0.0, 1.0, 0.0), (0.0, 1.2, 0.0), 40.0, 1920.
 
 # ---- the benchmark configurations of BASELINE.json
 
-def config(n: int, ply_path=None):
+CONFIG_MESH_LEVEL = {3: 6, 5: 8}
+
+
+def write_config_ply(n: int, ply_path):
+    """The PLY file config(n, ply_path, ply_exists=True) reads (configs 3 and 5)."""
+    write_mesh_ply(CONFIG_MESH_LEVEL[n], ply_path)
+
+
+def config(n: int, ply_path=None, ply_exists: bool = False):
     """(camera_args, objects, heuristic, spp, max_bounces) of configs[n-1]."""
     if n == 1:  # single diffuse sphere, 256x256, 64 spp
         cam, objs, h = diffuse_single_sphere()
@@ -139,12 +163,12 @@ def config(n: int, ply_path=None):
         cam, objs, h = cook_torrance_spheres_metallic()
         return camera_for_resolution(cam, 1024, 1024), objs, h, 256, 50
     if n == 3:  # ~70k-triangle mesh + area light, 1024x1024, 512 spp
-        cam, objs, h = mesh_scene(6, Material.LambertianDiffuse((0.8, 0.8, 0.8)), area_light=True, ply_path=ply_path)
+        cam, objs, h = mesh_scene(6, Material.LambertianDiffuse((0.8, 0.8, 0.8)), area_light=True, ply_path=ply_path, ply_exists=ply_exists)
         return camera_for_resolution(cam, 1024, 1024), objs, h, 512, 50
     if n == 4:  # frosted-glass spheres, max depth 32, 2048x2048, 4096 spp
         cam, objs, h = cook_torrance_spheres_frosted_glass()
         return camera_for_resolution(cam, 2048, 2048), objs, h, 4096, 32
     if n == 5:  # 1M-triangle mesh (20 * 4**8 = 1,310,720), 2048x2048, 1024 spp
-        cam, objs, h = mesh_scene(8, ply_path=ply_path)
+        cam, objs, h = mesh_scene(8, ply_path=ply_path, ply_exists=ply_exists)
         return camera_for_resolution(cam, 2048, 2048), objs, h, 1024, 50
     raise ValueError("config 1..5")

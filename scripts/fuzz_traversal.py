@@ -152,12 +152,28 @@ def families(seed, verts, idx, scale, per_scene, root_box, small=0.0):
 
 REQUIRED = ("general", "grazing >= 1e-7 near")
 
+# A finely tessellated sheet of slivers, as a property of the geometry (not of the seed): at least
+# FINE_TRIANGLES triangles whose median aspect ratio -- longest edge squared over twice the area -- is at least
+# SLIVER_ASPECT.  Measured on forty sheets of 250 ... 400 quads per side: the fast walk's culling loses hits to in-plane
+# rays at 1e-7 rad and more, from any distance, on sheets of aspect 2.7e4 and more (5 ... 17 of 24,000 near grazing rays
+# on three of eight such sheets), on none of aspect 1.7e4 or less.
+FINE_TRIANGLES = 100_000
+SLIVER_ASPECT = 1.0e4
 
-def required(seed, name):
-    """Where the fast walk is required to match.  Not on the grazing families of the finely tessellated SLIVER sheets
-    (seed % 11 == 0 with seed % 3 != 0): round 5 found its culling to lose hits there to in-plane rays at 1e-7 rad and more
-    from any distance, a few in 10^4 -- counted under "elsewhere"."""
-    return name in REQUIRED and not (seed % 11 == 0 and seed % 3 != 0 and name != "general")
+
+def fine_slivers(verts, idx):
+    v = verts.astype(np.float64)[idx]
+    e = np.stack([v[:, 1] - v[:, 0], v[:, 2] - v[:, 1], v[:, 0] - v[:, 2]], axis=1)
+    longest2 = (e * e).sum(axis=2).max(axis=1)
+    area2 = np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
+    aspect = float(np.median(longest2 / np.maximum(area2, 1e-300)))
+    return len(idx) >= FINE_TRIANGLES and aspect >= SLIVER_ASPECT
+
+
+def required(fine, name):
+    """Where the fast walk is required to match: the general family everywhere, and near grazing rays at 1e-7 rad and more
+    except on finely tessellated sliver sheets (fine_slivers) -- mismatches there are counted under their own heading."""
+    return name in REQUIRED and not (fine and name != "general")
 
 
 def main():
@@ -173,6 +189,7 @@ def main():
         objs, heur, scale, verts, idx = scene_for(seed)
         tmin, tmax = 1e-6 * scale, 1e9 * scale
         prod = rayrs_amd.Scene(objs, tmin, tmax, heur, hdri, device=-1)
+        fine = fine_slivers(verts, idx)
         osc = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod)
         osg = _oracle.OracleScene(objs, tmin, tmax, heur, hdri).use_walk_tree(prod, gate=True)
         for name, o, d in families(seed, verts, idx, scale, per_scene, prod.info()["root_box"], small_extent(verts, idx)):
@@ -190,11 +207,12 @@ def main():
             w, nf, nb = osc.cull_margin_probe(o, d, tmin, tmax)
             f["rays"] += len(o); f["hits"] += int((oa >= 0).sum())
             f["default"] += int(bad.sum()); f["leaves"] += int(badl.sum()); f["exact"] += int(badx.sum())
-            f["required"] = f.get("required", 0) + (int(bad.sum()) if required(seed, name) else 0)
+            f["required"] = f.get("required", 0) + (int(bad.sum()) if required(fine, name) else 0)
+            f["exempt"] = f.get("exempt", 0) + (int(bad.sum()) if (name in REQUIRED and not required(fine, name)) else 0)
             f["worst"] = max(f["worst"], w); f["in_front"] += nf; f["beyond"] += nb
             exact_bad += int(badx.sum())
             for which, bb, tw, ow in (("default", bad, tb, ob), ("exact", badx, tx, ox)):
-                if bb.any() and (which == "exact" or required(seed, name)):
+                if bb.any() and (which == "exact" or required(fine, name)):
                     i = int(np.argmax(bb))
                     print(f"MISMATCH ({which} walk, {name}) seed {seed}: o={o[i].tolist()} d={d[i].tolist()} reference=({oa[i]}, {ta[i]!r}) "
                           f"walk=({ow[i]}, {tw[i]!r})", flush=True)
@@ -205,9 +223,11 @@ def main():
                       f"exact {f['exact']}  largest (entry - t)/t {f['worst']:.3e} (2^{lw:.1f})  hits in front of a box {f['in_front']}, beyond the margin {f['beyond']}", flush=True)
             print(f"  {time.time() - t0:.0f} s", flush=True)
     req = sum(f.get("required", 0) for f in fam.values())
+    exempt = sum(f.get("exempt", 0) for f in fam.values())
     print("done:", sum(f["rays"] for f in fam.values()), "rays; default (exact) walk mismatches (must be 0):", exact_bad,
           "; fast walk mismatches where it must match:", req,
-          "; elsewhere:", sum(f["default"] for f in fam.values()) - req)
+          "; on finely tessellated sliver sheets, in families it must match elsewhere (counted, not required):", exempt,
+          "; in the other families:", sum(f["default"] for f in fam.values()) - req - exempt)
     sys.exit(1 if (req or exact_bad) else 0)
 
 

@@ -9,9 +9,11 @@ mkdir -p $OUT
 python -c 'import __graft_entry__ as g; g.check_built()' || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc -- python $ROOT/scripts/op_model.py $OUT/order.json > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
-python - "$OUT" "$ROOT/gpurun_out/${TAG}_op_model.json" <<'PY'
+python - "$OUT" "$ROOT/gpurun_out/${TAG}_op_model.json" "$ROOT" <<'PY'
 import csv, glob, json, sys
 out, dst = sys.argv[1], sys.argv[2]
+sys.path.insert(0, sys.argv[3])
+import bench
 order = json.load(open(out + "/order.json"))
 rows = []
 for f in glob.glob(out + "/pmc/*/*counter_collection.csv"):
@@ -29,7 +31,8 @@ base = res["none"]["valu_per_evaluation"]
 for k, v in res.items():
     if k not in ("none", "background"):
         v["valu_per_evaluation_net"] = round(v["valu_per_evaluation"] - base, 1)
-json.dump({"source": "scripts/op_model.sh: rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace around scripts/op_model.py; "
+json.dump({"shading_source_hash": bench.shading_source_hash(), "source_hash": bench.source_hash(),
+           "source": "scripts/op_model.sh: rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace around scripts/op_model.py; "
                      "valu_per_evaluation = SQ_INSTS_VALU x 64 / evaluations (all 64 lanes of every wave active); "
                      "_net = minus the `none` unit (the test kernel's own loads and stores)", "units": res}, open(dst, "w"), indent=1)
 for k, v in res.items():

@@ -20,7 +20,8 @@ cam = rayrs_amd.Camera(*cam_args)
 chunk = rayrs_amd.frame_sample_chunk(res, res, spp)
 rayrs_amd.render(scene, cam, 4, mb)
 ref = None
-WALKS = [("default", dict(), False), ("fast", dict(), True), ("fast on the gate tree", dict(gate_tree=1), True)]
+WALKS = [("default", dict(), False), ("whole gate tree", dict(hot_group=0xffffffff), False), ("fast", dict(), True),
+         ("fast on the gate tree", dict(gate_tree=1), True)]
 if os.environ.get("ONLY"):
     WALKS = [w for w in WALKS if w[0] in os.environ["ONLY"].split(",")]
 for name, lab, fast in WALKS + WALKS[::-1]:
@@ -30,7 +31,7 @@ for name, lab, fast in WALKS + WALKS[::-1]:
     if ref is None:
         ref = img.copy()
     prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
-    print(f"{name:22s}: trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f}  hit {st['hit_ms']:6.1f} miss {st['miss_ms']:6.1f}  "
+    print(f"{name:26s}: trace {st['trace_ms']:8.1f} ms  trav {st['kernel_ms']:8.1f}  hit {st['hit_ms']:6.1f} miss {st['miss_ms']:6.1f}  "
           f"Mray/s {st['rays'] / st['trace_ms'] / 1e3:7.1f}  records/ray {cst['interior_visits'] / cst['rays']:6.2f}  primitive tests/ray {prims / cst['rays']:6.2f}  "
-          f"lanes {cst['step_lane'] / max(cst['step_wave'], 1):.2f}/{cst['inner_wave'] / max(cst['leaf_wave'], 1):.2f}  exact_walk={st['exact_walk']}  "
+          f"lanes {cst['step_lane'] / max(cst['step_wave'], 1):.2f}/{cst['inner_wave'] / max(cst['leaf_wave'], 1):.2f}  exact_walk={st['exact_walk']} hot_group={st['hot_group']}  "
           f"same_bits={bool((img.view('u4') == ref.view('u4')).all())}", flush=True)

@@ -2,10 +2,11 @@
 # usage: bash scripts/ubench/pmc_libs.sh <config> <res> <spp>
 ROOT=${GRAFT_REPO_ROOT:-.}
 CFG=${1:-5}; RES=${2:-2048}; SPP=${3:-1024}
-cp $ROOT/rayrs_amd/librayrs_hip.so /tmp/cur.so
+# (the build is chosen with RAYRS_HIP_LIB, exported before rocprofv3 -- no `env` hop behind the profiler; nothing in the tree is overwritten)
+ROOT=$(cd $ROOT && pwd)
 cd /tmp && export TMPDIR=/tmp
-for l in /tmp/cur.so $(ls $ROOT/scripts/ubench/alt/*.so); do
-  cp $l $ROOT/rayrs_amd/librayrs_hip.so; echo "== $l"
+for l in $ROOT/rayrs_amd/librayrs_hip.so $(ls $ROOT/scripts/ubench/alt/*.so); do
+  export RAYRS_HIP_LIB=$l; echo "== $l"
   rm -rf /tmp/pmc_sq
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/pmc_sq -- python $ROOT/scripts/ubench/tune_sweep.py $CFG $RES $SPP "" > /tmp/pmc_sq.log 2>&1
   tail -n 1 /tmp/pmc_sq.log
@@ -27,4 +28,3 @@ for d in ("/tmp/pmc_sq", "/tmp/pmc_sq2"):
               "wait_inst_any/wave_cycles", round(agg["SQ_WAIT_INST_ANY"] / agg["SQ_WAVE_CYCLES"], 4))
 PY
 done
-cp /tmp/cur.so $ROOT/rayrs_amd/librayrs_hip.so

@@ -93,6 +93,7 @@ def lib():
     L.orc_flatten_export.argtypes = [vp, vp, vp, vp]
     L.orc_flatten_export_wide.argtypes = [vp, vp, vp]
     L.orc_set_wide.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.orc_set_hot_group.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.orc_vec_op.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.orc_vec_op.restype = None
     L.orc_vec_scalar.argtypes = [C.c_int, dp, dp]
@@ -217,11 +218,25 @@ class OracleScene:
                 "root_box": list(i.root_box), "n_wide": i.n_wide, "wide_root_ref": i.wide_root_ref,
                 "wide_depth": i.wide_depth}
 
-    def use_product_walk(self, product_scene, fast=False):
+    def use_product_walk(self, product_scene, fast=False, hot=None):
         """The walk the product makes: traversal=2 then visits what its traversal kernel visits -- by default the gate
-        tree with nothing culled (the reference's visit set), with fast=True the tree of single primitives with
+        tree with nothing culled (the reference's visit set; on a scene with a hot group: the tree without that group
+        and the group beside it, as the kernels do -- hot=False takes the whole gate tree all the same, which is what
+        the local-pool route and rayrs_lab hot_group=0xffffffff walk), with fast=True the tree of single primitives with
         closest-hit culling (rayrs_render_params.fast_traversal)."""
-        self.use_walk_tree(product_scene, gate=not fast)
+        info = product_scene.info()
+        if hot is None:
+            hot = not fast and info["hot_count"] > 0 and not info["local_pool"]
+        if hot:
+            assert not fast and info["hot_count"] > 0
+            box, ref = product_scene.export_hot_tree()
+            box, ref = np.ascontiguousarray(box), np.ascontiguousarray(ref)
+            assert self._L.orc_set_wide(self._h, info["hot_n_wide"], info["hot_root_ref"], info["hot_depth"],
+                                        box.ctypes.data, ref.ctypes.data) == 0
+            hb = np.array(info["hot_box"], dtype=np.float64)
+            assert self._L.orc_set_hot_group(self._h, hb.ctypes.data, info["hot_first"], info["hot_count"]) == 0
+        else:
+            self.use_walk_tree(product_scene, gate=not fast)
         self._walk_margin = 2.0 ** -10 if fast else float("inf")
         return self
 

@@ -125,7 +125,10 @@ def test_ctypes_structs_have_the_c_layout():
     n = L.rayrs_abi_layout(None, 0)
     table = (C.c_uint32 * n)()
     assert L.rayrs_abi_layout(table, n) == n
-    table, pos = list(table), 0
+    table, pos = list(table), 1
+    # the table's first word is the boundary's version: a binding that validates itself against the table alone
+    # still fails when a field changes its meaning at an unchanged offset (round 5's exact_traversal -> fast_traversal)
+    assert table[0] == L.rayrs_abi_version() == _ffi.ABI_VERSION
     for st in _ffi.ABI_STRUCTS:
         size, nfields = table[pos], table[pos + 1]
         offsets = table[pos + 2:pos + 2 + nfields]
@@ -200,7 +203,7 @@ def test_abi_version_and_zero_initialised_params():
     reference's visit set (fast_traversal = 0), and a field out of range is refused, not interpreted."""
     L = _ffi.lib()
     hdr = open(os.path.join(ROOT, "include", "rayrs_hip.h")).read()
-    assert int(re.search(r"#define RAYRS_ABI_VERSION (\d+)", hdr).group(1)) == L.rayrs_abi_version() >= 5
+    assert int(re.search(r"#define RAYRS_ABI_VERSION (\d+)", hdr).group(1)) == L.rayrs_abi_version() == _ffi.ABI_VERSION >= 6
     p = _ffi.RenderParams()
     assert p.fast_traversal == 0
     assert rayrs_amd.make_params(4).fast_traversal == 0 and rayrs_amd.make_params(4, fast_traversal=True).fast_traversal == 1

@@ -80,7 +80,7 @@ def tight_box(prim_box, gate):
     return out
 
 
-def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False):
+def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False, hot=False):
     """What makes a walk tree legal (scene_host.cpp build_walk_trees), checked from the outside: every interior
     slot's box is the union of the boxes below it (so a ray that misses it misses every leaf box inside); unused
     slots are marked; every record is reached once; the stack bound holds; and
@@ -89,10 +89,27 @@ def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False):
       gate=False (the default tree): every primitive sits alone in exactly one leaf slot, behind its own bounding
         box (prim_boxes[p]: Object::bbox of the object behind primitive p) widened by LEAF_MARGIN and clipped to its
         group's gating box -- inside the gating box, so it reaches nothing the reference does not, and around the
-        primitive with the margin to spare."""
+        primitive with the margin to spare;
+      hot=True (with gate=True: rayrs_scene_export_hot_tree, what the default walk reads on a scene with a hot group):
+        as gate=True, but ONE group is not in the records -- the hot group of rayrs_scene_info_t.hot_*: it must be one
+        of the reference's groups, behind exactly its gating box, the one with the largest box, covering at least a
+        quarter of the root Node's box (scene_host.cpp pick_hot_group): the tree's groups and that one are the groups."""
     groups = reference_groups(box, ref, info)
-    pre = "gate_" if gate else "wide_"
-    n_wide = info["gate_n_wide" if gate else "n_wide"]
+    pre = "hot_" if hot else ("gate_" if gate else "wide_")
+    n_wide = info["hot_n_wide" if hot else ("gate_n_wide" if gate else "n_wide")]
+    hot_ref = None
+    if hot:
+        assert gate and info["hot_count"] >= 1
+        hot_ref = (1 << 30) | (info["hot_first"] << 2) | (info["hot_count"] - 1)
+        assert hot_ref in groups and np.array(info["hot_box"]).tobytes() == groups[hot_ref]
+
+        def area(bb):
+            b = np.frombuffer(bb, dtype=np.float64)
+            x, y, z = b[1] - b[0], b[3] - b[2], b[5] - b[4]
+            return 2.0 * (x * y + y * z + x * z)
+        areas = {g: area(bb) for g, bb in groups.items()}
+        assert areas[hot_ref] == max(areas.values()) and areas[hot_ref] >= 0.25 * area(np.array(info["root_box"]).tobytes())
+        assert len(groups) >= 8
     if info["n_interior"] == 0:  # one bottom Node: both trees are the root group behind the root box
         assert n_wide == 0 and info[pre + "root_ref"] == info["root_ref"] and info[pre + "depth"] == 0
         return
@@ -145,6 +162,11 @@ def check_walk_tree(box, ref, wbox, wref, info, prim_boxes=None, gate=False):
     import sys
     sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
     (lo, hi), need = visit(info[pre + "root_ref"] & 0x3fffffff)
+    if hot:
+        assert hot_ref not in seen_leaves
+        seen_leaves.add(hot_ref)
+        hb = np.array(info["hot_box"])
+        lo, hi = np.minimum(lo, hb[0::2]), np.maximum(hi, hb[1::2])
     assert seen_leaves == (set(groups) if gate else set(gate_of)) and len(seen_records) == n_wide
     assert need == info[pre + "depth"]
     root = np.array(info["root_box"])
@@ -159,6 +181,12 @@ def check_walk_trees(prod, orc, n_objects):
     info = prod.info()
     check_walk_tree(pb, pr, *prod.export_gate_tree(), info, gate=True)
     check_walk_tree(pb, pr, *prod.export_wide(), info, prim_boxes=orc.object_boxes(n_objects)[pp])
+    if info["hot_count"]:
+        check_walk_tree(pb, pr, *prod.export_hot_tree(), info, gate=True, hot=True)
+    else:
+        with pytest.raises(rayrs_amd._ffi.RayrsError):
+            prod.export_hot_tree()
+    return info["hot_count"]
 
 
 SCENE_FNS = [scenes.diffuse_single_sphere, scenes.cook_torrance_spheres_metallic, scenes.material_test,

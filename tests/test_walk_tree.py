@@ -33,6 +33,16 @@ def both_walks(objs, heur, o, d, t0=1e-6, t1=1e6):
         _oracle.set_cull_margin(2.0 ** -10)
     assert np.array_equal(xobj, robj)
     assert np.array_equal(xt.view(np.uint64), rt.view(np.uint64))
+    # ... and on a scene with a hot group, the tree without it with the group tested beside the walk
+    if prod.info()["hot_count"]:
+        osh = _oracle.OracleScene(objs, t0, t1, heur, HDRI).use_product_walk(prod, hot=True)
+        try:
+            _oracle.set_cull_margin(float("inf"))
+            ht, hobj = osh.intersect_many(o, d, t0, t1, traversal=2)
+        finally:
+            _oracle.set_cull_margin(2.0 ** -10)
+        assert np.array_equal(hobj, robj)
+        assert np.array_equal(ht.view(np.uint64), rt.view(np.uint64))
     return robj
 
 
@@ -188,7 +198,7 @@ def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
             rt, robj = osc.intersect_batch(o, d, t0, t1, traversal=0)
             wt, wobj = osc.intersect_batch(o, d, t0, t1, traversal=2)
             same = (wobj == robj) & (wt.view(np.uint64) == rt.view(np.uint64))
-            if name in F.REQUIRED and not (seed == 11 and name != "general"):
+            if F.required(F.fine_slivers(verts, idx), name):
                 assert same.all(), (seed, name)
                 hits += int((robj >= 0).sum())
             elif name in F.REQUIRED:
@@ -207,7 +217,7 @@ def test_both_bets_on_slivers_flat_sheets_and_grazing_rays():
                 assert beyond == 0
     assert hits > 500_000
     assert 0 < elsewhere < 2000  # the bets do fail out there (a few in 1e4 rays aimed along a plane from far away)
-    assert 0 < fine_slivers < 100  # ... and, on finely tessellated slivers, from nearby too
+    assert fine_slivers < 100  # ... and, on finely tessellated slivers (seed 11: fuzz_traversal.fine_slivers), from nearby too -- counted, bounded
     assert worst_general < 2.0 ** -40  # general rays: a hit precedes a box of its own by ulps only
 
 
@@ -257,3 +267,34 @@ def test_the_bets_are_heuristics_and_this_is_where_they_end():
     assert robj[0] >= 0 and wobj[0] >= 0 and wobj[0] != robj[0] and 0 < wt[0] / rt[0] - 1 < 1e-7
     assert lobj[0] == wobj[0] and lt[0] == wt[0]                      # with or without culling
     assert xobj[0] == robj[0] and xt[0] == rt[0]
+
+
+def test_the_hot_group_is_the_floors_group_on_the_mesh_scenes_and_absent_on_the_sphere_scenes():
+    """scene_host.cpp pick_hot_group: the group with the largest gating box, if that covers a quarter of the root Node's
+    box and the scene has at least eight groups.  On the obj scenes that is the group the 50 x 50 floor is in; the
+    reference's sphere scenes (a handful of groups: the local-pool route) have none.  The oracle's walk of the tree
+    without the group, with the group tested beside it, returns the recursion's hits and tests exactly as many
+    primitives as its walk of the whole gate tree (the visit set is the same set)."""
+    for fn in (scenes.diffuse_single_sphere, scenes.cook_torrance_spheres_metallic, scenes.material_test):
+        cam, objs, heur = fn()
+        assert rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1).info()["hot_count"] == 0
+    for level, light in ((2, False), (3, True)):
+        cam, objs, heur = scenes.mesh_scene(level, area_light=light)
+        prod = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, HDRI, device=-1)
+        info = prod.info()
+        assert 1 <= info["hot_count"] <= 4 and info["hot_n_wide"] >= 2
+        pp = prod.export_bvh()[2]
+        assert objs[0].kind == "plane" and objs[0].umax - objs[0].umin == 50.0  # the floor is the first object
+        assert 0 in [int(pp[info["hot_first"] + k]) for k in range(info["hot_count"])]
+        o, d = random_rays(20000, 40 + level)
+        both_walks(objs, heur, o, d)
+        ocam = _oracle.OracleCamera(*scenes.camera_for_resolution(cam, 48, 32))
+        og = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI).use_product_walk(prod, hot=False)
+        oh = _oracle.OracleScene(objs, 1e-6, 1e6, heur, HDRI).use_product_walk(prod, hot=True)
+        fg, sg = og.render(ocam, 4, traversal=2)
+        fh, sh = oh.render(ocam, 4, traversal=2)
+        fr, sr = og.render(ocam, 4, traversal=0)
+        assert np.array_equal(fg.view(np.uint64), fr.view(np.uint64)) and np.array_equal(fh.view(np.uint64), fr.view(np.uint64))
+        for k in ("rays", "tri_tests", "sphere_tests", "plane_tests"):
+            assert sg[k] == sh[k], k
+        assert sh["interior_visits"] <= sg["interior_visits"]
