@@ -680,8 +680,6 @@ def main():
             else:
                 util = {"interior": round(cst["step_lane"] / max(cst["step_wave"], 1), 3),
                         "leaf": round(cst["inner_wave"] / max(cst["leaf_wave"], 1), 3)}
-                if cst.get("hot_group"):
-                    util["hot group"] = round(cst["hot_lane"] / max(cst["hot_wave"], 1), 3)
             roofline = {
                 "bound": "fp64_valu", "achieved": round(achieved, 3), "peak": round(F64_PEAK_TOPS, 2),
                 "unit": "Tlane-op/s", "frac": round(achieved / F64_PEAK_TOPS, 4), "traffic": traffic,
@@ -711,7 +709,7 @@ def main():
                     "rays_that_owed_the_test_per_ray": round(cst["hot_lane"] / max(cst["rays"], 1), 3),
                     "primitive_tests_per_ray": round(cst["hot_prim_tests"] / max(cst["rays"], 1), 3),
                     "triangle_tests_that_went_on_to_divide_per_ray": round(cst["hot_tri_divided"] / max(cst["rays"], 1), 4),
-                    "lanes": round(cst["hot_lane"] / max(cst["hot_wave"], 1), 3)},
+                    "queries_answered_by_the_kernel_that_made_the_ray": round(cst["pre_rays"] / max(cst["rays"], 1), 3)},
                 # SURVEY.md 8(d)'s figure: record fetches of an incoherent walk, served by LDS / L1 / L2 / Infinity
                 # Cache -- it can exceed the HBM peak and bounds nothing; kept for comparison
                 "algorithmic_bytes_per_launch": int(abytes / launches),

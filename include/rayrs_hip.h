@@ -155,9 +155,10 @@ typedef struct {
     /* The default walk's HOT GROUP (hot_count = 0: the scene has none): one group of the gate tree -- the one whose
      * gating box is the largest, if it covers at least a quarter of the root Node's box: on the reference's obj scenes the
      * floor's bottom Node, which nine rays in ten enter -- is left out of the records the default walk reads
-     * (rayrs_scene_export_hot_tree: hot_n_wide records) and tested ONCE PER RAY beside the walk, by a wave's rays
-     * together: its gating box hot_box exactly as AxisAlignedBoundingBox::intersect tests it, then its hot_count
-     * primitives hot_first ... in depth-first order exactly as the reference tests them.  The groups of that tree and
+     * (rayrs_scene_export_hot_tree: hot_n_wide records) and tested ONCE PER RAY beside the walk, by the kernel that
+     * makes the ray, for a whole batch of rays together: its gating box hot_box exactly as
+     * AxisAlignedBoundingBox::intersect tests it, then its hot_count primitives hot_first ... in depth-first order
+     * exactly as the reference tests them -- on wave-uniform f64 values.  The groups of that tree and
      * the hot group together are the groups of the gate tree, each behind its gating box: the primitives tested are
      * still exactly those BvhTree::intersect tests (tests/test_bvh_builder.py checks it from the exports). */
     uint32_t hot_n_wide;
@@ -311,12 +312,14 @@ typedef struct {
     uint32_t exact_walk;    /* 1 = this frame's queries were answered by the reference's visit set (the default); 0 = by the
                                fast walk (rayrs_render_params.fast_traversal = 1, the camera near enough, the streaming
                                route: the local-pool route never makes the bets) */
-    uint32_t hot_group;     /* 1 = ... with the scene's hot group tested beside the walk (rayrs_scene_info_t.hot_count) */
+    uint32_t hot_group;     /* 1 = ... with the scene's hot group (rayrs_scene_info_t.hot_count) and the first record of the walk tree
+                               tested by the kernels that MAKE the rays, for whole batches at once: a ray whose query ends
+                               there never travels through the traversal kernel */
     uint32_t stats_pad;
-    uint64_t hot_wave;      /* count_work only: executions of the hot-group phase x 64, the lanes that owed the test in */
-    uint64_t hot_lane;      /* them, and its shader-clock ticks (like step_wave / step_lane / interior_ticks) */
-    uint64_t hot_ticks;
-    uint64_t hot_prim_tests;  /* count_work only: of tri_tests + sphere_tests + plane_tests, those made in the hot-group phase */
+    uint64_t pre_rays;        /* the next four only with count_work: queries (of `rays`) that were answered by the kernel that made
+                                 the ray -- bounced rays that miss the root box, rays that enter no slot of the walk tree's first record */
+    uint64_t hot_lane;        /* rays put to the hot group's gating box */
+    uint64_t hot_prim_tests;  /* of tri_tests + sphere_tests + plane_tests, the hot group's */
     uint64_t hot_tri_divided; /* ... of its triangle tests, those that went on to the three divisions (the others were settled
                                  before them by two exact facts about IEEE division: device_path.h hot_triangle_intersect) */
 } rayrs_render_stats;
@@ -407,6 +410,9 @@ int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const 
                    int binary);
 /* wavefront_obj::load_obj_file, wavefront_obj.rs:15-45: `v x y z` / `f i j k` lines only. */
 int rayrs_obj_load(const char* path, double** verts, uint32_t* nverts, uint32_t** idx, uint32_t* ntris);
+/* wavefront_obj::load_obj_file_spheres, wavefront_obj.rs:46-64: one sphere centre per `v x y z` line, every other line
+ * skipped; centers: n*3 f64 -- with the radius, feed them to rayrs_object_from_spheres (Object::from_spheres, lib.rs:422). */
+int rayrs_obj_load_spheres(const char* path, double** centers, uint32_t* n);
 /* Radiance .hdr: what HdrDecoder / HDREncoder do at rayrs/src/main.rs:36-41 and :113-121.
  * rgb: w*h*3 f32, top row first. */
 int rayrs_hdr_load(const char* path, float** rgb, uint32_t* w, uint32_t* h);

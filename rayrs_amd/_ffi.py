@@ -23,14 +23,14 @@ SYMBOLS = [
     "rayrs_camera_new",
     "rayrs_frame_sample_chunk", "rayrs_render", "rayrs_render_launch", "rayrs_render_finish", "rayrs_render_multi",
     "rayrs_abi_layout", "rayrs_abi_version",
-    "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load",
+    "rayrs_io_last_error", "rayrs_buffer_free", "rayrs_ply_load", "rayrs_ply_save", "rayrs_obj_load", "rayrs_obj_load_spheres",
     "rayrs_hdr_load", "rayrs_hdr_save", "rayrs_image_to_bytes", "rayrs_ppm_save", "rayrs_png_save",
 ]
 
 
 # rayrs_amd/csrc/rayrs_selftest.h and rayrs_lab.h: private hooks of the library (tests/ and scripts/ only)
 PRIVATE_SYMBOLS = ["rayrs_test_math", "rayrs_test_rng", "rayrs_test_intersect", "rayrs_test_path_trace", "rayrs_test_material", "rayrs_test_background",
-                   "rayrs_lab_set", "rayrs_lab_round_ms"]
+                   "rayrs_lab_set", "rayrs_lab_round_ms", "rayrs_lab_multi_rehearse"]
 
 
 class MaterialDesc(C.Structure):
@@ -79,7 +79,7 @@ class RenderStats(C.Structure):
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
                 ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32), ("hot_group", C.c_uint32),
-                ("stats_pad", C.c_uint32), ("hot_wave", C.c_uint64), ("hot_lane", C.c_uint64), ("hot_ticks", C.c_uint64),
+                ("stats_pad", C.c_uint32), ("pre_rays", C.c_uint64), ("hot_lane", C.c_uint64),
                 ("hot_prim_tests", C.c_uint64), ("hot_tri_divided", C.c_uint64)]
 
     def as_dict(self):
@@ -98,8 +98,7 @@ class LabTuning(C.Structure):
     _fields_ = [("refill_min", C.c_uint32), ("leaf_min", C.c_uint32), ("static_pct", C.c_uint32),
                 ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32),
                 ("eager_light", C.c_uint32), ("local_reserve", C.c_uint32), ("local_segment_items", C.c_uint32),
-                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("hot_group", C.c_uint32),
-                ("hot_min", C.c_uint32), ("hot_wait", C.c_uint32)]
+                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("hot_group", C.c_uint32)]
 
 
 # RAYRS_ABI_VERSION these mirrors were written against: lib() refuses a library of another version
@@ -158,6 +157,8 @@ def lib():
     L.rayrs_scene_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     L.rayrs_lab_set.argtypes = [vp, C.POINTER(LabTuning)]  # private: rayrs_amd/csrc/rayrs_lab.h
     L.rayrs_lab_set.restype = C.c_int
+    L.rayrs_lab_multi_rehearse.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32]
+    L.rayrs_lab_multi_rehearse.restype = C.c_int
     L.rayrs_frame_sample_chunk.argtypes = [C.c_uint32] * 4
     L.rayrs_frame_sample_chunk.restype = C.c_uint32
     L.rayrs_abi_layout.argtypes = [vp, C.c_uint32]
@@ -185,6 +186,7 @@ def lib():
     L.rayrs_ply_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, C.POINTER(vp), u32p]
     L.rayrs_ply_save.argtypes = [C.c_char_p, vp, C.c_uint32, vp, C.c_uint32, C.c_int]
     L.rayrs_obj_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, C.POINTER(vp), u32p]
+    L.rayrs_obj_load_spheres.argtypes = [C.c_char_p, C.POINTER(vp), u32p]
     L.rayrs_hdr_load.argtypes = [C.c_char_p, C.POINTER(vp), u32p, u32p]
     L.rayrs_hdr_save.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.rayrs_image_to_bytes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_double, vp, C.POINTER(C.c_uint64)]

@@ -517,7 +517,7 @@ extern "C" int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_r
 int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
-    if (lab->hot_min > 64u || lab->hot_wait > 64u || (lab->hot_group != 0u && lab->hot_group != 0xffffffffu)) return RAYRS_INVALID_ARG;
+    if (lab->hot_group != 0u && lab->hot_group != 0xffffffffu) return RAYRS_INVALID_ARG;
     if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
@@ -576,7 +576,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
     RAYRS_FIELD(rayrs_render_params, fast_traversal);
-    RAYRS_STRUCT(rayrs_render_stats, 33);
+    RAYRS_STRUCT(rayrs_render_stats, 32);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -591,8 +591,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, exact_walk);
     RAYRS_FIELD(rayrs_render_stats, hot_group), RAYRS_FIELD(rayrs_render_stats, stats_pad);
-    RAYRS_FIELD(rayrs_render_stats, hot_wave), RAYRS_FIELD(rayrs_render_stats, hot_lane);
-    RAYRS_FIELD(rayrs_render_stats, hot_ticks);
+    RAYRS_FIELD(rayrs_render_stats, pre_rays), RAYRS_FIELD(rayrs_render_stats, hot_lane);
     RAYRS_FIELD(rayrs_render_stats, hot_prim_tests), RAYRS_FIELD(rayrs_render_stats, hot_tri_divided);
     RAYRS_STRUCT(rayrs_tuning, 2);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
@@ -756,8 +755,6 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     const bool exact = params->fast_traversal == 0u || camera_is_far(scene, camera);
     scene->last_exact = exact;
     rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
-    rp.hot_min = lab.hot_min ? lab.hot_min : 40u;
-    rp.hot_wait = lab.hot_wait ? lab.hot_wait : 8u;
     const SceneDev sc = make_scene_dev(scene, exact);
     const CameraDev cam = make_camera_dev(camera);
 
@@ -992,7 +989,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         stats->direct_rays = c.direct_rays;
-        stats->hot_wave = c.hot_wave, stats->hot_lane = c.hot_lane, stats->hot_ticks = c.hot_ticks;
+        stats->pre_rays = c.pre_rays, stats->hot_lane = c.hot_lane;
         stats->hot_prim_tests = c.hot_prim_tests, stats->hot_tri_divided = c.hot_tri_divided;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));

@@ -292,6 +292,40 @@ static int rayrs_ply_save_impl(const char* path, const float* verts, uint32_t nv
 
 // load_obj_file, wavefront_obj.rs:15-45: `v x y z` and `f i j k` lines only, fields split
 // on single spaces, 1-based plain indices, triangles only.  Vertices stay f64.
+// wavefront_obj::load_obj_file_spheres (wavefront_obj.rs:46-64): the `v` lines only, one sphere centre each; every other
+// line -- `f` lines too, which load_obj_file would parse -- is skipped.  The radius is the caller's (rayrs_object_from_spheres).
+static int rayrs_obj_load_spheres_impl(const char* path, double** centers_out, uint32_t* n_out) {
+    if (!path || !centers_out || !n_out) return RAYRS_INVALID_ARG;
+    std::ifstream f(path);
+    if (!f) return io_fail(std::string("cannot open ") + path);
+    std::vector<double> c;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<std::string> v;
+        size_t start = 0;
+        for (;;) {  // text.split(' ')
+            const size_t sp = line.find(' ', start);
+            v.push_back(line.substr(start, sp == std::string::npos ? std::string::npos : sp - start));
+            if (sp == std::string::npos) break;
+            start = sp + 1;
+        }
+        if (v[0] != "v") continue;
+        if (v.size() < 4) return io_fail("bad v line");  // the reference .unwrap()s
+        for (int k = 1; k <= 3; k++) {
+            char* end = nullptr;
+            const double x = std::strtod(v[(size_t)k].c_str(), &end);
+            if (end == v[(size_t)k].c_str()) return io_fail("bad number in v line");
+            c.push_back(x);
+        }
+    }
+    *centers_out = static_cast<double*>(std::malloc(std::max<size_t>(c.size(), 1) * sizeof(double)));
+    if (!*centers_out) return RAYRS_OOM;
+    std::memcpy(*centers_out, c.data(), c.size() * sizeof(double));
+    *n_out = (uint32_t)(c.size() / 3);
+    return RAYRS_OK;
+}
+
 static int rayrs_obj_load_impl(const char* path, double** verts_out, uint32_t* nverts_out, uint32_t** idx_out,
                    uint32_t* ntris_out) {
     if (!path || !verts_out || !nverts_out || !idx_out || !ntris_out) return RAYRS_INVALID_ARG;
@@ -558,6 +592,7 @@ int rayrs_ply_save(const char* path, const float* verts, uint32_t nverts, const 
                    int binary) { IO_GUARDED(rayrs_ply_save_impl(path, verts, nverts, idx, ntris, binary)); }
 int rayrs_obj_load(const char* path, double** verts_out, uint32_t* nverts_out, uint32_t** idx_out,
                    uint32_t* ntris_out) { IO_GUARDED(rayrs_obj_load_impl(path, verts_out, nverts_out, idx_out, ntris_out)); }
+int rayrs_obj_load_spheres(const char* path, double** centers_out, uint32_t* n_out) { IO_GUARDED(rayrs_obj_load_spheres_impl(path, centers_out, n_out)); }
 int rayrs_hdr_load(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out) { IO_GUARDED(rayrs_hdr_load_impl(path, rgb_out, w_out, h_out)); }
 int rayrs_hdr_save(const char* path, const float* rgb, uint32_t w, uint32_t h) { IO_GUARDED(rayrs_hdr_save_impl(path, rgb, w, h)); }
 int rayrs_png_save(const char* path, const uint8_t* bytes, uint32_t w, uint32_t h) { IO_GUARDED(rayrs_png_save_impl(path, bytes, w, h)); }

@@ -153,8 +153,11 @@ struct Counters {
     unsigned long long interior_ticks, leaf_ticks, refill_ticks;  // shader clock, summed over waves
     unsigned long long surface_hits[8];  // closest hits per surface row (rows 7 and up together), count_work only
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
-    unsigned long long hot_prim_tests, hot_tri_divided;  // of the primitive tests: made in the hot-group phase; of its triangle tests: with the divisions made
-    unsigned long long hot_wave, hot_lane, hot_ticks;  // the hot-group phase (count_work only): executions x 64, lanes that owed the test, shader clock
+    // the pre-test of new rays by the kernels that make them (wavefront.hip finish_rays; count_work only):
+    unsigned long long pre_rays;          // queries answered there: bounced rays that miss the root box, rays that enter no slot of the walk tree's first record
+    unsigned long long hot_lane;          // rays put to the hot group's gating box
+    unsigned long long hot_prim_tests;    // of tri + sphere + plane tests: the hot group's
+    unsigned long long hot_tri_divided;   // of its triangle tests: those that went on to the three divisions
 #ifdef RAYRS_LAB_TICKS
     unsigned long long lab_ticks[16];  // development build only (make LAB=1): shader-clock shares of the hit / miss loops
 #endif
@@ -171,7 +174,6 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
-    uint32_t hot_min, hot_wait;     // ... of the hot-group phase: run it once hot_min lanes owe the test, or hot_wait of them have nothing else left to do
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)

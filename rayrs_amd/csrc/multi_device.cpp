@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -79,13 +80,67 @@ int rccl_fail(Rccl& r, ncclResult_t e, const char* what) {
     return RAYRS_RCCL_ERROR;
 }
 
-#define RCCL_TRY(expr)                                             \
-    do {                                                           \
-        ncclResult_t _e = (expr);                                  \
-        if (_e != ncclSuccess) return rccl_fail(g_rccl, _e, #expr); \
+#define RCCL_TRY(r, expr)                                    \
+    do {                                                     \
+        ncclResult_t _e = (expr);                            \
+        if (_e != ncclSuccess) return rccl_fail(r, _e, #expr); \
     } while (0)
 
-// Sum of the framebuffers of the distinct devices into bufs[0] (on devs[0]); one stream per device.
+// What the reduce needs of the HIP runtime, as a table: the real one below, a recording one in rayrs_lab_multi_rehearse
+// (a CPU-side rehearsal of the calls an N-GPU node makes, on a box that has no N GPUs).
+struct DeviceOps {
+    hipError_t (*set_device)(int) = nullptr;
+    hipError_t (*stream_sync)(hipStream_t) = nullptr;
+};
+const DeviceOps HIP_OPS{[](int d) { return hipSetDevice(d); }, [](hipStream_t s) { return hipStreamSynchronize(s); }};
+
+// Which ranks' framebuffers are summed where: the ranks in order; the first rank on a device LEADS it (its buffer and
+// stream take part in the collective), every later rank on that device is summed into its leader's buffer on the device.
+struct ReducePlan {
+    std::vector<int> devs;             // the distinct devices, in order of first appearance: devs[0] receives the frame
+    std::vector<uint32_t> leader;      // leader[k] = the first rank on devs[k]
+    std::vector<std::pair<uint32_t, uint32_t>> local;  // (k, rank): rank's buffer is added to devs[k]'s leader on the device
+};
+
+ReducePlan plan_reduce(const std::vector<int>& rank_device) {
+    ReducePlan p;
+    for (uint32_t i = 0; i < rank_device.size(); i++) {
+        const auto at = std::find(p.devs.begin(), p.devs.end(), rank_device[i]);
+        if (at == p.devs.end()) p.devs.push_back(rank_device[i]), p.leader.push_back(i);
+        else p.local.emplace_back((uint32_t)(at - p.devs.begin()), i);
+    }
+    return p;
+}
+
+// Sum of the framebuffers of the distinct devices into bufs[0] (on devs[0]); one stream per device.  The communicators
+// of a device list are created at its first use and kept (r.comms).  The caller holds g_rccl_mutex when r is g_rccl.
+int rccl_reduce_to_first(Rccl& r, const DeviceOps& ops, const std::vector<int>& devs, const std::vector<void*>& bufs,
+                         const std::vector<hipStream_t>& streams, size_t count, bool f64) {
+    auto it = r.comms.find(devs);
+    if (it == r.comms.end()) {
+        std::vector<ncclComm_t> c(devs.size());
+        RCCL_TRY(r, r.CommInitAll(c.data(), (int)devs.size(), devs.data()));
+        it = r.comms.emplace(devs, c).first;
+    }
+    const std::vector<ncclComm_t>& comms = it->second;
+    RCCL_TRY(r, r.GroupStart());
+    for (size_t i = 0; i < devs.size(); i++) {
+        HIP_TRY(ops.set_device(devs[i]));
+        const ncclResult_t e = r.Reduce(bufs[i], bufs[i], count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, 0, comms[i],
+                                        streams[i]);
+        if (e != ncclSuccess) {
+            (void)r.GroupEnd();
+            return rccl_fail(r, e, "ncclReduce");
+        }
+    }
+    RCCL_TRY(r, r.GroupEnd());
+    for (size_t i = 0; i < devs.size(); i++) {
+        HIP_TRY(ops.set_device(devs[i]));
+        HIP_TRY(ops.stream_sync(streams[i]));
+    }
+    return RAYRS_OK;
+}
+
 int rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*>& bufs, const std::vector<hipStream_t>& streams,
                          size_t count, bool f64) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
@@ -93,29 +148,7 @@ int rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*>&
         set_last_error(g_rccl.error);
         return RAYRS_RCCL_ERROR;
     }
-    auto it = g_rccl.comms.find(devs);
-    if (it == g_rccl.comms.end()) {
-        std::vector<ncclComm_t> c(devs.size());
-        RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data()));
-        it = g_rccl.comms.emplace(devs, c).first;
-    }
-    const std::vector<ncclComm_t>& comms = it->second;
-    RCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < devs.size(); i++) {
-        HIP_TRY(hipSetDevice(devs[i]));
-        const ncclResult_t e = g_rccl.Reduce(bufs[i], bufs[i], count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, 0, comms[i],
-                                             streams[i]);
-        if (e != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            return rccl_fail(g_rccl, e, "ncclReduce");
-        }
-    }
-    RCCL_TRY(g_rccl.GroupEnd());
-    for (size_t i = 0; i < devs.size(); i++) {
-        HIP_TRY(hipSetDevice(devs[i]));
-        HIP_TRY(hipStreamSynchronize(streams[i]));
-    }
-    return RAYRS_OK;
+    return rccl_reduce_to_first(g_rccl, HIP_OPS, devs, bufs, streams, count, f64);
 }
 
 struct Rank {
@@ -198,18 +231,17 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
         std::vector<void*> bufs;
         std::vector<hipStream_t> streams;
         if (st == RAYRS_OK) {
-            for (uint32_t i = 0; i < n && st == RAYRS_OK; i++) {
-                const int dev = ranks[i].scene->device;
-                const auto at = std::find(devs.begin(), devs.end(), dev);
-                if (at == devs.end()) {
-                    devs.push_back(dev), bufs.push_back(ranks[i].d_out), streams.push_back(ranks[i].stream);
-                } else {
-                    const size_t k = (size_t)(at - devs.begin());
-                    hipError_t e = hipSetDevice(dev);
-                    if (e == hipSuccess) e = launch_accumulate(bufs[k], ranks[i].d_out, count, f64, streams[k]);
-                    if (e == hipSuccess) e = hipStreamSynchronize(streams[k]);
-                    if (e != hipSuccess) st = hip_fail(e, "rayrs_render_multi: same-device sum");
-                }
+            std::vector<int> rank_device(n);
+            for (uint32_t i = 0; i < n; i++) rank_device[i] = ranks[i].scene->device;
+            const ReducePlan plan = plan_reduce(rank_device);
+            devs = plan.devs;
+            for (const uint32_t l : plan.leader) bufs.push_back(ranks[l].d_out), streams.push_back(ranks[l].stream);
+            for (const auto& [k, i] : plan.local) {
+                if (st != RAYRS_OK) break;
+                hipError_t e = hipSetDevice(devs[k]);
+                if (e == hipSuccess) e = launch_accumulate(bufs[k], ranks[i].d_out, count, f64, streams[k]);
+                if (e == hipSuccess) e = hipStreamSynchronize(streams[k]);
+                if (e != hipSuccess) st = hip_fail(e, "rayrs_render_multi: same-device sum");
             }
         }
         // one device (a rehearsal with several handles on it): everything is summed already, no collective, no RCCL --
@@ -235,7 +267,7 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->inner_wave += s.inner_wave, stats->leaf_wave += s.leaf_wave;
                 stats->interior_ticks += s.interior_ticks, stats->leaf_ticks += s.leaf_ticks;
                 stats->refill_ticks += s.refill_ticks;
-                stats->hot_wave += s.hot_wave, stats->hot_lane += s.hot_lane, stats->hot_ticks += s.hot_ticks;
+                stats->pre_rays += s.pre_rays, stats->hot_lane += s.hot_lane;
                 stats->hot_prim_tests += s.hot_prim_tests, stats->hot_tri_divided += s.hot_tri_divided;
                 for (int k = 0; k < 8; k++) stats->surface_hits[k] += s.surface_hits[k];
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;
@@ -246,6 +278,75 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 if (s.kernel_launches > stats->kernel_launches) stats->kernel_launches = s.kernel_launches;
             }
         }
+        return st;
+    })
+}
+
+// ---- rayrs_lab.h: the calls rayrs_render_multi's reduce makes on an N-GPU node, rehearsed without one ----
+namespace {
+struct Rehearsal {
+    std::string log;
+    int fail_reduce_at = -1;  // the n-th ncclReduce (0-based, over all rounds) reports an error
+    int reduces = 0;
+    int next_comm = 1;
+};
+thread_local Rehearsal* g_rehearsal = nullptr;
+void say(const std::string& t) { g_rehearsal->log += t + ";"; }
+}  // namespace
+
+extern "C" int rayrs_lab_multi_rehearse(const int* rank_devices, uint32_t n, uint32_t rounds, int fail_reduce_at, char* log,
+                                        uint32_t cap) {
+    RAYRS_GUARDED({
+        if (!rank_devices || n == 0 || !log || cap == 0) return RAYRS_INVALID_ARG;
+        Rehearsal reh;
+        reh.fail_reduce_at = fail_reduce_at;
+        g_rehearsal = &reh;
+        Rccl stub;  // records instead of calling librccl; communicators are small integers
+        stub.CommInitAll = [](ncclComm_t* c, int nd, const int* d) {
+            std::string t = "init[";
+            for (int i = 0; i < nd; i++) {
+                t += (i ? "," : "") + std::to_string(d[i]);
+                c[i] = reinterpret_cast<ncclComm_t>((intptr_t)g_rehearsal->next_comm++);
+            }
+            say(t + "]");
+            return ncclSuccess;
+        };
+        stub.GroupStart = []() { say("group_start"); return ncclSuccess; };
+        stub.GroupEnd = []() { say("group_end"); return ncclSuccess; };
+        stub.Reduce = [](const void* src, void* dst, size_t count, ncclDataType_t, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t) {
+            say("reduce(comm=" + std::to_string((intptr_t)comm) + ",root=" + std::to_string(root) + ",count=" + std::to_string(count) +
+                ",in_place=" + std::to_string(src == dst) + ",sum=" + std::to_string(op == ncclSum) + ")");
+            return g_rehearsal->reduces++ == g_rehearsal->fail_reduce_at ? ncclInternalError : ncclSuccess;
+        };
+        stub.GetErrorString = [](ncclResult_t) { return "rehearsed failure"; };
+        const DeviceOps ops{[](int d) { say("set_device(" + std::to_string(d) + ")"); return hipSuccess; },
+                            [](hipStream_t) { say("sync"); return hipSuccess; }};
+        std::vector<int> rank_device(rank_devices, rank_devices + n);
+        int st = RAYRS_OK;
+        for (uint32_t r = 0; r < rounds; r++) {
+            const ReducePlan plan = plan_reduce(rank_device);
+            std::string t = "plan devs[";
+            for (size_t k = 0; k < plan.devs.size(); k++) t += (k ? "," : "") + std::to_string(plan.devs[k]) + ":" + std::to_string(plan.leader[k]);
+            t += "] local[";
+            for (size_t k = 0; k < plan.local.size(); k++) t += (k ? "," : "") + std::to_string(plan.local[k].first) + "<-" + std::to_string(plan.local[k].second);
+            say(t + "]");
+            // one fake buffer and stream per distinct device (the addresses are only compared)
+            std::vector<void*> bufs;
+            std::vector<hipStream_t> streams;
+            for (size_t k = 0; k < plan.devs.size(); k++) bufs.push_back(reinterpret_cast<void*>((intptr_t)(0x1000 * (k + 1)))), streams.push_back(nullptr);
+            if (plan.devs.size() > 1) {
+                const int s1 = rccl_reduce_to_first(stub, ops, plan.devs, bufs, streams, 12, false);
+                say("status=" + std::to_string(s1));
+                if (s1 != RAYRS_OK && st == RAYRS_OK) st = s1;
+            } else {
+                say("one device: no collective");
+            }
+        }
+        say("communicator_sets=" + std::to_string(stub.comms.size()));
+        g_rehearsal = nullptr;
+        const size_t m = std::min<size_t>(reh.log.size(), cap - 1);
+        std::memcpy(log, reh.log.data(), m);
+        log[m] = 0;
         return st;
     })
 }

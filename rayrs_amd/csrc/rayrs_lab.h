@@ -36,9 +36,8 @@ typedef struct {
                                of single primitives: what rounds 2 and 3 walked, kept for the same-box A/B of
                                profiles/r04_tight_leaves.txt */
     uint32_t hot_group;     /* 0xffffffff = the default walk reads the whole gate tree also where the scene has a hot group
-                               (layout.h HotGroupDev): the walk of round 5, kept for the same-box A/B */
-    uint32_t hot_min;       /* traversal: run the hot-group phase once this many lanes owe the test (40) */
-    uint32_t hot_wait;      /* ... or once this many of them have finished their walk and wait for nothing else (8) */
+                               (layout.h HotGroupDev), and the kernels that make rays pre-test nothing: the walk of round 5,
+                               kept for the same-box A/B */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
@@ -48,6 +47,13 @@ int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab);
  * local-pool route: its launch, 0, 0).  Returns the number of rounds (negative: rayrs_status); writes min(rounds,
  * cap_rounds) * 3 floats. */
 int rayrs_lab_round_ms(rayrs_scene* scene, float* out, uint32_t cap_rounds);
+
+/* The calls rayrs_render_multi's reduce makes for ranks on these devices -- the plan (which rank leads a device, which
+ * are summed on it first), ncclCommInitAll once per device list, the grouped in-place ncclReduce to root 0, the syncs --
+ * `rounds` times against a RECORDING table instead of librccl and the HIP runtime: no GPU is touched, so the path a node
+ * of N distinct devices takes can be checked on a box that has none (tests/test_multi_plan.py).  fail_reduce_at >= 0: that
+ * ncclReduce (counted over all rounds) reports an error.  log: ';'-separated record.  Returns the first non-OK status. */
+int rayrs_lab_multi_rehearse(const int* rank_devices, uint32_t n, uint32_t rounds, int fail_reduce_at, char* log, uint32_t cap);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@
 
 #include "device_path.h"
 #include "kernels.h"
+#include "lab_ticks.h"
 #include "wavefront.h"
 
 namespace rayrs {
@@ -265,7 +266,50 @@ struct SampleCount {
     unsigned long long direct;    // of them: primary rays that missed the root box (answered here, below)
     unsigned long long deferred;  // of them: primary rays that missed the root box, left to the miss kernel (DEFER)
     uint32_t retired;             // slots that found no further item
+    // wave-uniform (scalar) tallies of finish_rays, the pre-test of the rays these kernels make:
+    HotTally hot;                 // the hot group's gate and primitive tests
+    uint32_t pre_miss;            // bounced rays that missed the root box: a Miss (bvh.rs:394), left to the miss kernel
+    uint32_t pre_done;            // rays that entered the root box and none of the four slots of the walk tree's first record:
+                                  // their query ends with the hot group's answer, here
 };
+
+// ---- the pre-test of a new ray by the kernel that made it (scenes with a hot group: layout.h HotGroupDev) ----
+// BvhTree::intersect begins every query with the root Node's box (bvh.rs:394).  On a scene with a hot group the default
+// walk then owes the ray (i) the hot group -- its gating box, its primitives -- and (ii) the walk of the tree without it,
+// which begins with that tree's first record.  (i) and the first record of (ii) are wave-uniform data, and the kernels
+// that MAKE rays hold them in full waves (compacted batches), so they do both here, for every ray of a batch at once:
+//   * a ray that misses the root box is a Miss: state MISS;
+//   * the closest hit so far -- the hot group's -- is written to the slot (RaySlot::t / prim: t1 and "none" without one);
+//   * a ray that enters none of the first record's four slots has nothing left to visit: its query is answered, state HIT
+//     or MISS, and it never travels through the traversal kernel (six rays in ten on the headline frame);
+//   * the others become READY: the traversal kernel takes the closest hit so far from the slot and starts at the first
+//     record (which it tests again: a record is a unit of its walk).
+// Every test is the one BvhTree::intersect makes, on the same values; the closest hit is the smallest accepted t, the
+// first primitive in depth-first order on exact ties (bvh.rs:62), in whatever order and by whichever kernel the
+// primitives are tested.  `got`: the lane holds a ray (o, d) for `slot`; `enters`: it is known to enter the root box.
+RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o, V3 d, V3 inv, uint32_t bd, const SceneDev& sc,
+                        const WfDev& wf, SampleCount& sn) {
+    Trav tv;
+    tv.inv = inv, tv.best_t = sc.t1, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
+    WorkCount wc{0, 0, 0, 0, 0};
+    const bool live = got && enters;
+    hot_group_step<false>(sc, o, d, live, tv, wc, sn.hot);
+    const bool walk = live && hot_root_record_entered(sc, o, inv);
+    sn.pre_done += (uint32_t)__popcll(__ballot(live && !walk));
+    sn.pre_miss += (uint32_t)__popcll(__ballot(got && !enters && !primary));
+    if (got) {
+        RaySlot* rs = ray_slot(wf, slot);
+        rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
+        rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
+        rs->bd = bd;
+        const bool hit = tv.best_prim != 0xffffffffu;
+        if (walk || hit) {  // (a MISS says it all: nothing reads t or prim of such a slot)
+            rs->t = tv.best_t;
+            rs->prim = tv.best_prim;
+        }
+        wf.state[slot] = walk ? ready_state(d) : (hit ? WF_HIT : WF_MISS);
+    }
+}
 
 // A primary ray that misses the box of the BVH's root Node is a Miss before anything else is looked at
 // (bvh.rs:394), so its sample is the background (lib.rs:555) -- finished here, in registers, instead of
@@ -277,10 +321,14 @@ struct SampleCount {
 // fetch that the lane waits for with everything the wave has stored so far still in flight (a wave's memory operations
 // complete in order), in nearly every batch (a seventh of the new samples, ~25 of them per batch), and another turn of
 // the loop below: the hit kernel has bandwidth to spare and no latency to spare; the miss kernel does this work anyway.
+// CARRY (the hit kernel): lanes whose path goes on bring their bounced ray (co, cd, cbd) along; it is written out at the
+// end together with the new samples' primary rays, so that the pre-test above runs once, on a full wave.
 template <bool COMPACT, bool DEFER = false>
 RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
                         const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
-                        SampleCount& sn) {
+                        SampleCount& sn, bool carry = false, V3 co = V3{0.0, 0.0, 0.0}, V3 cd = V3{0.0, 0.0, 1.0},
+                        uint32_t cbd = 0u) {
+    const bool pre = sc.hot != nullptr;  // wave-uniform: the rays made here are pre-tested (finish_rays)
     bool todo = want;  // lanes still without a ray for their slot
     bool has_item = want && ir.has_item != 0u;
     uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
@@ -288,6 +336,10 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     double acc0 = ir.acc[0], acc1 = ir.acc[1], acc2 = ir.acc[2];
     bool fresh = false;            // the slot's item record has to be written in full
     bool acc_write = acc_dirty;    // the item goes on with a sum the slot does not hold yet
+    // the ray the lane ends up with, written out behind the loop
+    bool got = carry, enters = true;
+    V3 o = co, d = cd, inv = mk(0.0, 0.0, 0.0);
+    uint32_t bd = cbd;
     for (;;) {
         // an item whose samples are all done is written out (its sum goes to the resolve kernel)
         if (todo && has_item && s_cur >= s_end) {
@@ -341,12 +393,15 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
             Rng rng;
             rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
             rng.draw = 0;
-            V3 o, d;
             // image origin is upper left, camera origin lower right (main.rs:74-75)
             primary_ray(cam, cam.H - row, cam.W - col, rng, o, d);
             sn.paths++;
             s_cur++;
-            const bool enters = root_box_hit(sc, o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z));
+            // (DEFER with the pre-test: 1 / d and the root box wait for the end, where the bounced rays need them too)
+            if (!(DEFER && pre)) {
+                inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                enters = root_box_hit(sc, o, inv);
+            }
             if (!enters && !DEFER) {
                 // radiance() with the first query a Miss: light 0 + throughput 1 * background (lib.rs:522-523, :555)
                 const V3 result = v_add(mk(0.0, 0.0, 0.0), v_mul(mk(1.0, 1.0, 1.0), background(sc, d)));
@@ -355,11 +410,9 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                 acc2 += result.z;
                 acc_write = true;
                 sn.direct++;
+                enters = true;
             } else {
-                RaySlot* rs = ray_slot(wf, slot);
-                rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
-                rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
-                rs->bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
+                bd = 1u | (rng.draw << 16);  // first query; throughput 1 and light 0 are implied
                 TailSlot* t = tail_slot(wf, slot);
                 t->s_cur = s_cur | SLOT_ITEM_BIT;  // a new path: no light yet
                 if (fresh) {
@@ -368,27 +421,58 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                     t->pix = row << 16 | col;  // both below 2^16 (checked at launch)
                 }
                 if (fresh || acc_write) t->acc[0] = acc0, t->acc[1] = acc1, t->acc[2] = acc2;
-                if (DEFER && !enters) {
-                    wf.state[slot] = WF_MISS;  // the root box test was this ray's query (bvh.rs:394): the miss kernel's
-                    sn.deferred++;
-                } else {
-                    wf.state[slot] = ready_state(d);
-                }
+                got = true;
                 todo = false;
             }
         }
         if (__ballot(todo) == 0ull) break;
     }
+    // ---- the rays: bounced ones brought along (carry) and the new samples' primary rays
+    if (__ballot(got) == 0ull) return;
+    const bool primary = got && !carry;
+    if (pre) {
+        if (DEFER) {  // every ray of the batch: 1 / d and the root Node's box (bvh.rs:394)
+            inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            enters = root_box_hit(sc, o, inv);
+        }
+        if (primary && !enters) sn.deferred++;  // (only with DEFER: elsewhere such a sample was finished above)
+        finish_rays(got, enters, primary, slot, o, d, inv, bd, sc, wf, sn);
+    } else if (got) {
+        RaySlot* rs = ray_slot(wf, slot);
+        rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
+        rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
+        rs->bd = bd;
+        if (primary && !enters) {  // DEFER
+            wf.state[slot] = WF_MISS;  // the root box test was this ray's query (bvh.rs:394): the miss kernel's
+            sn.deferred++;
+        } else {
+            wf.state[slot] = ready_state(d);  // (a bounced ray's root box is the traversal kernel's to test)
+        }
+    }
 }
 
 // rays and samples the sample-starting kernels account for, one atomic each per wave
-RR_DEV void store_sample_count(const RenderDev& rp, const WfDev& wf, const SampleCount& sn) {
+RR_DEV void store_sample_count(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, const SampleCount& sn) {
     wave_atomic_add(&rp.counters->paths, sn.paths);
     const unsigned long long direct = wave_sum(sn.direct), deferred = wave_sum(sn.deferred);
-    if ((threadIdx.x & 63u) == 0 && (direct | deferred)) {
-        atomicAdd(&rp.counters->rays, direct + deferred);
+    const unsigned long long pre = (unsigned long long)sn.pre_miss + sn.pre_done;  // queries answered by finish_rays
+    if ((threadIdx.x & 63u) == 0 && (direct | deferred | pre)) {
+        atomicAdd(&rp.counters->rays, direct + deferred + pre);
         if (direct) atomicAdd(&rp.counters->escaped_paths, direct);  // (the miss kernel counts the deferred ones' escape)
-        atomicAdd(&rp.counters->direct_rays, direct + deferred);
+        if (direct | deferred) atomicAdd(&rp.counters->direct_rays, direct + deferred);
+    }
+    if (rp.count_work && sc.hot != nullptr && (threadIdx.x & 63u) == 0) {  // what the pre-test did, for the work counters
+        Counters* c = rp.counters;
+        const HotPtr h = hot_ptr(sc);
+        const unsigned long long e = sn.hot.entered;
+        atomicAdd(&c->pre_rays, pre);
+        atomicAdd(&c->interior_visits, (unsigned long long)sn.pre_done);  // the first record of the walk tree, for the rays that end there
+        atomicAdd(&c->hot_lane, (unsigned long long)sn.hot.owed);
+        atomicAdd(&c->hot_prim_tests, e * h->count);
+        atomicAdd(&c->hot_tri_divided, (unsigned long long)sn.hot.divided);
+        if (h->n_tri) atomicAdd(&c->tri_tests, e * h->n_tri);
+        if (h->n_sphere) atomicAdd(&c->sphere_tests, e * h->n_sphere);
+        if (h->n_plane) atomicAdd(&c->plane_tests, e * h->n_plane);
     }
     const uint32_t r = (uint32_t)wave_sum(sn.retired);
     if ((threadIdx.x & 63u) == 0 && r) atomicSub(&wf.ctl->live_slots, r);
@@ -403,7 +487,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    SampleCount sn{0, 0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -420,7 +504,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
         }
     }
     store_item_range(wf, wave, range);
-    store_sample_count(rp, wf, sn);
+    store_sample_count(sc, rp, wf, sn);
 }
 
 // ------------------------------------------------------------------- trav
@@ -430,12 +514,10 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
 
-// HOT (the default walk on a scene with a hot group, layout.h HotGroupDev): a third phase kind.  Every ray that enters
-// the root box OWES the hot group its test -- gating box, then the group's primitives (device_path.h hot_group_step) -- once,
-// at any point of its walk; the lane walks the tree meanwhile.  The phase runs for all the lanes that owe it together:
-// once rp.hot_min of them do, or once rp.hot_wait of them have finished their walk and wait for nothing else (a lane is
-// retired only when it owes nothing), or when the wave has nothing else to do.
-template <bool COMPACT, bool COUNT, bool EXACT, bool HOT>
+// PRE (the default walk on a scene with a hot group, layout.h HotGroupDev): the rays come pre-tested by the kernel that
+// made them (finish_rays above) -- they are known to enter the root box and at least one slot of the tree's first record,
+// and the slot holds the closest hit so far (the hot group's): the walk starts from that, at the first record.
+template <bool COMPACT, bool COUNT, bool EXACT, bool PRE>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
@@ -473,7 +555,6 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     bool no_more = false;                                // wave-uniform: window cursor ran off the end
 
     bool active = false, pending = false;
-    bool owe = false;  // HOT: the lane's ray has not been through the hot group yet
     uint32_t slot = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     Trav tv;
@@ -481,38 +562,16 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     WorkCount wc{0, 0, 0, 0, 0};
     unsigned long long n_rays = 0;
     unsigned long long u_int_wave = 0, u_int_lane = 0, u_leaf_wave = 0, u_leaf_lane = 0;
-    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_hot = 0, tk_last = COUNT ? clock64() : 0ull;
-    unsigned long long u_hot_wave = 0, u_hot_lane = 0;
-    HotTally ht{0, 0, 0};
+    unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
 
     for (;;) {
         const bool at_int = active && trav_at_interior(tv);
         const bool at_leaf = active && !trav_at_interior(tv);
         const int n_int = __popcll(__ballot(at_int));
         const int n_leaf = __popcll(__ballot(at_leaf));
-        int n_wait = 0;  // HOT: lanes whose walk has ended but which still owe the hot group its test: neither retired nor refilled
-        if (HOT) {
-            const unsigned long long owe_mask = __ballot(owe);
-            if (owe_mask != 0ull) {
-                const int n_owe = __popcll(owe_mask);
-                n_wait = __popcll(__ballot(owe && !active));
-                if (n_owe >= (int)rp.hot_min || n_wait >= (int)rp.hot_wait || n_int + n_leaf == 0) {
-                    // ---- hot-group phase: every lane that owes the test
-                    if (COUNT) u_hot_wave += 1, u_hot_lane += owe ? 1 : 0;
-                    hot_group_step<COUNT>(sc, o, d, owe, tv, wc, ht);
-                    owe = false;
-                    if (COUNT) {
-                        const unsigned long long now = clock64();
-                        tk_hot += now - tk_last, tk_last = now;
-                    }
-                    continue;
-                }
-            }
-        }
-        // (waiting lanes count as occupied: a refill must find lanes to fill, or the wave would come back here for ever)
-        if ((n_int + n_leaf + n_wait < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
-            // ---- retire finished queries: result and new state to the slot (HOT: of lanes that owe nothing)
-            if (pending && !(HOT && owe)) {
+        if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
+            // ---- retire finished queries: result and new state to the slot
+            if (pending) {
                 const bool hit = tv.best_prim != 0xffffffffu;
                 if (hit) {  // (a MISS says it all: nothing reads t or prim of such a slot, and its line stays clean)
                     RaySlot* rs = ray_slot(wf, slot);
@@ -524,7 +583,7 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             }
             if (no_more) break;  // only reached with no query in flight
             // ---- idle lanes take rays from the wave's window list
-            bool need = !active && !pending;
+            bool need = !active;
             unsigned long long need_mask = __ballot(need);
             while (need_mask != 0ull) {
                 if (list_pos >= list_len) {
@@ -552,11 +611,20 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
                     n_rays++;
-                    trav_init(sc, o, d, tv);
-                    if (tv.cur == TRAV_DONE)
-                        pending = true;  // missed the root box: retired at the next refill
-                    else
-                        active = true, owe = HOT;
+                    if (PRE) {
+                        tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                        tv.best_t = rs->t;
+                        tv.best_prim = rs->prim;
+                        tv.sp = 0;
+                        tv.cur = sc.root_ref;
+                        active = true;
+                    } else {
+                        trav_init(sc, o, d, tv);
+                        if (tv.cur == TRAV_DONE)
+                            pending = true;  // missed the root box: retired at the next refill
+                        else
+                            active = true;
+                    }
                     need = false;
                 }
                 const uint32_t wanted = (uint32_t)__popcll(need_mask);
@@ -607,11 +675,6 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         if (lane == 0) {
             atomicAdd(&c->interior_ticks, tk_int), atomicAdd(&c->leaf_ticks, tk_leaf);
             atomicAdd(&c->refill_ticks, tk_refill);
-            if (HOT) atomicAdd(&c->hot_ticks, tk_hot);
-        }
-        if (HOT) {
-            wave_atomic_add(&c->hot_wave, u_hot_wave), wave_atomic_add(&c->hot_lane, u_hot_lane);
-            if (lane == 0) atomicAdd(&c->hot_prim_tests, (unsigned long long)ht.entered * hot_ptr(sc)->count), atomicAdd(&c->hot_tri_divided, (unsigned long long)ht.divided);
         }
     }
 }
@@ -666,7 +729,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    SampleCount sn{0, 0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -682,12 +745,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
         load_hit_in<EAGER>(wf, cur);
         rec_cur = load_prim<COMPACT>(sc.prims, cur.valid ? cur.prim : 0u);
     }
-#ifdef RAYRS_LAB_TICKS
-    unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, tk_n = 0, tk_last = clock64();
-#define RR_TICK(i) { const unsigned long long now_ = clock64(); tk[i] += now_ - tk_last, tk_last = now_; }
-#else
-#define RR_TICK(i)
-#endif
+    RR_TICKS_BEGIN(7);
     while (have) {
         HitIn nxt;
         bool have_next = false;
@@ -705,10 +763,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             V3 thr = mk(1.0, 1.0, 1.0), light = mk(0.0, 0.0, 0.0), position = mk(0.0, 0.0, 0.0), dir = mk(0.0, 0.0, 1.0);
             uint32_t bd_next = 0;
             if (valid) {
-#ifdef RAYRS_LAB_TICKS
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (LAB build: the wait for this batch's records, apart from the arithmetic)
-                RR_TICK(6)
-#endif
+                RR_TICK_LOADS_ARRIVED(6)
                 const V3 o = cur.o;
                 const V3 d = cur.d;
                 const double t = cur.t;
@@ -757,10 +812,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
             RR_TICK(2)
             if (goes_on) {
-                RaySlot* rs = ray_slot(wf, slot);
-                rs->o[0] = position.x, rs->o[1] = position.y, rs->o[2] = position.z;
-                rs->d[0] = dir.x, rs->d[1] = dir.y, rs->d[2] = dir.z;
-                rs->bd = bd_next;
+                // (the bounced ray itself -- origin, direction, bounce | draw, state -- is written by next_sample below, together
+                // with the new samples' primary rays: one pre-test for the whole batch, finish_rays)
                 TailSlot* lt = tail_slot(wf, slot);
                 lt->thr[0] = thr.x, lt->thr[1] = thr.y, lt->thr[2] = thr.z;
                 const bool keep_light = !light_is_plus_zero(light);
@@ -771,7 +824,6 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 // (the cursor word changes only when the path gets or loses its light: mostly it is left alone, and with
                 // it the 32-byte sector it lies in -- stores cost these kernels more than anything they compute)
                 if (keep_light != (ir.has_light != 0u)) lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
-                wf.state[slot] = ready_state(dir);
             }
             if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
 #pragma unroll
@@ -781,26 +833,17 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
             }
             RR_TICK(3)
-            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn, goes_on, position, dir, bd_next);
             RR_TICK(4)
         }
         cur = nxt;
         rec_cur = rec_nxt;
         have = have_next;
-#ifdef RAYRS_LAB_TICKS
-        tk_n++;
-#endif
+        RR_TICKS_BATCH();
     }
-#ifdef RAYRS_LAB_TICKS
-    if ((threadIdx.x & 63u) == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(&rp.counters->lab_ticks[i], tk[i]);
-        atomicAdd(&rp.counters->lab_ticks[5], tk_n);
-        atomicAdd(&rp.counters->lab_ticks[6], tk[5]), atomicAdd(&rp.counters->lab_ticks[7], tk[6]);
-    }
-#endif
-#undef RR_TICK
+    RR_TICKS_END_HIT(rp)
     store_item_range(wf, wave, range);
-    store_sample_count(rp, wf, sn);
+    store_sample_count(sc, rp, wf, sn);
 }
 
 // ------------------------------------------------------------------- miss
@@ -833,19 +876,14 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
-    SampleCount sn{0, 0, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
     MissIn cur;
     bool have = feed_next(feed, wf, cur.slot, cur.valid);
     if (have) load_miss_in<EAGER>(wf, cur);
-#ifdef RAYRS_LAB_TICKS
-    unsigned long long tk[3] = {0, 0, 0}, tk_n = 0, tk_last = clock64();
-#define RR_TICK(i) { const unsigned long long now_ = clock64(); tk[i] += now_ - tk_last, tk_last = now_; }
-#else
-#define RR_TICK(i)
-#endif
+    RR_TICKS_BEGIN(3);
     while (have) {
         MissIn nxt;
         const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
@@ -868,21 +906,13 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
         RR_TICK(2)
         cur = nxt;
         have = have_next;
-#ifdef RAYRS_LAB_TICKS
-        tk_n++;
-#endif
+        RR_TICKS_BATCH();
     }
-#ifdef RAYRS_LAB_TICKS
-    if ((threadIdx.x & 63u) == 0) {
-        for (int i = 0; i < 3; i++) atomicAdd(&rp.counters->lab_ticks[8 + i], tk[i]);
-        atomicAdd(&rp.counters->lab_ticks[11], tk_n);
-    }
-#endif
-#undef RR_TICK
+    RR_TICKS_END_MISS(rp)
     n_escaped = feed.total;
     store_item_range(wf, wave, range);
     if (lane == 0 && n_escaped) atomicAdd(&rp.counters->escaped_paths, n_escaped);
-    store_sample_count(rp, wf, sn);
+    store_sample_count(sc, rp, wf, sn);
 }
 
 // ----------------------------------------------------------- launch glue
@@ -909,7 +939,7 @@ template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
     const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
-    if (sc.exact && sc.hot) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
+    if (sc.exact && sc.hot) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);  // PRE
     else if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     return hipGetLastError();

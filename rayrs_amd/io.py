@@ -42,6 +42,19 @@ def load_obj(path):
     return _take(v, nv.value * 3, np.float64).reshape(-1, 3), _take(i, nt.value * 3, np.uint32).reshape(-1, 3)
 
 
+def load_obj_spheres(path, radius, mat=None, emission=None):
+    """wavefront_obj::load_obj_file_spheres(filename, radius) (wavefront_obj.rs:46-64): one sphere per `v` line.
+    -> centres (n,3) float64; with a material and an emission, the Vec<Object> Object::from_spheres makes of them."""
+    L = _ffi.lib()
+    c, n = C.c_void_p(), C.c_uint32()
+    _ffi.check(L.rayrs_obj_load_spheres(str(path).encode(), C.byref(c), C.byref(n)), "rayrs_obj_load_spheres")
+    centers = _take(c, n.value * 3, np.float64).reshape(-1, 3)
+    if mat is None:
+        return centers
+    from .api import Object
+    return Object.from_spheres(float(radius), centers, mat, emission)
+
+
 def load_hdr(path):
     """-> (H, W, 3) float32, what HdrDecoder::read_image_hdr yields (main.rs:36-41)."""
     L = _ffi.lib()

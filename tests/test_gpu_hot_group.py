@@ -1,10 +1,13 @@
-"""The default walk's hot-group phase (layout.h HotGroupDev, device_path.h hot_group_step, wavefront.hip HOT) on the GPU.
+"""The default walk's hot group and the pre-test of new rays (layout.h HotGroupDev, device_path.h hot_group_step,
+wavefront.hip finish_rays) on the GPU.
 
 The hot group -- on the obj scenes the floor's bottom Node: the 50 x 50 rectangle and the three mesh triangles the
-reference's builder left beside it -- is tested once per ray by a wave's lanes together, outside the tree.  What must hold:
-the frame, the ray counts and the primitive-test counts are those of the walk over the whole gate tree (rayrs_lab
-hot_group = 0xffffffff) and of the oracle; rays aimed AT the group's primitives, where the phase's early rejection is not
-settled and the divisions are made, return the recursion's hits bit for bit; and when the phase runs changes nothing."""
+reference's builder left beside it -- is tested once per ray, outside the tree, by the kernel that MAKES the ray, for a
+whole batch at once, together with the first record of the tree without it; a ray that enters none of that record's slots
+never travels through the traversal kernel.  What must hold: the frame, the ray counts and the primitive-test counts are
+those of the walk over the whole gate tree (rayrs_lab hot_group = 0xffffffff) and of the oracle; rays aimed AT the group's
+primitives, where the early rejection is not settled and the divisions are made, return the recursion's hits bit for bit;
+and how the frame is cut up -- pool size, sample chunk, tile share -- changes nothing."""
 import numpy as np
 import pytest
 
@@ -42,16 +45,18 @@ def test_the_frame_and_the_tests_made_are_those_of_the_whole_gate_tree():
     scene, cam, osc, ocam, _ = make(4, 96, 64)
     assert scene.info()["hot_count"] >= 1
     img, st = rayrs_amd.render(scene, cam, 8, out_f64=True, count_work=True)
-    assert st["hot_group"] == 1 and st["exact_walk"] == 1 and st["hot_lane"] > 0
+    assert st["hot_group"] == 1 and st["exact_walk"] == 1 and st["hot_lane"] > 0 and 0 < st["pre_rays"] < st["rays"]
+    assert st["hot_prim_tests"] == scene.info()["hot_count"] * (st["hot_prim_tests"] // scene.info()["hot_count"]) > 0
+    assert st["hot_tri_divided"] < st["hot_prim_tests"] // 4   # most of the group's triangle tests are settled before the divisions
     scene.lab_set(hot_group=0xffffffff)
     ref, rst = rayrs_amd.render(scene, cam, 8, out_f64=True, count_work=True)
-    assert rst["hot_group"] == 0 and rst["hot_lane"] == 0
+    assert rst["hot_group"] == 0 and rst["hot_lane"] == 0 and rst["pre_rays"] == 0
     scene.lab_set()
     assert np.array_equal(bits(img), bits(ref))
     for k in ("rays", "paths", "tri_tests", "sphere_tests", "plane_tests", "escaped_paths"):
         assert st[k] == rst[k], k
     assert st["interior_visits"] < rst["interior_visits"]
-    # every ray that enters the root box owes the group its test exactly once (bounced rays that leave the scene miss it)
+    # every ray that enters the root box is put to the group's gate exactly once (bounced rays that leave the scene miss it)
     assert 0 < st["hot_lane"] <= st["rays"] - st["direct_rays"]
     # the oracle: its recursion (the parity claim) and its walk of the product's records with the group beside them (the counters)
     oref, ost = osc.render(ocam, 8, traversal=0)
@@ -105,18 +110,30 @@ def test_rays_aimed_at_the_groups_primitives_return_the_recursions_hits():
     assert np.array_equal(obj2, robj) and np.array_equal(bits(t2), bits(rt))
 
 
-@pytest.mark.parametrize("lab", [dict(hot_min=1, hot_wait=1), dict(hot_min=64, hot_wait=64), dict(hot_min=16, hot_wait=2),
-                                 dict(hot_min=64, hot_wait=1, refill_min=64), dict(hot_min=8, hot_wait=64, leaf_min=1)],
-                         ids=["at_once", "only_when_idle", "early", "every_refill", "leaves_first"])
-def test_when_the_phase_runs_changes_nothing(lab):
-    scene, cam, osc, ocam, _ = make(3, 64, 48, area_light=True)
-    ref, rst = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True)
-    scene.lab_set(**lab)
-    img, st = rayrs_amd.render(scene, cam, 6, out_f64=True, count_work=True)
-    assert st["hot_group"] == 1
-    assert np.array_equal(bits(img), bits(ref))
-    for k in ("rays", "interior_visits", "tri_tests", "plane_tests", "hot_lane"):
-        assert st[k] == rst[k], k
+@pytest.mark.parametrize("how", [dict(pool_slots=1024), dict(sample_chunk=1), dict(sample_chunk=5, pool_slots=4096), dict(ranks=3),
+                                 dict(lab=dict(refill_min=64, leaf_min=1)), dict(lab=dict(stack_lds=2))],
+                         ids=["tiny_pool", "chunk_1", "chunk_5_small_pool", "three_tile_shares", "thresholds", "stack_in_hbm"])
+def test_how_the_frame_is_cut_up_changes_nothing(how):
+    """A tiny pool (many rounds: slots answered by the kernels that make the rays wait a round in state HIT or MISS), other
+    sample chunks, tile shares, other thresholds: the same frame, the same counters."""
+    scene, cam, osc, ocam, _ = make(3, 61, 43, area_light=True)
+    spp = 7
+    chunk = how.get("sample_chunk", 0)
+    oref, ost = osc.render(ocam, spp, 50, sample_chunk=chunk, traversal=0)
+    _, wst = osc.use_product_walk(scene).render(ocam, spp, 50, sample_chunk=chunk, traversal=2)
+    scene.set_tuning(pool_slots=how.get("pool_slots", 0))
+    scene.lab_set(**how.get("lab", {}))
+    ranks = how.get("ranks", 1)
+    img, tot = None, {}
+    for r in range(ranks):
+        img, st = rayrs_amd.render(scene, cam, spp, 50, sample_chunk=chunk, out_f64=True, count_work=True, tile_rank=r, tile_ranks=ranks, out=img)
+        assert st["hot_group"] == 1
+        for k in ("rays", "paths", "interior_visits", "tri_tests", "plane_tests", "escaped_paths", "pre_rays", "hot_lane"):
+            tot[k] = tot.get(k, 0) + st[k]
+    assert np.array_equal(bits(img), bits(oref))
+    for k in ("rays", "interior_visits", "tri_tests", "plane_tests", "escaped_paths"):
+        assert tot[k] == wst[k], k
+    assert tot["rays"] == ost["rays"] and 0 < tot["pre_rays"] < tot["rays"]
 
 
 def test_a_group_of_spheres_and_a_rectangle_can_be_the_hot_group():

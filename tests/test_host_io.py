@@ -47,6 +47,24 @@ def test_obj_loader_follows_the_reference(tmp_path):
     assert i.tolist() == [[0, 1, 2], [0, 2, 3]]  # 1-based -> 0-based (wavefront_obj.rs:37-41)
 
 
+def test_obj_sphere_loader_follows_the_reference(tmp_path):
+    """wavefront_obj::load_obj_file_spheres (wavefront_obj.rs:46-64): one sphere of the given radius per `v` line; `f` lines --
+    even ones load_obj_file would choke on -- and everything else are skipped."""
+    p = tmp_path / "s.obj"
+    p.write_text("# comment\nv 0 0 0\nv 1 0.5 -2\nvn 0 0 1\nf 1 2 99\nf nonsense\nv 0.5 0.25 1e-3\n")
+    c = io.load_obj_spheres(p, 0.1)
+    assert c.dtype == np.float64 and c.tolist() == [[0, 0, 0], [1, 0.5, -2], [0.5, 0.25, 1e-3]]
+    from rayrs_amd.api import Emission, Material
+    objs = io.load_obj_spheres(p, 0.1, Material.NoReflect(), Emission.Dark())
+    assert [o.kind for o in objs] == ["sphere"] * 3 and objs[1].radius == 0.1 and objs[1].origin == (1.0, 0.5, -2.0)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 1 2\n")
+    with pytest.raises(_ffi.RayrsError):
+        io.load_obj_spheres(bad, 1.0)
+    with pytest.raises(_ffi.RayrsError):
+        io.load_obj_spheres(tmp_path / "missing.obj", 1.0)
+
+
 def test_hdr_round_trip_within_rgbe_precision(tmp_path):
     img = procedural.make_hdri(64, 32)
     img[0, 0] = 0.0

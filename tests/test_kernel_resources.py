@@ -37,16 +37,16 @@ def pick(res, *parts):
 def test_streaming_kernels_keep_their_occupancy(tmp_path):
     res = kernel_resources("wavefront.hip", tmp_path)
     # the timed traversal kernels (COUNT = false, EXACT = false): five waves per SIMD, nothing in scratch
-    # (template arguments: COMPACT, COUNT, EXACT, HOT)
+    # (template arguments: COMPACT, COUNT, EXACT, PRE)
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb0ELb0EEE").items():
         assert vgpr <= 96 and scratch == 0, (name, vgpr, scratch)
     # the default walk's instances (EXACT: nothing culled): the same occupancy; at most the stack strip's pointer
     # parked in scratch for the deep-stack path, never a spill inside the walk
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb1ELb0EEE").items():
         assert vgpr <= 96 and scratch <= 16, (name, vgpr, scratch)
-    # ... with the hot-group phase (HOT): the same, plus at most one more pair parked
+    # ... for pre-tested rays (PRE: scenes with a hot group): the same
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb1ELb1EEE").items():
-        assert vgpr <= 96 and scratch <= 24, (name, vgpr, scratch)
+        assert vgpr <= 96 and scratch <= 16, (name, vgpr, scratch)
     # hit: two waves per SIMD (its look-ahead batch fills the file), miss: three; no scratch in either
     for name, (vgpr, scratch) in pick(res, "wf_hit_kernel").items():
         assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
