@@ -158,41 +158,58 @@ def hot_group_kinds(scene, info, objs):
     return kinds.count("triangle"), kinds.count("sphere"), kinds.count("plane")
 
 
+def hot_counts(stats, hot_kinds):
+    """(triangle, sphere, rectangle) tests of the frame made on the hot group, by the kernels that make the rays."""
+    if not stats.get("hot_group"):
+        return 0, 0, 0
+    entered = stats["hot_prim_tests"] // max(sum(hot_kinds), 1)
+    return tuple(entered * k for k in hot_kinds)
+
+
 def traversal_ops(stats, info, hot_kinds=(0, 0, 0)):
-    """Useful f64-rate lane operations of the frame's BVH walks (records entered, primitives tested)."""
+    """Useful f64-rate lane operations of the BVH walks the TRAVERSAL kernel (or the local-pool kernel) makes: records
+    entered, primitives tested.  On a scene with a hot group the kernels that make the rays test that group and the walk
+    tree's first record (pretest_ops): those tests are not in here."""
     rec = OPS_RECORD_COMPACT if info["compact"] else OPS_RECORD_F64
     if stats.get("exact_walk"):  # (the local-pool kernel's loop over a record's gates neither culls nor ranks either)
         rec -= OPS_RECORD_NO_CULL
     tri = OPS_TRIANGLE_COMPACT if info["compact"] else OPS_TRIANGLE_F64
-    ops = stats["interior_visits"] * rec
-    n_tri, n_sph, n_pl = stats["tri_tests"], stats["sphere_tests"], stats["plane_tests"]
-    if stats.get("hot_group"):
-        # the hot-group phase: its gate per ray that owed the test, its primitives per ray that entered it, on uniform f64 data
-        entered = stats["hot_prim_tests"] // max(sum(hot_kinds), 1)
-        h_tri, h_sph, h_pl = (entered * k for k in hot_kinds)
-        ops += stats["hot_lane"] * OPS_HOT_GATE + h_tri * OPS_HOT_TRIANGLE + stats["hot_tri_divided"] * OPS_HOT_DIVISIONS
-        n_tri, n_sph, n_pl = n_tri - h_tri, n_sph - h_sph, n_pl - h_pl
-        ops += h_sph * OPS_SPHERE + h_pl * OPS_PLANE
-    return ops + n_tri * tri + n_sph * OPS_SPHERE + n_pl * OPS_PLANE
+    h_tri, h_sph, h_pl = hot_counts(stats, hot_kinds)
+    return ((stats["interior_visits"] - stats.get("pre_root_records", 0)) * rec + (stats["tri_tests"] - h_tri) * tri
+            + (stats["sphere_tests"] - h_sph) * OPS_SPHERE + (stats["plane_tests"] - h_pl) * OPS_PLANE)
+
+
+def traversal_rays(stats):
+    """Rays the traversal kernel takes from the pool: not the primary rays that miss the root box (direct_rays: the kernel
+    that makes them finishes their sample), not the queries answered by the pre-test (pre_rays)."""
+    return stats["rays"] - stats.get("direct_rays", 0) - stats.get("pre_rays", 0)
+
+
+def pretest_ops(stats, info, hot_kinds=(0, 0, 0)):
+    """Useful lane operations of the pre-test (wavefront.hip finish_rays) in the kernels that make the rays: 1 / d and the
+    root box for the bounced rays (a new sample's are in OPS_SAMPLE), the hot group's gate and primitives, the walk tree's
+    first record for every ray that enters the root box -- all on wave-uniform f64 data."""
+    if not stats.get("hot_group"):
+        return 0
+    h_tri, h_sph, h_pl = hot_counts(stats, hot_kinds)
+    bounced = stats["rays"] - stats["paths"]
+    return (bounced * OPS_RAY + stats["hot_lane"] * (OPS_HOT_GATE + 4 * OPS_HOT_GATE) + h_tri * OPS_HOT_TRIANGLE
+            + stats["hot_tri_divided"] * OPS_HOT_DIVISIONS + h_sph * OPS_SPHERE + h_pl * OPS_PLANE)
 
 
 def reference_flops(stats, info, hot_kinds=(0, 0, 0)):
-    """roofline.frac_ref_flops' numerator for the traversal kernel: reference arithmetic only (REF_* above)."""
-    n_tri = stats["tri_tests"]
-    settled = 0
-    flops = stats["interior_visits"] * REF_RECORD
-    if stats.get("hot_group"):
-        entered = stats["hot_prim_tests"] // max(sum(hot_kinds), 1)
-        settled = entered * hot_kinds[0] - stats["hot_tri_divided"]
-        flops += stats["hot_lane"] * REF_BOX
-    return (flops + (n_tri - settled) * REF_TRIANGLE + settled * REF_TRIANGLE_SETTLED + stats["sphere_tests"] * REF_SPHERE
-            + stats["plane_tests"] * REF_PLANE + (stats["rays"] - stats.get("direct_rays", 0)) * REF_RAY)
+    """roofline.frac_ref_flops' numerator for the traversal kernel: reference arithmetic only (REF_* above), of the
+    records and primitives IT visits."""
+    h_tri, h_sph, h_pl = hot_counts(stats, hot_kinds)
+    return ((stats["interior_visits"] - stats.get("pre_root_records", 0)) * REF_RECORD + (stats["tri_tests"] - h_tri) * REF_TRIANGLE
+            + (stats["sphere_tests"] - h_sph) * REF_SPHERE + (stats["plane_tests"] - h_pl) * REF_PLANE
+            + traversal_rays(stats) * (3 if stats.get("hot_group") else REF_RAY))
 
 
 def useful_f64_ops(stats, info, hot_kinds=(0, 0, 0)):
-    """Of the traversal kernel: the walks plus the setup of the rays it took.  Primary rays that miss the root box
-    never reach it (direct_rays: the kernel that makes them finishes their sample)."""
-    return traversal_ops(stats, info, hot_kinds) + (stats["rays"] - stats.get("direct_rays", 0)) * OPS_RAY
+    """Of the traversal kernel: the walks plus the setup of the rays it took (pre-tested rays: 1 / d only -- their root box
+    was the pre-test's)."""
+    return traversal_ops(stats, info, hot_kinds) + traversal_rays(stats) * (OPS_RAY - 21 if stats.get("hot_group") else OPS_RAY)
 
 
 def layout_conversion_ops(stats, info, hot_kinds=(0, 0, 0)):
@@ -200,11 +217,9 @@ def layout_conversion_ops(stats, info, hot_kinds=(0, 0, 0)):
     because of the reference's arithmetic (24 per record, 9 per triangle read from its record)."""
     if not info["compact"]:
         return 0
-    n_tri = stats["tri_tests"]
-    if stats.get("hot_group"):
-        n_tri -= stats["hot_prim_tests"] // max(sum(hot_kinds), 1) * hot_kinds[0]
-    return (stats["interior_visits"] * (OPS_RECORD_COMPACT - OPS_RECORD_F64)
-            + n_tri * (OPS_TRIANGLE_COMPACT - OPS_TRIANGLE_F64))
+    h_tri = hot_counts(stats, hot_kinds)[0]
+    return ((stats["interior_visits"] - stats.get("pre_root_records", 0)) * (OPS_RECORD_COMPACT - OPS_RECORD_F64)
+            + (stats["tri_tests"] - h_tri) * (OPS_TRIANGLE_COMPACT - OPS_TRIANGLE_F64))
 
 
 def surface_units(objs):
@@ -231,12 +246,13 @@ def shading_ops(stats, units):
 
 def algorithmic_bytes(stats, info):
     """bytes the traversal kernel must move on the flattened layout:
-    one record per interior visit and per primitive test, plus, per BVH query, the
-    ray it reads from the path pool (origin + direction, 48 B), the result it
-    writes back (t + primitive, 12 B) and the slot's state byte (read + write)."""
-    return (stats["interior_visits"] * info["node_bytes"]
-            + (stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"]) * info["prim_bytes"]
-            + (stats["rays"] - stats.get("direct_rays", 0)) * (48 + 12 + 2))
+    one record per interior visit and per primitive test (of ITS walks: the pre-test's data is wave-uniform, a few
+    hundred bytes per wave), plus, per BVH query it takes, the ray it reads from the path pool (origin + direction, 48 B; a
+    pre-tested ray's closest hit so far, 12 B), the result it writes back (t + primitive, 12 B) and the slot's state
+    byte (read + write)."""
+    prims = stats["tri_tests"] + stats["sphere_tests"] + stats["plane_tests"] - stats.get("hot_prim_tests", 0)
+    return ((stats["interior_visits"] - stats.get("pre_root_records", 0)) * info["node_bytes"] + prims * info["prim_bytes"]
+            + traversal_rays(stats) * (48 + 12 + 2 + (12 if stats.get("hot_group") else 0)))
 
 
 def source_hash():
@@ -625,9 +641,14 @@ def main():
                 kern = {"lp_path_kernel": {"ms": sum(kernel_ms) / n_st,
                                            "ops": traversal_ops(cst, info, hot_kinds) + cst["rays"] * OPS_RAY + ops_hit + ops_miss + ops_gen}}
             else:
+                # the pre-test of new rays is the work of the kernel that makes them: bounced rays are the hit kernel's, a new
+                # sample's primary ray belongs to the kernel its path ended in
+                ops_pre = pretest_ops(cst, info, hot_kinds)
+                bounced = cst["rays"] - cst["paths"]
+                pre_hit = ops_pre * (bounced + cst["paths"] * (1.0 - share_miss)) / max(cst["rays"], 1)
                 kern = {"wf_trav_kernel": {"ms": sum(kernel_ms) / n_st, "ops": useful_f64_ops(cst, info, hot_kinds)},
-                        "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss)},
-                        "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss}}
+                        "wf_hit_kernel": {"ms": sum(hit_ms) / n_st, "ops": ops_hit + ops_gen * (1.0 - share_miss) + pre_hit},
+                        "wf_miss_kernel": {"ms": sum(miss_ms) / n_st, "ops": ops_miss + ops_gen * share_miss + ops_pre - pre_hit}}
             for k in kern.values():
                 k["share_of_step"] = round(k["ms"] / share_base_ms, 3)
                 k["achieved_Tops"] = round(k["ops"] / max(k["ms"], 1e-9) / 1e9, 3)
@@ -702,6 +723,7 @@ def main():
                               "FP64 FLOP fraction, and is not comparable with the traversal kernel's",
                 "kernels": kern,
                 "useful_ops_per_launch": int(ops / launches), "useful_ops_per_ray": round(ops / max(cst["rays"], 1), 1),
+                "rays_through_the_traversal_kernel": int(traversal_rays(cst)) if not st["local_pool"] else None,
                 "records_per_ray": round(cst["interior_visits"] / max(cst["rays"], 1), 2),
                 "prim_tests_per_ray": round(prims / max(cst["rays"], 1), 2),
                 "lane_utilisation": util,
@@ -861,7 +883,7 @@ def main():
                 # which walk answered the timed frames' BVH queries (rayrs_render_stats.exact_walk)
                 "walk": ("local pool: the gate tree's groups, nothing culled (the reference's visit set)" if main_run["local_pool"] else
                          ("default: the gate tree, nothing culled -- the reference's visit set by construction"
-                          + (", its hot group (the floor's bottom Node) tested once per ray beside the walk" if main_run["hot_group"] else ""))
+                          + ("; root box, hot group (the floor's bottom Node) and the tree's first record are tested by the kernels that make the rays" if main_run["hot_group"] else ""))
                          if main_run["exact_walk"]
                          else "fast_traversal: closest-hit culling + tight leaf boxes (two bets)"),
                 "layout": "compact f32 records" if info["compact"] else "f64 records",

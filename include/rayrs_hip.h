@@ -316,8 +316,10 @@ typedef struct {
                                tested by the kernels that MAKE the rays, for whole batches at once: a ray whose query ends
                                there never travels through the traversal kernel */
     uint32_t stats_pad;
-    uint64_t pre_rays;        /* the next four only with count_work: queries (of `rays`) that were answered by the kernel that made
+    uint64_t pre_rays;        /* the next five only with count_work: queries (of `rays`) that were answered by the kernel that made
                                  the ray -- bounced rays that miss the root box, rays that enter no slot of the walk tree's first record */
+    uint64_t pre_root_records;/* ... of them, the rays that entered the root box: each is one visit of the walk tree's first record
+                                 (counted in interior_visits) that ended the query */
     uint64_t hot_lane;        /* rays put to the hot group's gating box */
     uint64_t hot_prim_tests;  /* of tri_tests + sphere_tests + plane_tests, the hot group's */
     uint64_t hot_tri_divided; /* ... of its triangle tests, those that went on to the three divisions (the others were settled

@@ -79,7 +79,7 @@ class RenderStats(C.Structure):
                 ("trace_ms", C.c_double), ("refill_ticks", C.c_uint64),
                 ("surface_hits", C.c_uint64 * 8), ("direct_rays", C.c_uint64), ("hit_ms", C.c_double), ("miss_ms", C.c_double),
                 ("local_pool", C.c_uint32), ("exact_walk", C.c_uint32), ("hot_group", C.c_uint32),
-                ("stats_pad", C.c_uint32), ("pre_rays", C.c_uint64), ("hot_lane", C.c_uint64),
+                ("stats_pad", C.c_uint32), ("pre_rays", C.c_uint64), ("pre_root_records", C.c_uint64), ("hot_lane", C.c_uint64),
                 ("hot_prim_tests", C.c_uint64), ("hot_tri_divided", C.c_uint64)]
 
     def as_dict(self):

@@ -576,7 +576,7 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_params, tile_rank), RAYRS_FIELD(rayrs_render_params, tile_ranks);
     RAYRS_FIELD(rayrs_render_params, out_format), RAYRS_FIELD(rayrs_render_params, count_work);
     RAYRS_FIELD(rayrs_render_params, fast_traversal);
-    RAYRS_STRUCT(rayrs_render_stats, 32);
+    RAYRS_STRUCT(rayrs_render_stats, 33);
     RAYRS_FIELD(rayrs_render_stats, rays), RAYRS_FIELD(rayrs_render_stats, paths);
     RAYRS_FIELD(rayrs_render_stats, nan_pixels), RAYRS_FIELD(rayrs_render_stats, neg_pixels);
     RAYRS_FIELD(rayrs_render_stats, interior_visits), RAYRS_FIELD(rayrs_render_stats, tri_tests);
@@ -591,7 +591,8 @@ uint32_t rayrs_abi_layout(uint32_t* out, uint32_t cap) {
     RAYRS_FIELD(rayrs_render_stats, hit_ms), RAYRS_FIELD(rayrs_render_stats, miss_ms);
     RAYRS_FIELD(rayrs_render_stats, local_pool), RAYRS_FIELD(rayrs_render_stats, exact_walk);
     RAYRS_FIELD(rayrs_render_stats, hot_group), RAYRS_FIELD(rayrs_render_stats, stats_pad);
-    RAYRS_FIELD(rayrs_render_stats, pre_rays), RAYRS_FIELD(rayrs_render_stats, hot_lane);
+    RAYRS_FIELD(rayrs_render_stats, pre_rays), RAYRS_FIELD(rayrs_render_stats, pre_root_records);
+    RAYRS_FIELD(rayrs_render_stats, hot_lane);
     RAYRS_FIELD(rayrs_render_stats, hot_prim_tests), RAYRS_FIELD(rayrs_render_stats, hot_tri_divided);
     RAYRS_STRUCT(rayrs_tuning, 2);
     RAYRS_FIELD(rayrs_tuning, pool_slots), RAYRS_FIELD(rayrs_tuning, local_pool);
@@ -720,7 +721,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_nchunks = 1.0 / (double)rp.nchunks;
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
-    rp.refill_min = lab.refill_min ? lab.refill_min : 52u;
+    rp.refill_min = lab.refill_min ? lab.refill_min : 52u;  // (56 for pre-tested rays: set below, once the walk is known)
     // (a leaf phase once this many lanes stand on a leaf: 24 where a leaf is one primitive -- the fast walk's tree: 612 -> 604 ms
     // of traversal on the headline frame against 32 --, 32 where it is a group of up to four -- the default walk: 988 -> 962 ms
     // against 24; it is set below, once the walk is known)
@@ -756,6 +757,9 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     scene->last_exact = exact;
     rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
     const SceneDev sc = make_scene_dev(scene, exact);
+    // (pre-tested rays -- a scene with a hot group, wavefront.hip finish_rays -- are the ones that need a walk: fewer of them
+    // finish within a step or two, and refilling a little earlier pays: 664 -> 659 ms of traversal, profiles/r06_tuning_sweep.txt)
+    if (sc.hot != nullptr && !lab.refill_min) rp.refill_min = 56u;
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up
@@ -989,7 +993,7 @@ int rayrs_render_finish(rayrs_scene* scene, rayrs_render_stats* stats) {
         stats->refill_ticks = c.refill_ticks;
         for (int k = 0; k < 8; k++) stats->surface_hits[k] = c.surface_hits[k];
         stats->direct_rays = c.direct_rays;
-        stats->pre_rays = c.pre_rays, stats->hot_lane = c.hot_lane;
+        stats->pre_rays = c.pre_rays, stats->pre_root_records = c.pre_root_records, stats->hot_lane = c.hot_lane;
         stats->hot_prim_tests = c.hot_prim_tests, stats->hot_tri_divided = c.hot_tri_divided;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, scene->ev[0], scene->ev[1]));

@@ -155,6 +155,7 @@ struct Counters {
     unsigned long long direct_rays;  // primary rays that missed the root box: answered by the kernel that made them
     // the pre-test of new rays by the kernels that make them (wavefront.hip finish_rays; count_work only):
     unsigned long long pre_rays;          // queries answered there: bounced rays that miss the root box, rays that enter no slot of the walk tree's first record
+    unsigned long long pre_root_records;  // ... of them: rays that entered the root box and no slot of the first record (one record visit each)
     unsigned long long hot_lane;          // rays put to the hot group's gating box
     unsigned long long hot_prim_tests;    // of tri + sphere + plane tests: the hot group's
     unsigned long long hot_tri_divided;   // of its triangle tests: those that went on to the three divisions

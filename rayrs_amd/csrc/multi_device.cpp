@@ -267,7 +267,7 @@ extern "C" int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const 
                 stats->inner_wave += s.inner_wave, stats->leaf_wave += s.leaf_wave;
                 stats->interior_ticks += s.interior_ticks, stats->leaf_ticks += s.leaf_ticks;
                 stats->refill_ticks += s.refill_ticks;
-                stats->pre_rays += s.pre_rays, stats->hot_lane += s.hot_lane;
+                stats->pre_rays += s.pre_rays, stats->pre_root_records += s.pre_root_records, stats->hot_lane += s.hot_lane;
                 stats->hot_prim_tests += s.hot_prim_tests, stats->hot_tri_divided += s.hot_tri_divided;
                 for (int k = 0; k < 8; k++) stats->surface_hits[k] += s.surface_hits[k];
                 if (s.total_ms > stats->total_ms) stats->total_ms = s.total_ms;

@@ -467,6 +467,7 @@ RR_DEV void store_sample_count(const SceneDev& sc, const RenderDev& rp, const Wf
         const unsigned long long e = sn.hot.entered;
         atomicAdd(&c->pre_rays, pre);
         atomicAdd(&c->interior_visits, (unsigned long long)sn.pre_done);  // the first record of the walk tree, for the rays that end there
+        atomicAdd(&c->pre_root_records, (unsigned long long)sn.pre_done);
         atomicAdd(&c->hot_lane, (unsigned long long)sn.hot.owed);
         atomicAdd(&c->hot_prim_tests, e * h->count);
         atomicAdd(&c->hot_tri_divided, (unsigned long long)sn.hot.divided);

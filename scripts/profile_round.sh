@@ -17,7 +17,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 python -c 'import __graft_entry__ as g; g.build()'
-python bench.py --no-build --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err  # (for the hash and the workload key)
+python bench.py --no-build --no-cpu-baseline --no-configs --no-fast --no-secondary --no-roofline "$@" > $OUT/bench.json 2> $OUT/bench.err  # (for the hash and the workload key)
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --no-build --steps 1 --warmup 0 --no-cpu-baseline --no-roofline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
