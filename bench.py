@@ -670,7 +670,7 @@ def main():
             abytes = algorithmic_bytes(cst, info)
             prims = cst["tri_tests"] + cst["sphere_tests"] + cst["plane_tests"]
             pmc = find_pmc_profile(workload_key(cx, W, H, chunk))
-            traffic = fabric_gbs = valu_busy = valu_per_ray = pmc_src = None
+            traffic = fabric_gbs = valu_busy = valu_per_ray = valu_per_trav_ray = pmc_src = None
             step_fabric = None
             if pmc is not None:
                 pmc_src, pj = pmc
@@ -680,6 +680,8 @@ def main():
                     fabric_gbs = round(k["fabric_bytes"] / (dom_ms * 1e-3) / 1e9, 1)
                     valu_busy = k.get("valu_busy")
                     valu_per_ray = round(k["valu_wave_instructions"] / max(cst["rays"], 1), 2)
+                    if dom == "wf_trav_kernel":  # (per ray that goes through the kernel: with the pre-test most do not)
+                        valu_per_trav_ray = round(k["valu_wave_instructions"] / max(traversal_rays(cst), 1), 2)
                     step_fabric = sum(kk["fabric_bytes"] for kk in pj["kernels"].values())  # every kernel of ONE frame
             # the whole step: every kernel's useful operations, and (from the PMC passes) all fabric traffic, over the
             # step's wall time -- what the one-kernel-after-the-other schedule makes of the chip as a whole
@@ -743,7 +745,8 @@ def main():
                 # share of SIMD cycles with a vector instruction issued (SQ_INSTS_VALU x 4 cycles)
                 "fabric_GBps": fabric_gbs,
                 "fabric_frac_of_hbm_peak": None if fabric_gbs is None else round(fabric_gbs / HBM_PEAK_GBS, 4),
-                "fp64_valu_busy": valu_busy, "valu_wave_instructions_per_ray": valu_per_ray, "pmc_source": pmc_src,
+                "fp64_valu_busy": valu_busy, "valu_wave_instructions_per_ray": valu_per_ray,
+                "valu_wave_instructions_per_traversal_ray": valu_per_trav_ray, "pmc_source": pmc_src,
             }
         return {"cam": cam, "W": W, "H": H, "chunk": chunk, "value": total_rays / max_elapsed / 1e6, "flights": F,
                 "warm_frames": n_warm, "unpipelined_ms": None if unpipelined_s is None else unpipelined_s * 1e3,

@@ -155,7 +155,7 @@ typedef struct {
     /* The default walk's HOT GROUP (hot_count = 0: the scene has none): one group of the gate tree -- the one whose
      * gating box is the largest, if it covers at least a quarter of the root Node's box: on the reference's obj scenes the
      * floor's bottom Node, which nine rays in ten enter -- is left out of the records the default walk reads
-     * (rayrs_scene_export_hot_tree: hot_n_wide records) and tested ONCE PER RAY beside the walk, by the kernel that
+     * (rayrs_scene_export_hot_tree: hot_n_wide records) and tested ONCE PER RAY outside that tree, by the kernel that
      * makes the ray, for a whole batch of rays together: its gating box hot_box exactly as
      * AxisAlignedBoundingBox::intersect tests it, then its hot_count primitives hot_first ... in depth-first order
      * exactly as the reference tests them -- on wave-uniform f64 values.  The groups of that tree and

@@ -588,10 +588,6 @@ RR_DEV bool hot_triangle_intersect(V3 p1, V3 e1, V3 e2, V3 o, V3 d, bool live, d
     return true;
 }
 
-// What BvhTree::intersect does with the hot group (bvh.rs:396-410): the gating box, and if the ray enters it, the
-// group's primitives in depth-first order.  Every lane of the wave that owes the test runs it here, once per ray, at
-// whatever point of its walk: the closest hit is the smallest accepted t, the first primitive in depth-first order on
-// exact ties (bvh.rs:62), in any visiting order.  `owe` lanes only; the others idle.
 // AxisAlignedBoundingBox::intersect (geometry.rs:458-513) on a wave-uniform box, as slab() computes it: the near / far
 // bound is chosen by the sign of 1 / d -- here after the two products instead of before (the same two products either way).
 RR_DEV bool uniform_box_entered(double x0, double x1, double y0, double y1, double z0, double z1, V3 o, V3 inv, double tmin,
@@ -607,6 +603,11 @@ RR_DEV bool uniform_box_entered(double x0, double x1, double y0, double y1, doub
     return !(hi <= lo);
 }
 
+// What BvhTree::intersect does with the hot group (bvh.rs:396-410): the gating box, and if the ray enters it, the
+// group's primitives in depth-first order.  Every lane of the wave that owes the test (`owe`; the others idle) runs it
+// here, once per ray -- in the kernel that made the ray (wavefront.hip finish_rays) or at the start of a query
+// (bvh_intersect below): the closest hit is the smallest accepted t, the first primitive in depth-first order on exact
+// ties (bvh.rs:62), in any visiting order.
 template <bool COUNT>
 RR_DEV void hot_group_step(const SceneDev& sc, V3 o, V3 d, bool owe, Trav& tv, WorkCount& wc, HotTally& ht) {
     const HotPtr h = hot_ptr(sc);

@@ -91,8 +91,9 @@ struct SurfaceDev {
 // The HOT GROUP of the default walk (scene_host.cpp pick_hot_group, device_path.h hot_group_step): one leaf group of the
 // reference's tree whose gating box covers most of the root Node's box -- on the benchmark scenes the 50 x 50 floor and
 // the three mesh triangles that share its bottom Node, which 89 % of all rays enter.  It is taken out of the tree the
-// default walk reads and tested once per ray, by all the lanes of a wave that owe the test together: the same gating-box
-// test and the same primitive tests on the same f64 values as BvhTree::intersect makes (bvh.rs:391-415), but on
+// default walk reads and tested once per ray by the kernel that MAKES the ray, for a whole batch of rays together
+// (wavefront.hip finish_rays): the same gating-box test and the same primitive tests on the same f64 values as
+// BvhTree::intersect makes (bvh.rs:391-415), but on
 // wave-uniform data -- read with scalar loads, nothing converted, e1 = p2 - p1 and e2 = p3 - p1 formed on the host as
 // Triangle::new forms them (geometry.rs:342-343).
 struct HotPrim {       // 80 B
