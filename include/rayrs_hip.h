@@ -242,9 +242,13 @@ typedef struct {
      * 0 (default): the walk over the reference's leaf groups behind their exact gating boxes
      *   (rayrs_scene_export_gate_tree) with nothing culled: it tests exactly the primitives the reference tests, so
      *   its closest hit (smallest accepted t, first primitive in depth-first order on ties, bvh.rs:62) is the
-     *   reference's for EVERY ray BY CONSTRUCTION.  The local-pool route walks this way too.
+     *   reference's for EVERY ray BY CONSTRUCTION.  The local-pool route walks this way too.  Which kernel makes a
+     *   test, and when, is the library's business: on a scene with a hot group (rayrs_scene_info_t.hot_count) the root
+     *   box, that group and the first record of the tree without it are tested by the kernel that makes the ray, the
+     *   rest by the traversal kernel -- the same tests on the same values, the same set of primitives.
      * 1: the fast walk, which makes two bets on the reference's arithmetic, each measured, neither a construction
-     *   (it was the default until round 5; the headline frame renders 23 % faster with it, profiles/r05_walks.txt):
+     *   (it was the default until round 5; the headline frame renders 10 % faster with it -- 23 % before round 6 moved
+     *   the default walk's cheap tests out of the traversal kernel, profiles/r05_walks.txt, r06_final_bench.json):
      *   - closest-hit culling: a box entered beyond best_t * (1 + 2^-10) is skipped -- the reference's answer
      *     unless a primitive's COMPUTED t lies more than that in front of a box around it;
      *   - tight leaf boxes (rayrs_scene_export_wide): a primitive is tested only if the ray enters its own bounding
