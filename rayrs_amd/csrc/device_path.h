@@ -649,16 +649,16 @@ RR_DEV void hot_group_step(const SceneDev& sc, V3 o, V3 d, bool owe, Trav& tv, W
 }
 
 // The first record of the tree without the hot group (HotGroupDev::root_box, the f64 values its record holds): does the ray
-// enter any of its four slots?  The same test, on the same values, that trav_interior_step makes of that record.
-RR_DEV bool hot_root_record_entered(const SceneDev& sc, V3 o, V3 inv) {
+// enter which of its four slots?  The same test, on the same values, that trav_interior_step makes of that record.
+RR_DEV uint32_t hot_root_record_entered(const SceneDev& sc, V3 o, V3 inv) {  // bit c: the ray enters slot c
     const HotPtr h = hot_ptr(sc);
     const double tmin = sc.t0, tmax = sc.t1;
-    bool any = false;
+    uint32_t mask = 0u;
 #pragma unroll
     for (int c = 0; c < 4; c++)
-        any |= uniform_box_entered(h->root_box[c][0], h->root_box[c][1], h->root_box[c][2], h->root_box[c][3], h->root_box[c][4],
-                                   h->root_box[c][5], o, inv, tmin, tmax);
-    return any;
+        mask |= uniform_box_entered(h->root_box[c][0], h->root_box[c][1], h->root_box[c][2], h->root_box[c][3], h->root_box[c][4],
+                                    h->root_box[c][5], o, inv, tmin, tmax) ? (1u << c) : 0u;
+    return mask;
 }
 
 template <bool COMPACT, bool COUNT, bool EXACT = false>

@@ -87,6 +87,32 @@ RR_DEV uint32_t compact_window_ready(const WfDev& wf, uint32_t win, uint16_t* li
     return count;
 }
 
+// A PRE-TESTED ray's READY state (finish_rays) carries, instead of the octant, WHICH slots of the walk tree's first record it
+// enters (bits 3..6; at least one): the traversal kernel starts the walk below those slots -- the record has been tested, by the
+// kernel that made the ray, with the arithmetic and the values trav_interior_step would test it with -- and builds its
+// list slot by slot of the FIRST slot entered: the rays a wave takes together start in the same quarter of the scene.
+// A list entry carries the mask above the slot's offset in its window (9 bits).
+RR_DEV uint8_t ready_state_pre(uint32_t mask) { return (uint8_t)(WF_READY | (mask << 3)); }
+RR_DEV uint32_t compact_window_ready_pre(const WfDev& wf, uint32_t win, uint16_t* list) {
+    const StateWords sw = load_state_words(wf, win);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    uint32_t count = 0;
+#pragma nounroll
+    for (uint32_t key = 0; key < 4u; key++) {
+#pragma unroll
+        for (int j = 0; j < (int)SPL; j++) {
+            const uint32_t s = (sw.w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+            const uint32_t m = (s >> 3) & 15u;
+            const bool hit = (s & 7u) == (uint32_t)WF_READY && (m & (0u - m)) == (1u << key);
+            const unsigned long long mask = __ballot(hit);
+            if (hit) list[count + (uint32_t)__popcll(mask & lanemask_lt)] = (uint16_t)((lane * SPL + (uint32_t)j) | (m << 9));
+            count += (uint32_t)__popcll(mask);
+        }
+    }
+    return count;
+}
+
 // The hit and miss kernels' walk over their slots: wave g of n_waves takes windows g,
 // g + n_waves, ... and within a window the slots of state `want`, 64 at a time.  The state
 // bytes of the following window are loaded while the current one is being worked on, and the
@@ -271,6 +297,7 @@ struct SampleCount {
     uint32_t pre_miss;            // bounced rays that missed the root box: a Miss (bvh.rs:394), left to the miss kernel
     uint32_t pre_done;            // rays that entered the root box and none of the four slots of the walk tree's first record:
                                   // their query ends with the hot group's answer, here
+    uint32_t pre_root;            // rays put to the first record (all that entered the root box): one record visit each
 };
 
 // ---- the pre-test of a new ray by the kernel that made it (scenes with a hot group: layout.h HotGroupDev) ----
@@ -282,8 +309,8 @@ struct SampleCount {
 //   * the closest hit so far -- the hot group's -- is written to the slot (RaySlot::t / prim: t1 and "none" without one);
 //   * a ray that enters none of the first record's four slots has nothing left to visit: its query is answered, state HIT
 //     or MISS, and it never travels through the traversal kernel (six rays in ten on the headline frame);
-//   * the others become READY: the traversal kernel takes the closest hit so far from the slot and starts at the first
-//     record (which it tests again: a record is a unit of its walk).
+//   * the others become READY, with the slots they enter in their state byte (ready_state_pre): the traversal kernel takes
+//     the closest hit so far from the slot and starts the walk below those slots.
 // Every test is the one BvhTree::intersect makes, on the same values; the closest hit is the smallest accepted t, the
 // first primitive in depth-first order on exact ties (bvh.rs:62), in whatever order and by whichever kernel the
 // primitives are tested.  `got`: the lane holds a ray (o, d) for `slot`; `enters`: it is known to enter the root box.
@@ -294,7 +321,9 @@ RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o
     WorkCount wc{0, 0, 0, 0, 0};
     const bool live = got && enters;
     hot_group_step<false>(sc, o, d, live, tv, wc, sn.hot);
-    const bool walk = live && hot_root_record_entered(sc, o, inv);
+    const uint32_t slots = live ? hot_root_record_entered(sc, o, inv) : 0u;
+    const bool walk = slots != 0u;
+    sn.pre_root += (uint32_t)__popcll(__ballot(live));
     sn.pre_done += (uint32_t)__popcll(__ballot(live && !walk));
     sn.pre_miss += (uint32_t)__popcll(__ballot(got && !enters && !primary));
     if (got) {
@@ -307,7 +336,7 @@ RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o
             rs->t = tv.best_t;
             rs->prim = tv.best_prim;
         }
-        wf.state[slot] = walk ? ready_state(d) : (hit ? WF_HIT : WF_MISS);
+        wf.state[slot] = walk ? ready_state_pre(slots) : (hit ? WF_HIT : WF_MISS);
     }
 }
 
@@ -466,8 +495,8 @@ RR_DEV void store_sample_count(const SceneDev& sc, const RenderDev& rp, const Wf
         const HotPtr h = hot_ptr(sc);
         const unsigned long long e = sn.hot.entered;
         atomicAdd(&c->pre_rays, pre);
-        atomicAdd(&c->interior_visits, (unsigned long long)sn.pre_done);  // the first record of the walk tree, for the rays that end there
-        atomicAdd(&c->pre_root_records, (unsigned long long)sn.pre_done);
+        atomicAdd(&c->interior_visits, (unsigned long long)sn.pre_root);  // the first record of the walk tree: tested here for every ray, never again
+        atomicAdd(&c->pre_root_records, (unsigned long long)sn.pre_root);
         atomicAdd(&c->hot_lane, (unsigned long long)sn.hot.owed);
         atomicAdd(&c->hot_prim_tests, e * h->count);
         atomicAdd(&c->hot_tri_divided, (unsigned long long)sn.hot.divided);
@@ -488,7 +517,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_windows = wf.np / WINDOW;
-    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     for (uint32_t win = wave; win < n_windows; win += n_waves) {
         const uint32_t count = compact_window(wf, win, WF_IDLE, list);
@@ -539,6 +568,12 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     }
     const HotNodes hot{hot_lds, sc.hot_records};
     const unsigned long long lanemask_lt = (1ull << lane) - 1ull;
+    // PRE: the references of the first record's four slots (wave-uniform: scalar registers)
+    uint32_t root_ref0 = 0, root_ref1 = 0, root_ref2 = 0, root_ref3 = 0;
+    if (PRE) {
+        const HotPtr h = hot_ptr(sc);
+        root_ref0 = h->root_ref[0], root_ref1 = h->root_ref[1], root_ref2 = h->root_ref[2], root_ref3 = h->root_ref[3];
+    }
 
     const uint32_t n_windows = wf.np / WINDOW;
     // Windows of the pool are handed out in two ways.  The first rp.static_windows windows are
@@ -600,14 +635,15 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                         break;
                     }
                     list_base = w * WINDOW;
-                    list_len = compact_window_ready(wf, w, list);
+                    list_len = PRE ? compact_window_ready_pre(wf, w, list) : compact_window_ready(wf, w, list);
                     list_pos = 0;
                     continue;
                 }
                 const uint32_t avail = list_len - list_pos;
                 const uint32_t rank = (uint32_t)__popcll(need_mask & lanemask_lt);
                 if (need && rank < avail) {
-                    slot = list_base + (uint32_t)list[list_pos + rank];
+                    const uint32_t entry = (uint32_t)list[list_pos + rank];
+                    slot = list_base + (PRE ? (entry & 511u) : entry);
                     const RaySlot* rs = ray_slot(wf, slot);
                     o = mk(rs->o[0], rs->o[1], rs->o[2]);
                     d = mk(rs->d[0], rs->d[1], rs->d[2]);
@@ -616,8 +652,21 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                         tv.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
                         tv.best_t = rs->t;
                         tv.best_prim = rs->prim;
-                        tv.sp = 0;
-                        tv.cur = sc.root_ref;
+                        // the slots of the first record this ray enters (finish_rays tested it): the first becomes the lane's
+                        // reference, the others wait on its stack so that they come off it in slot order, as
+                        // trav_interior_step would have left them
+                        const uint32_t m = entry >> 9;
+                        const int n = (int)__popc(m);
+                        const uint32_t low = m & (0u - m);
+                        // (the references are scalars; taken through an empty asm here so that their copies into vector
+                        // registers for the stores below are made here and not kept -- spilled -- across the whole walk)
+                        uint32_t r1 = root_ref1, r2 = root_ref2, r3 = root_ref3;
+                        asm volatile("" : "+s"(r1), "+s"(r2), "+s"(r3));
+                        tv.cur = (low & 1u) ? root_ref0 : (low & 2u) ? r1 : (low & 4u) ? r2 : r3;
+                        tv.sp = n - 1;
+                        if ((m & 2u) && low != 2u) stack.put(n - 1 - (int)__popc(m & 1u), r1);  // (put: in LDS, or in the lane's HBM strip
+                        if ((m & 4u) && low != 4u) stack.put(n - 1 - (int)__popc(m & 3u), r2);  //  when fewer than three entries are kept in
+                        if ((m & 8u) && low != 8u) stack.put(n - 1 - (int)__popc(m & 7u), r3);  //  LDS; a branch-free variant measured the same)
                         active = true;
                     } else {
                         trav_init(sc, o, d, tv);
@@ -730,7 +779,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     uint32_t* list = lists[threadIdx.x >> 6];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
@@ -877,7 +926,7 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long n_escaped = 0;
-    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0};
+    SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0, 0};
     ItemRange range = load_item_range(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_MISS, list);
