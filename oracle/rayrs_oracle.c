@@ -1776,12 +1776,23 @@ static v3 radiance(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng
     return radiance_traced(s, r, max_bounces, rng, traversal, pc, NULL);
 }
 
+/* Diagnostics (scripts/sim/: the traversal kernel's scheduling is simulated on the rays a real frame makes): when set,
+ * radiance() appends every ray it puts to the scene -- o, d and the loop iteration -- to the buffer (single-threaded use). */
+static double* g_ray_dump = NULL;
+static uint64_t g_ray_dump_cap = 0, g_ray_dump_n = 0;
+void orc_set_ray_dump(double* rays7, uint64_t cap) { g_ray_dump = rays7, g_ray_dump_cap = cap, g_ray_dump_n = 0; }
+uint64_t orc_ray_dump_count(void) { return g_ray_dump_n; }
+
 static v3 radiance_traced(const orc_scene* s, ray_t r, uint32_t max_bounces, rng_t* rng, int traversal, path_counters* pc,
                           path_trace* tr) {
     v3 throughput = V(1.0, 1.0, 1.0);
     v3 light = V(0.0, 0.0, 0.0);
     for (uint32_t b = 0; b < max_bounces; b++) {
         if (pc) pc->rays++;
+        if (g_ray_dump && g_ray_dump_n < g_ray_dump_cap) {
+            double* q = g_ray_dump + 7 * g_ray_dump_n++;
+            q[0] = r.o.x, q[1] = r.o.y, q[2] = r.o.z, q[3] = r.d.x, q[4] = r.d.y, q[5] = r.d.z, q[6] = (double)b;
+        }
         isect_t h = scene_intersect(s, r, traversal, pc ? &pc->trav : NULL);
         if (h.hit) {
             const object_t* obj = &s->objs[h.obj];

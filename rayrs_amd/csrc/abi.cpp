@@ -26,6 +26,11 @@ namespace {
 thread_local std::string g_last_error;
 constexpr uint32_t TRAV_STACK_LDS = 12;
 constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
+// The trees the default walk reads: a lane's leaf groups wait in a queue of LEAFQ entries behind its stack
+// (device_path.h trav_interior_step_defer), so its stack holds interior records only -- 8 entries in LDS serve what 12
+// served with the leaves among them -- and the records kept in LDS give up the other 4 KiB of the queue's 8.
+constexpr uint32_t TRAV_STACK_LDS_DEFER = 8;
+constexpr uint32_t TRAV_HOT_BYTES_DEFER = 10u * 1024u;
 }  // namespace
 
 namespace rayrs {
@@ -240,14 +245,15 @@ static int scene_configure_traversal(rayrs_scene* s) {
         const WalkTree& t = s->tree(x);
         rayrs_scene::Walk& w = s->trav[x];
         const uint32_t depth = t.depth ? t.depth : 1;
-        uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : TRAV_STACK_LDS;
+        w.leafq = x == 0 ? 0u : TRAV_LEAFQ;  // ([0] is the fast walk's tree; [1] is walked either way, [2] by the default walk only)
+        uint32_t want = s->lab.stack_lds ? s->lab.stack_lds : (w.leafq ? TRAV_STACK_LDS_DEFER : TRAV_STACK_LDS);
         w.stack_lds = want < depth ? want : depth;
         const uint32_t rec_bytes = f.compact ? (uint32_t)sizeof(Node4F32) + 16u : (uint32_t)sizeof(Node4F64) + 16u;
-        uint32_t hot = TRAV_HOT_BYTES / rec_bytes;
+        uint32_t hot = (w.leafq ? TRAV_HOT_BYTES_DEFER : TRAV_HOT_BYTES) / rec_bytes;
         if (s->lab.hot_records == 0xffffffffu) hot = 0;
         else if (s->lab.hot_records) hot = s->lab.hot_records < WIDE_FRONT ? s->lab.hot_records : WIDE_FRONT;
         w.hot_records = hot < t.n() ? hot : t.n();
-        HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.hot_records, &w.blocks_per_cu));
+        HIP_TRY(wf_trav_occupancy(f.compact, w.stack_lds, w.leafq, w.hot_records, &w.blocks_per_cu));
         if (w.blocks_per_cu < 1) w.blocks_per_cu = 1;
     }
     return RAYRS_OK;
@@ -518,7 +524,7 @@ int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
     if (lab->hot_group != 0u && lab->hot_group != 0xffffffffu) return RAYRS_INVALID_ARG;
-    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->leaf_wait > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
@@ -630,6 +636,7 @@ static SceneDev make_scene_dev(const rayrs_scene* s, bool exact) {
     sc.stack_depth = t.depth ? t.depth : 1;
     sc.stack_lds = w.stack_lds;
     sc.hot_records = w.hot_records;
+    sc.leafq = w.leafq;
     sc.n_surfaces = (uint32_t)s->surfaces.size();
     for (int i = 0; i < 6; i++) sc.root_box[i] = s->flat.root_box[i];
     sc.t0 = s->flat.t0;
@@ -721,7 +728,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     rp.inv_nchunks = 1.0 / (double)rp.nchunks;
     rp.inv_tiles_x = 1.0 / (double)rp.tiles_x;
     if (rp.total_items >= (1ull << 32)) return RAYRS_UNSUPPORTED;
-    rp.refill_min = lab.refill_min ? lab.refill_min : 52u;  // (56 for pre-tested rays: set below, once the walk is known)
+    rp.refill_min = lab.refill_min ? lab.refill_min : 52u;
     // (a leaf phase once this many lanes stand on a leaf: 24 where a leaf is one primitive -- the fast walk's tree: 612 -> 604 ms
     // of traversal on the headline frame against 32 --, 32 where it is a group of up to four -- the default walk: 988 -> 962 ms
     // against 24; it is set below, once the walk is known)
@@ -755,11 +762,14 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
 
     const bool exact = params->fast_traversal == 0u || camera_is_far(scene, camera);
     scene->last_exact = exact;
-    rp.leaf_min = lab.leaf_min ? lab.leaf_min : ((exact || lab.gate_tree) ? 32u : 24u);
+    rp.leaf_min = lab.leaf_min ? lab.leaf_min : (exact ? 48u : lab.gate_tree ? 32u : 24u);
+    // (the default walk: its lanes walk on while their leaf groups wait, so a leaf phase may wait for more of them -- or for
+    // leaf_wait lanes that can do nothing else; scripts/sim/walk_sched_sim.py, swept on the GPU: profiles/r06_leaf_queue.txt)
+    rp.leaf_wait = lab.leaf_wait ? lab.leaf_wait : 16u;
     const SceneDev sc = make_scene_dev(scene, exact);
-    // (pre-tested rays -- a scene with a hot group, wavefront.hip finish_rays -- are the ones that need a walk: fewer of them
-    // finish within a step or two, and refilling a little earlier pays: 664 -> 659 ms of traversal, profiles/r06_tuning_sweep.txt)
-    if (sc.hot != nullptr && !lab.refill_min) rp.refill_min = 56u;
+    // (pre-tested rays -- a scene with a hot group, wavefront.hip finish_rays -- wanted 56 while a lane stood idle on its
+    // leaf: 664 -> 659 ms of traversal, profiles/r06_tuning_sweep.txt; with the leaf groups set aside 52 is best again:
+    // 626 -> 619 ms, profiles/r06_leaf_queue.txt)
     const CameraDev cam = make_camera_dev(camera);
 
     // ---- path pool.  A traversal launch works through the whole pool, and its ramp-up

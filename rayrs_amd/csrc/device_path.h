@@ -525,6 +525,163 @@ RR_DEV void trav_leaf_step(const SceneDev& sc, V3 o, V3 d, const LaneStack& stac
 
 RR_DEV bool trav_at_interior(const Trav& tv) { return (tv.cur >> 30) == REF_INTERIOR; }
 
+// ---- the default walk with a lane's leaf groups SET ASIDE (wavefront.hip wf_trav_kernel<.., EXACT>) ----
+// The default walk culls nothing: which groups a ray's primitives are tested of is decided by the gating boxes alone, and
+// the closest hit is the smallest accepted t, the first primitive in depth-first order on exact ties (bvh.rs:62), in ANY
+// visiting order.  So a lane need not stop at a leaf slot: it puts the group's reference on a queue of its own (LEAFQ entries
+// in LDS behind its stack) and walks on; a leaf phase of the wave serves one queued group per lane.  A lane then takes part
+// in an interior phase whenever it has a record to visit and in a leaf phase whenever it has a group waiting, instead of
+// standing idle through the phases of the other kind (lanes at work per step 0.59 -> 0.8, scripts/sim/walk_sched_sim.py).
+// Trav::cur is an interior record or TRAV_DONE, the stack holds interior records only, and Trav::sp carries two counts:
+// stack height in its low half, queued groups in its high half.  A lane whose queue could not take four more groups sits
+// out interior phases until a leaf phase has served it (the queue never overflows).
+constexpr uint32_t LEAFQ = TRAV_LEAFQ;                // queue entries per lane (layout.h)
+constexpr uint32_t LEAFQ_ONE = 1u << 16;              // one queued group, in Trav::sp
+constexpr uint32_t LEAFQ_ROOM = (LEAFQ - 3u) << 16;   // sp below this: four more groups fit
+constexpr uint32_t REF_LEAF_BASE = REF_RANGE << 30;   // an entered slot's reference at or above this is a leaf group
+RR_DEV bool defer_has_leaf(const Trav& tv) { return (uint32_t)tv.sp >= LEAFQ_ONE; }
+RR_DEV bool defer_has_room(const Trav& tv) { return (uint32_t)tv.sp < LEAFQ_ROOM; }
+RR_DEV bool defer_finished(const Trav& tv) { return tv.cur == TRAV_DONE && (uint32_t)tv.sp < LEAFQ_ONE; }
+
+// The lane's queue lives behind its stack's spare entry: entry cap + 1 + k of the lane's LDS column.
+RR_DEV uint32_t* defer_queue(const LaneStack& stack) { return stack.lds + (stack.cap + 1u) * 64u; }
+
+// A reference the lane is handed from outside a record (the root of a tree, the first record's slots at a refill).
+RR_DEV void defer_take_ref(const LaneStack& stack, Trav& tv, uint32_t ref) {
+    if (ref >= REF_LEAF_BASE) {
+        defer_queue(stack)[((uint32_t)tv.sp >> 16) * 64u] = ref;
+        tv.sp += (int)LEAFQ_ONE;
+    } else if (tv.cur == TRAV_DONE) {
+        tv.cur = ref;
+    } else {
+        stack.put((int)((uint32_t)tv.sp & 0xffffu), ref);
+        tv.sp += 1;
+    }
+}
+
+template <bool COMPACT, bool COUNT>
+RR_DEV void trav_interior_step_defer(const SceneDev& sc, V3 o, const LaneStack& stack, const HotNodes& hot, Trav& tv,
+                                     WorkCount& wc) {
+    const double tmin = sc.t0, tmax = sc.t1;
+    const V3 inv = tv.inv;
+    const bool nx = inv.x < 0.0, ny = inv.y < 0.0, nz = inv.z < 0.0;
+    const uint32_t rec = tv.cur & 0x3fffffffu;
+    if (COUNT) wc.interior++;
+    double e0, e1, e2, e3;
+    bool h0, h1, h2, h3;
+    uint32_t r0, r1, r2, r3;
+    if (COMPACT) {
+        uint4 a, b, c, d, f, g, r;
+        if (rec < hot.count) {
+            const uint4* src = hot.lds + rec * HotNodes::stride<true>();
+            a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 8;
+            a = src[0], b = src[1], c = src[2], d = src[3], f = src[4], g = src[5], r = src[6];
+        }
+        r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+        h0 = slab_f32(a.x, a.y, a.z, a.w, b.x, b.y, nx, ny, nz, o, inv, tmin, tmax, e0);
+        h1 = slab_f32(b.z, b.w, c.x, c.y, c.z, c.w, nx, ny, nz, o, inv, tmin, tmax, e1);
+        h2 = slab_f32(d.x, d.y, d.z, d.w, f.x, f.y, nx, ny, nz, o, inv, tmin, tmax, e2);
+        h3 = slab_f32(f.z, f.w, g.x, g.y, g.z, g.w, nx, ny, nz, o, inv, tmin, tmax, e3);
+    } else {
+        const bool in_lds = rec < hot.count;
+        const uint4* lsrc = hot.lds + (in_lds ? rec : 0u) * HotNodes::stride<false>();
+        const uint4* gsrc = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)rec * 16;
+        uint4 x, y, z, r;
+        if (in_lds) x = lsrc[0], y = lsrc[1], z = lsrc[2], r = lsrc[12];
+        else x = gsrc[0], y = gsrc[1], z = gsrc[2], r = gsrc[12];
+        r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+        h0 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e0);
+        if (in_lds) x = lsrc[3], y = lsrc[4], z = lsrc[5];
+        else x = gsrc[3], y = gsrc[4], z = gsrc[5];
+        h1 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e1);
+        if (in_lds) x = lsrc[6], y = lsrc[7], z = lsrc[8];
+        else x = gsrc[6], y = gsrc[7], z = gsrc[8];
+        h2 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e2);
+        if (in_lds) x = lsrc[9], y = lsrc[10], z = lsrc[11];
+        else x = gsrc[9], y = gsrc[10], z = gsrc[11];
+        h3 = slab_f64(x, y, z, nx, ny, nz, o, inv, tmin, tmax, e3);
+    }
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));  // (the references' load stays with the boxes': see trav_interior_step)
+    // Entered slots, as wave masks (unused slots carry the inverted box: never entered), split by what the slot refers to.
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(h2), m3 = __builtin_amdgcn_ballot_w64(h3);
+    const unsigned long long q0 = __builtin_amdgcn_ballot_w64(r0 >= REF_LEAF_BASE), q1 = __builtin_amdgcn_ballot_w64(r1 >= REF_LEAF_BASE);
+    const unsigned long long q2 = __builtin_amdgcn_ballot_w64(r2 >= REF_LEAF_BASE), q3 = __builtin_amdgcn_ballot_w64(r3 >= REF_LEAF_BASE);
+#define RR_LANE_BIT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+    const bool i0 = RR_LANE_BIT(m0 & ~q0), i1 = RR_LANE_BIT(m1 & ~q1), i2 = RR_LANE_BIT(m2 & ~q2), i3 = RR_LANE_BIT(m3 & ~q3);
+    const bool l0 = RR_LANE_BIT(m0 & q0), l1 = RR_LANE_BIT(m1 & q1), l2 = RR_LANE_BIT(m2 & q2), l3 = RR_LANE_BIT(m3 & q3);
+#undef RR_LANE_BIT
+    // rank of an entered slot among the entered slots of its kind, in slot order
+    const int ki1 = (int)i0, ki2 = ki1 + (int)i1, ki3 = ki2 + (int)i2, n_int = ki3 + (int)i3;
+    const int kl1 = (int)l0, kl2 = kl1 + (int)l1, kl3 = kl2 + (int)l2, n_leaf = kl3 + (int)l3;
+    const int sp = (int)((uint32_t)tv.sp & 0xffffu);
+    const int lq = (int)((uint32_t)tv.sp >> 16);
+    // interior slots: the first becomes the lane's next record, rank k >= 1 goes to stack entry top - k (they come off
+    // in slot order); leaf slots: queue entries lq + rank; everything else to the lane's spare entry
+    const int top = sp + n_int - 1;  // the new stack height if n_int >= 1
+    const int spare = (int)stack.cap;
+    const int qbase = spare + 1 + lq;
+    const int d0 = i0 ? top : (l0 ? qbase : spare);
+    const int d1 = i1 ? top - ki1 : (l1 ? qbase + kl1 : spare);
+    const int d2 = i2 ? top - ki2 : (l2 ? qbase + kl2 : spare);
+    const int d3 = i3 ? top - ki3 : (l3 ? qbase + kl3 : spare);
+    if (__ballot(n_int > 0 && (uint32_t)top > stack.cap) == 0ull) {  // all of the wave's stack entries are in LDS: no branches
+        // (the rank-0 interior slot is written too, to entry `top`: the first free one above the new stack top)
+        stack.lds[d0 * 64] = r0;
+        stack.lds[d1 * 64] = r1;
+        stack.lds[d2 * 64] = r2;
+        stack.lds[d3 * 64] = r3;
+    } else {
+        if (l0) stack.lds[d0 * 64] = r0;  // (an interior slot 0 has rank 0: it becomes the lane's next record)
+        if (l1) stack.lds[d1 * 64] = r1;
+        else if (i1 && ki1 > 0) stack.put(top - ki1, r1);
+        if (l2) stack.lds[d2 * 64] = r2;
+        else if (i2 && ki2 > 0) stack.put(top - ki2, r2);
+        if (l3) stack.lds[d3 * 64] = r3;
+        else if (i3 && ki3 > 0) stack.put(top - ki3, r3);
+    }
+    if (n_int > 0) {
+        tv.cur = i0 ? r0 : i1 ? r1 : i2 ? r2 : r3;
+        tv.sp = (int)(((uint32_t)(lq + n_leaf) << 16) | (uint32_t)top);
+    } else if (sp > 0) {
+        tv.cur = stack.get(sp - 1);
+        tv.sp = (int)(((uint32_t)(lq + n_leaf) << 16) | (uint32_t)(sp - 1));
+    } else {
+        tv.cur = TRAV_DONE;
+        tv.sp = (int)((uint32_t)(lq + n_leaf) << 16);
+    }
+}
+
+// One queued leaf group of the lane: its 1..4 primitives in DFS order.
+template <bool COMPACT, bool COUNT>
+RR_DEV void trav_leaf_step_defer(const SceneDev& sc, V3 o, V3 d, const LaneStack& stack, Trav& tv, WorkCount& wc) {
+    const double tmin = sc.t0, tmax = sc.t1;
+    tv.sp -= (int)LEAFQ_ONE;
+    const uint32_t ref = defer_queue(stack)[((uint32_t)tv.sp >> 16) * 64u];
+    const uint32_t first = (ref & 0x3fffffffu) >> 2;
+    const uint32_t count = (ref & 3u) + 1u;
+    if (COUNT) wc.leaf_prims = count;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t p = first + k;
+        const PrimRec<COMPACT> r = load_prim<COMPACT>(sc.prims, p);
+        if (COUNT) {
+            const uint32_t kind = r.tag() & 3u;
+            if (kind == PRIM_TRIANGLE) wc.tri++;
+            else if (kind == PRIM_SPHERE) wc.sphere++;
+            else wc.plane++;
+        }
+        double t;
+        if (prim_intersect<COMPACT>(r, o, d, t) && t > tmin && t < tmax) {  // bvh.rs:406
+            if (t < tv.best_t || (t == tv.best_t && p < tv.best_prim)) {    // bvh.rs:62
+                tv.best_t = t;
+                tv.best_prim = p;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------- the hot group (layout.h HotGroupDev)
 
 // Read with scalar loads: the data is the same for every lane, and a load through the constant address space with a

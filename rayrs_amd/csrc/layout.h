@@ -62,6 +62,7 @@ struct Node4F64 {  // 256 B
 };
 // records renumbered to the front, largest box first (scene_host.cpp front_largest)
 constexpr uint32_t WIDE_FRONT = 256;
+constexpr uint32_t TRAV_LEAFQ = 8;  // leaf groups a lane of the default walk may have waiting (device_path.h LEAFQ, abi.cpp's LDS sizing)
 static_assert(sizeof(Node4F32) == 128, "Node4F32");
 static_assert(sizeof(Node4F64) == 256, "Node4F64");
 
@@ -127,7 +128,7 @@ struct SceneDev {
     uint32_t stack_lds;    // how many of them live in LDS; the rest overflow to HBM (LaneStack)
     uint32_t hot_records;  // leading wide records the traversal kernel copies to LDS (HotNodes)
     uint32_t n_surfaces;
-    uint32_t pad0;
+    uint32_t leafq;        // the default walk: leaf groups a lane may have waiting in LDS (device_path.h LEAFQ); 0 = the fast walk
     double root_box[6];
     double t0, t1;  // Scene::t_range, lib.rs:218
     double hdri_wm1, hdri_hm1;  // (hdri_w - 1) as f64 and (hdri_h - 1) as f64, lib.rs:262-263 (converted on the host: a kernel
@@ -176,6 +177,7 @@ struct RenderDev {
     uint64_t total_items;  // n_local_tiles * nchunks * 64
     double inv_nchunks, inv_tiles_x;  // reciprocals for udiv_by() in the kernels
     uint32_t refill_min, leaf_min;  // traversal scheduling thresholds (lanes)
+    uint32_t leaf_wait, pad_rd;     // ... the default walk: a leaf phase once this many lanes can do nothing but wait for one
     uint32_t static_windows;        // pool windows dealt to the traversal waves round robin (wavefront.hip)
     uint32_t count_work;            // also count closest hits per surface (hit kernel)
     double* partial;       // item sums, 3 doubles each, of the items partial_item0 .. (all of them, or one segment's)

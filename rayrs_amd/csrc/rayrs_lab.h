@@ -38,6 +38,8 @@ typedef struct {
     uint32_t hot_group;     /* 0xffffffff = the default walk reads the whole gate tree also where the scene has a hot group
                                (layout.h HotGroupDev), and the kernels that make rays pre-test nothing: the walk of round 5,
                                kept for the same-box A/B */
+    uint32_t leaf_wait;     /* traversal, default walk: run a leaf phase once this many lanes can do nothing but wait for one
+                               (leaf groups queued, no record to visit) (16) */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */

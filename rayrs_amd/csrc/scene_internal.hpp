@@ -39,6 +39,7 @@ struct rayrs_scene {
         int blocks_per_cu = 0;       // traversal kernel, from the occupancy query
         uint32_t stack_lds = 1;      // traversal stack entries kept in LDS
         uint32_t hot_records = 0;    // leading records kept in LDS
+        uint32_t leafq = 0;          // leaf groups a lane of the default walk may have waiting in LDS (0: the fast walk's tree)
     };
     // [2] FlatScene::gate_hot (the default walk on a scene with a hot group: layout.h HotGroupDev).
     Walk trav[3];

@@ -90,7 +90,7 @@ hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam,
                          uint32_t blocks, hipStream_t stream);
 hipError_t wf_launch_trav(bool compact, bool count, const SceneDev& sc, const RenderDev& rp, const WfDev& wf,
                           uint32_t blocks, hipStream_t stream);
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu);
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t leafq, uint32_t hot_records, int* blocks_per_cu);
 // eager_light: request the side array's entry together with the slot (scenes in which a surface emits)
 hipError_t wf_launch_hit(bool compact, bool eager_light, const SceneDev& sc, const CameraDev& cam, const RenderDev& rp, const WfDev& wf,
                          uint32_t blocks, hipStream_t stream);

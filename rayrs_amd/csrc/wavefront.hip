@@ -549,16 +549,19 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // and the slot holds the closest hit so far (the hot group's): the walk starts from that, at the first record.
 template <bool COMPACT, bool COUNT, bool EXACT, bool PRE>
 __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev rp, WfDev wf) {
+    static_assert(EXACT || !PRE, "pre-tested rays are the default walk's");
     extern __shared__ uint32_t lds_dyn[];
     WfCtl* ctl = wf.ctl;
     if (ctl->live_slots == 0u) return;  // a round enqueued behind the frame's last one (abi.cpp look-behind)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // dynamic LDS: 4 stacks of (stack_lds + 1 spare) x 64 words, 4 window lists of WINDOW uint16, hot_records wide records
-    const LaneStack stack{lds_dyn + (size_t)wave * (sc.stack_lds + 1u) * 64u + lane,
+    // dynamic LDS: 4 stacks of (stack_lds + 1 spare + leafq queued leaf groups) x 64 words, 4 window lists of WINDOW uint16,
+    // hot_records wide records
+    const uint32_t stack_words = (sc.stack_lds + 1u + sc.leafq) * 64u;
+    const LaneStack stack{lds_dyn + (size_t)wave * stack_words + lane,
                           wf.stack_spill + ((size_t)blockIdx.x * 256u + threadIdx.x), sc.stack_lds, wf.trav_threads};
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u) + wave * WINDOW;
-    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)(sc.stack_lds + 1u) * 64u + 4u * WINDOW / 2u);
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds_dyn + 4u * (size_t)stack_words) + wave * WINDOW;
+    uint4* hot_lds = reinterpret_cast<uint4*>(lds_dyn + 4u * (size_t)stack_words + 4u * WINDOW / 2u);
     {
         constexpr uint32_t G = COMPACT ? 8u : 16u;  // 16-byte granules per record
         const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
@@ -574,6 +577,9 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
         const HotPtr h = hot_ptr(sc);
         root_ref0 = h->root_ref[0], root_ref1 = h->root_ref[1], root_ref2 = h->root_ref[2], root_ref3 = h->root_ref[3];
     }
+    // which of them are leaf groups (an unused slot is never entered)
+    const uint32_t root_leaves = (root_ref0 >= REF_LEAF_BASE ? 1u : 0u) | (root_ref1 >= REF_LEAF_BASE ? 2u : 0u) |
+                                 (root_ref2 >= REF_LEAF_BASE ? 4u : 0u) | (root_ref3 >= REF_LEAF_BASE ? 8u : 0u);
 
     const uint32_t n_windows = wf.np / WINDOW;
     // Windows of the pool are handed out in two ways.  The first rp.static_windows windows are
@@ -601,11 +607,15 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
     unsigned long long tk_int = 0, tk_leaf = 0, tk_refill = 0, tk_last = COUNT ? clock64() : 0ull;
 
     for (;;) {
-        const bool at_int = active && trav_at_interior(tv);
-        const bool at_leaf = active && !trav_at_interior(tv);
+        // EXACT (the default walk): a lane's leaf groups wait in its queue while it walks on (device_path.h
+        // trav_interior_step_defer) -- it is at_int whenever it has a record to visit (and room for what the record may
+        // queue), at_leaf whenever a group waits; both at once is the rule.  Else: the lane stands on ONE reference.
+        const bool at_int = EXACT ? (active && tv.cur != TRAV_DONE && defer_has_room(tv)) : (active && trav_at_interior(tv));
+        const bool at_leaf = EXACT ? (active && defer_has_leaf(tv)) : (active && !trav_at_interior(tv));
         const int n_int = __popcll(__ballot(at_int));
         const int n_leaf = __popcll(__ballot(at_leaf));
-        if ((n_int + n_leaf < (int)rp.refill_min && !no_more) || n_int + n_leaf == 0) {
+        const int n_work = EXACT ? __popcll(__ballot(active)) : n_int + n_leaf;
+        if ((n_work < (int)rp.refill_min && !no_more) || n_work == 0) {
             // ---- retire finished queries: result and new state to the slot
             if (pending) {
                 const bool hit = tv.best_prim != 0xffffffffu;
@@ -656,24 +666,39 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
                         // reference, the others wait on its stack so that they come off it in slot order, as
                         // trav_interior_step would have left them
                         const uint32_t m = entry >> 9;
-                        const int n = (int)__popc(m);
-                        const uint32_t low = m & (0u - m);
                         // (the references are scalars; taken through an empty asm here so that their copies into vector
                         // registers for the stores below are made here and not kept -- spilled -- across the whole walk)
                         uint32_t r1 = root_ref1, r2 = root_ref2, r3 = root_ref3;
                         asm volatile("" : "+s"(r1), "+s"(r2), "+s"(r3));
-                        tv.cur = (low & 1u) ? root_ref0 : (low & 2u) ? r1 : (low & 4u) ? r2 : r3;
-                        tv.sp = n - 1;
-                        if ((m & 2u) && low != 2u) stack.put(n - 1 - (int)__popc(m & 1u), r1);  // (put: in LDS, or in the lane's HBM strip
-                        if ((m & 4u) && low != 4u) stack.put(n - 1 - (int)__popc(m & 3u), r2);  //  when fewer than three entries are kept in
-                        if ((m & 8u) && low != 8u) stack.put(n - 1 - (int)__popc(m & 7u), r3);  //  LDS; a branch-free variant measured the same)
+                        // leaf slots among them go to the lane's queue; of the interior ones the first becomes the lane's
+                        // record, the others wait on its stack so that they come off it in slot order
+                        const uint32_t mi = m & ~root_leaves, ml = m & root_leaves;  // (root_leaves: scalar)
+                        const int n = (int)__popc(mi);
+                        const uint32_t low = mi & (0u - mi);
+                        tv.cur = mi == 0u ? TRAV_DONE : (low & 1u) ? root_ref0 : (low & 2u) ? r1 : (low & 4u) ? r2 : r3;
+                        tv.sp = n > 0 ? n - 1 : 0;
+                        if ((mi & 2u) && low != 2u) stack.put(n - 1 - (int)__popc(mi & 1u), r1);  // (put: in LDS, or in the lane's HBM strip
+                        if ((mi & 4u) && low != 4u) stack.put(n - 1 - (int)__popc(mi & 3u), r2);  //  when fewer than three entries are kept in
+                        if ((mi & 8u) && low != 8u) stack.put(n - 1 - (int)__popc(mi & 7u), r3);  //  LDS; a branch-free variant measured the same)
+                        if (ml != 0u) {  // (not on the obj scenes: their first record's slots are the mesh's quarters)
+                            if (ml & 1u) defer_take_ref(stack, tv, root_ref0);
+                            if (ml & 2u) defer_take_ref(stack, tv, r1);
+                            if (ml & 4u) defer_take_ref(stack, tv, r2);
+                            if (ml & 8u) defer_take_ref(stack, tv, r3);
+                        }
                         active = true;
                     } else {
                         trav_init(sc, o, d, tv);
-                        if (tv.cur == TRAV_DONE)
+                        if (tv.cur == TRAV_DONE) {
                             pending = true;  // missed the root box: retired at the next refill
-                        else
+                        } else {
                             active = true;
+                            if (EXACT && tv.cur >= REF_LEAF_BASE) {  // a tree that is one leaf group
+                                const uint32_t ref = tv.cur;
+                                tv.cur = TRAV_DONE;
+                                defer_take_ref(stack, tv, ref);
+                            }
+                        }
                     }
                     need = false;
                 }
@@ -688,12 +713,21 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             if (__ballot(active || pending) == 0ull && no_more) break;
             continue;
         }
-        if (n_leaf >= (int)rp.leaf_min || n_int == 0) {
-            // ---- leaf phase: every lane standing on a leaf tests its primitives
+        // EXACT: a leaf phase also once leaf_wait lanes can do nothing else (they have groups waiting and no record to
+        // visit, or no room): those lanes idle through interior phases, and a lane is retired only when its queue is empty
+        const bool leaf_phase = n_leaf >= (int)rp.leaf_min || n_int == 0 ||
+                                (EXACT && __popcll(__ballot(at_leaf && !at_int)) >= (int)rp.leaf_wait);
+        if (leaf_phase) {
+            // ---- leaf phase: every lane standing on a leaf (EXACT: with a group waiting) tests its primitives
             if (COUNT) u_leaf_wave += 1, u_leaf_lane += at_leaf ? 1 : 0;
             if (at_leaf) {
-                trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
-                if (tv.cur == TRAV_DONE) active = false, pending = true;
+                if (EXACT) {
+                    trav_leaf_step_defer<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                    if (defer_finished(tv)) active = false, pending = true;
+                } else {
+                    trav_leaf_step<COMPACT, COUNT>(sc, o, d, stack, tv, wc);
+                    if (tv.cur == TRAV_DONE) active = false, pending = true;
+                }
             }
             if (COUNT) {
                 const unsigned long long now = clock64();
@@ -703,8 +737,13 @@ __global__ void __launch_bounds__(256, 5) wf_trav_kernel(SceneDev sc, RenderDev 
             // ---- interior phase: one record for every lane standing on one
             if (COUNT) u_int_wave += 1, u_int_lane += at_int ? 1 : 0;
             if (at_int) {
-                trav_interior_step<COMPACT, COUNT, EXACT>(sc, o, stack, hot, tv, wc);
-                if (tv.cur == TRAV_DONE) active = false, pending = true;
+                if (EXACT) {
+                    trav_interior_step_defer<COMPACT, COUNT>(sc, o, stack, hot, tv, wc);
+                    if (defer_finished(tv)) active = false, pending = true;
+                } else {
+                    trav_interior_step<COMPACT, COUNT, false>(sc, o, stack, hot, tv, wc);
+                    if (tv.cur == TRAV_DONE) active = false, pending = true;
+                }
             }
             if (COUNT) {
                 const unsigned long long now = clock64();
@@ -967,8 +1006,8 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
 
 // ----------------------------------------------------------- launch glue
 
-static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t hot_records) {
-    return 4u * 64u * (stack_lds + 1u) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
+static inline uint32_t trav_lds_bytes(bool compact, uint32_t stack_lds, uint32_t leafq, uint32_t hot_records) {
+    return 4u * 64u * (stack_lds + 1u + leafq) * 4u + 4u * WINDOW * 2u + hot_records * (compact ? 144u : 272u);
 }
 
 uint32_t wf_window_slots() { return WINDOW; }
@@ -988,7 +1027,7 @@ hipError_t wf_launch_gen(bool compact, const SceneDev& sc, const CameraDev& cam,
 template <bool COMPACT, bool COUNT>
 static hipError_t launch_trav_t(const SceneDev& sc, const RenderDev& rp, const WfDev& wf, uint32_t blocks,
                                 hipStream_t stream) {
-    const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.hot_records);
+    const uint32_t lds = trav_lds_bytes(COMPACT, sc.stack_lds, sc.leafq, sc.hot_records);
     if (sc.exact && sc.hot) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, true>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);  // PRE
     else if (sc.exact) hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, true, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
     else hipLaunchKernelGGL((wf_trav_kernel<COMPACT, COUNT, false, false>), dim3(blocks), dim3(256), lds, stream, sc, rp, wf);
@@ -1016,9 +1055,9 @@ static hipError_t trav_set_lds(uint32_t lds) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t hot_records, int* blocks_per_cu) {
+hipError_t wf_trav_occupancy(bool compact, uint32_t stack_lds, uint32_t leafq, uint32_t hot_records, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
-    const uint32_t lds = trav_lds_bytes(compact, stack_lds, hot_records);
+    const uint32_t lds = trav_lds_bytes(compact, stack_lds, leafq, hot_records);
     if (compact) {
         if ((e = trav_set_lds<true, false>(lds)) != hipSuccess) return e;
         if ((e = trav_set_lds<true, true>(lds)) != hipSuccess) return e;
