@@ -98,7 +98,7 @@ class LabTuning(C.Structure):
     _fields_ = [("refill_min", C.c_uint32), ("leaf_min", C.c_uint32), ("static_pct", C.c_uint32),
                 ("stack_lds", C.c_uint32), ("hot_records", C.c_uint32), ("trav_blocks_per_cu", C.c_uint32),
                 ("eager_light", C.c_uint32), ("local_reserve", C.c_uint32), ("local_segment_items", C.c_uint32),
-                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("hot_group", C.c_uint32), ("leaf_wait", C.c_uint32)]
+                ("force_rccl", C.c_uint32), ("gate_tree", C.c_uint32), ("hot_group", C.c_uint32), ("leaf_wait", C.c_uint32), ("flat_blocks_per_cu", C.c_uint32)]
 
 
 # RAYRS_ABI_VERSION these mirrors were written against: lib() refuses a library of another version

@@ -29,6 +29,7 @@ constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 // The trees the default walk reads: a lane's leaf groups wait in a queue of LEAFQ entries behind its stack
 // (device_path.h trav_interior_step_defer), so its stack holds interior records only -- 8 entries in LDS serve what 12
 // served with the leaves among them -- and the records kept in LDS give up the other 4 KiB of the queue's 8.
+constexpr uint32_t FLAT_BLOCKS_PER_CU = 8;  // the gen / hit / miss kernels' common grid (rayrs_lab_tuning.flat_blocks_per_cu)
 constexpr uint32_t TRAV_STACK_LDS_DEFER = 8;
 constexpr uint32_t TRAV_HOT_BYTES_DEFER = 10u * 1024u;
 }  // namespace
@@ -524,7 +525,7 @@ int rayrs_lab_set(rayrs_scene* scene, const rayrs_lab_tuning* lab) {
     if (!scene || !lab) return RAYRS_INVALID_ARG;
     if (lab->stack_lds > 64u) return RAYRS_INVALID_ARG;  // 4 x 64 lanes x 65 entries x 4 B: what a workgroup's LDS can spare
     if (lab->hot_group != 0u && lab->hot_group != 0xffffffffu) return RAYRS_INVALID_ARG;
-    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->leaf_wait > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
+    if (lab->static_pct > 100u || lab->refill_min > 64u || lab->leaf_min > 64u || lab->leaf_wait > 64u || lab->flat_blocks_per_cu > 64u || lab->eager_light > 1u || lab->force_rccl > 1u || lab->gate_tree > 1u)
         return RAYRS_INVALID_ARG;
     if (lab->local_reserve != 0u && (lab->local_reserve < 8u || lab->local_reserve > 4096u)) return RAYRS_INVALID_ARG;
     if (lab->local_segment_items != 0u && lab->local_segment_items < 65536u) return RAYRS_INVALID_ARG;
@@ -837,7 +838,7 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three: one
         // wave per window, at most eight workgroups per CU
         uint32_t fb = (n_windows + 3u) / 4u;
-        const uint32_t flat_cap = (uint32_t)scene->cu_count * 8u;
+        const uint32_t flat_cap = (uint32_t)scene->cu_count * (lab.flat_blocks_per_cu ? lab.flat_blocks_per_cu : FLAT_BLOCKS_PER_CU);
         if (fb > flat_cap) fb = flat_cap;
         flat_blocks = fb;
         wf.n_flat_waves = fb * 4u;

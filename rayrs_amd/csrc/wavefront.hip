@@ -190,6 +190,26 @@ RR_DEV void wave_atomic_add(unsigned long long* dst, unsigned long long v) {
     if ((threadIdx.x & 63u) == 0 && s) atomicAdd(dst, s);
 }
 
+// ---- kernel arguments, re-read where they are used ----
+// The gen, hit and miss kernels take (SceneDev, CameraDev, RenderDev, WfDev) by value: 488 bytes of scalars, loop invariants
+// all.  Left to itself the compiler loads them at the kernel's entry, runs out of scalar registers in the hit kernel's loop,
+// parks them in lanes of a vector register and fetches each back with a v_readlane -- a VECTOR instruction per dword -- where
+// it is used: 330 of them in next_sample and finish_rays.  The arguments sit in memory already (the kernarg segment, served
+// by the scalar cache): karg<T, OFF>() hands out a view of one of them behind a pointer the compiler cannot see through, so
+// the fields are s_load-ed where the view is made and live only as long as that region needs them.
+constexpr uint32_t ka_up(uint32_t off, uint32_t a) { return (off + a - 1u) / a * a; }
+constexpr uint32_t KA_SC = 0;
+constexpr uint32_t KA_CAM = ka_up(KA_SC + (uint32_t)sizeof(SceneDev), (uint32_t)alignof(CameraDev));
+constexpr uint32_t KA_RP = ka_up(KA_CAM + (uint32_t)sizeof(CameraDev), (uint32_t)alignof(RenderDev));
+constexpr uint32_t KA_WF = ka_up(KA_RP + (uint32_t)sizeof(RenderDev), (uint32_t)alignof(WfDev));
+template <class T, uint32_t OFF>
+RR_DEV const T& karg() {
+    typedef const __attribute__((address_space(4))) char* KPtr;
+    KPtr p = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + OFF;
+    asm volatile("" : "+s"(p));
+    return *(const T*)p;
+}
+
 RR_DEV RaySlot* ray_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].ray; }
 RR_DEV TailSlot* tail_slot(const WfDev& wf, uint32_t slot) { return &wf.slots[slot].tail; }
 RR_DEV double* light_slot(const WfDev& wf, uint32_t slot) { return wf.light + (size_t)slot * 4u; }
@@ -314,8 +334,9 @@ struct SampleCount {
 // Every test is the one BvhTree::intersect makes, on the same values; the closest hit is the smallest accepted t, the
 // first primitive in depth-first order on exact ties (bvh.rs:62), in whatever order and by whichever kernel the
 // primitives are tested.  `got`: the lane holds a ray (o, d) for `slot`; `enters`: it is known to enter the root box.
-RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o, V3 d, V3 inv, uint32_t bd, const SceneDev& sc,
-                        const WfDev& wf, SampleCount& sn) {
+RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o, V3 d, V3 inv, uint32_t bd, SampleCount& sn) {
+    const SceneDev& sc = karg<SceneDev, KA_SC>();
+    const WfDev& wf = karg<WfDev, KA_WF>();
     Trav tv;
     tv.inv = inv, tv.best_t = sc.t1, tv.best_prim = 0xffffffffu, tv.cur = TRAV_DONE, tv.sp = 0;
     WorkCount wc{0, 0, 0, 0, 0};
@@ -353,11 +374,11 @@ RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o
 // CARRY (the hit kernel): lanes whose path goes on bring their bounced ray (co, cd, cbd) along; it is written out at the
 // end together with the new samples' primary rays, so that the pre-test above runs once, on a full wave.
 template <bool COMPACT, bool DEFER = false>
-RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, const SceneDev& sc,
-                        const CameraDev& cam, const RenderDev& rp, const WfDev& wf, ItemRange& range,
+RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, ItemRange& range,
                         SampleCount& sn, bool carry = false, V3 co = V3{0.0, 0.0, 0.0}, V3 cd = V3{0.0, 0.0, 1.0},
                         uint32_t cbd = 0u) {
-    const bool pre = sc.hot != nullptr;  // wave-uniform: the rays made here are pre-tested (finish_rays)
+    // (the kernel's arguments: views made where a region needs them -- karg above)
+    const bool pre = karg<SceneDev, KA_SC>().hot != nullptr;  // wave-uniform: the rays made here are pre-tested (finish_rays)
     bool todo = want;  // lanes still without a ray for their slot
     bool has_item = want && ir.has_item != 0u;
     uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
@@ -370,6 +391,9 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     V3 o = co, d = cd, inv = mk(0.0, 0.0, 0.0);
     uint32_t bd = cbd;
     for (;;) {
+        const RenderDev& rp = karg<RenderDev, KA_RP>();
+        const WfDev& wf = karg<WfDev, KA_WF>();
+        const uint32_t cam_W = karg<CameraDev, KA_CAM>().W, cam_H = karg<CameraDev, KA_CAM>().H;
         // an item whose samples are all done is written out (its sum goes to the resolve kernel)
         if (todo && has_item && s_cur >= s_end) {
             double* dst = rp.partial + (size_t)item * 3;
@@ -395,11 +419,11 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
                 uint32_t s_begin;
                 item_geometry(rp, item, row, col, s_begin, s_end);
                 s_cur = s_begin;
-                if (row >= cam.H || col >= cam.W || rp.max_bounces == 0u) {
+                if (row >= cam_H || col >= cam_W || rp.max_bounces == 0u) {
                     // padding pixel of an edge tile (never read) or radiance() with an empty loop: zeros
                     double* dst = rp.partial + (size_t)item * 3;
                     dst[0] = dst[1] = dst[2] = 0.0;
-                    if (row < cam.H && col < cam.W) sn.paths += s_end - s_begin;
+                    if (row < cam_H && col < cam_W) sn.paths += s_end - s_begin;
                 } else {
                     has_item = true;
                     fresh = true;
@@ -419,6 +443,8 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         }
         if (todo && has_item) {
             // start the slot's next sample (main.rs:68-76)
+            const CameraDev& cam = karg<CameraDev, KA_CAM>();
+            const SceneDev& sc = karg<SceneDev, KA_SC>();
             Rng rng;
             rng.key = rr_path_key(rp.seed, (uint64_t)row * cam.W + col, (uint64_t)s_cur);
             rng.draw = 0;
@@ -462,11 +488,12 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
     if (pre) {
         if (DEFER) {  // every ray of the batch: 1 / d and the root Node's box (bvh.rs:394)
             inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-            enters = root_box_hit(sc, o, inv);
+            enters = root_box_hit(karg<SceneDev, KA_SC>(), o, inv);
         }
         if (primary && !enters) sn.deferred++;  // (only with DEFER: elsewhere such a sample was finished above)
-        finish_rays(got, enters, primary, slot, o, d, inv, bd, sc, wf, sn);
+        finish_rays(got, enters, primary, slot, o, d, inv, bd, sn);
     } else if (got) {
+        const WfDev& wf = karg<WfDev, KA_WF>();
         RaySlot* rs = ray_slot(wf, slot);
         rs->o[0] = o.x, rs->o[1] = o.y, rs->o[2] = o.z;
         rs->d[0] = d.x, rs->d[1] = d.y, rs->d[2] = d.z;
@@ -530,7 +557,7 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
             ItemRegs ir;
             ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
             ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;
-            next_sample<COMPACT>(valid, slot, ir, false, sc, cam, rp, wf, range, sn);
+            next_sample<COMPACT>(valid, slot, ir, false, range, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -838,9 +865,12 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     while (have) {
         HitIn nxt;
         bool have_next = false;
-        have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        RR_TICK(5)
-        if (have_next) load_hit_in<EAGER>(wf, nxt);
+        {
+            const WfDev& wfv = karg<WfDev, KA_WF>();  // (the kernel's arguments are re-read where they are used: karg)
+            have_next = feed_next(feed, wfv, nxt.slot, nxt.valid);
+            RR_TICK(5)
+            if (have_next) load_hit_in<EAGER>(wfv, nxt);
+        }
         RR_TICK(0)
         PrimRec<COMPACT> rec_nxt;
         {
@@ -853,6 +883,9 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             uint32_t bd_next = 0;
             if (valid) {
                 RR_TICK_LOADS_ARRIVED(6)
+                const SceneDev& sc = karg<SceneDev, KA_SC>();
+                const RenderDev& rp = karg<RenderDev, KA_RP>();
+                const WfDev& wf = karg<WfDev, KA_WF>();
                 const V3 o = cur.o;
                 const V3 d = cur.d;
                 const double t = cur.t;
@@ -861,7 +894,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
                 light = mk(0.0, 0.0, 0.0);
                 if (bounce > 1u && ir.has_light) light = EAGER ? cur.light : load_light(wf, slot);
-                Rng rng{sample_key(rp, cam, ir), cur.bd >> 16};
+                Rng rng{sample_key(rp, karg<CameraDev, KA_CAM>(), ir), cur.bd >> 16};
                 // lib.rs:528-551
                 const PrimRec<COMPACT>& rec = rec_cur;
                 position = v_add(o, v_scale(d, t));
@@ -898,9 +931,10 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
             }
             RR_TICK(1)
             // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
-            if (have_next) rec_nxt = load_prim<COMPACT>(sc.prims, nxt.valid ? nxt.prim : 0u);
+            if (have_next) rec_nxt = load_prim<COMPACT>(karg<SceneDev, KA_SC>().prims, nxt.valid ? nxt.prim : 0u);
             RR_TICK(2)
             if (goes_on) {
+                const WfDev& wf = karg<WfDev, KA_WF>();
                 // (the bounced ray itself -- origin, direction, bounce | draw, state -- is written by next_sample below, together
                 // with the new samples' primary rays: one pre-test for the whole batch, finish_rays)
                 TailSlot* lt = tail_slot(wf, slot);
@@ -914,7 +948,8 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 // it the 32-byte sector it lies in -- stores cost these kernels more than anything they compute)
                 if (keep_light != (ir.has_light != 0u)) lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
             }
-            if (rp.count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
+            if (karg<RenderDev, KA_RP>().count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
+                const RenderDev& rp = karg<RenderDev, KA_RP>();
 #pragma unroll
                 for (uint32_t k = 0; k < 8u; k++) {
                     const uint32_t c = (uint32_t)__popcll(__ballot(hit_sid == k));
@@ -922,7 +957,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
             }
             RR_TICK(3)
-            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, sc, cam, rp, wf, range, sn, goes_on, position, dir, bd_next);
+            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, range, sn, goes_on, position, dir, bd_next);
             RR_TICK(4)
         }
         cur = nxt;
@@ -975,8 +1010,12 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     RR_TICKS_BEGIN(3);
     while (have) {
         MissIn nxt;
-        const bool have_next = feed_next(feed, wf, nxt.slot, nxt.valid);
-        if (have_next) load_miss_in<EAGER>(wf, nxt);
+        bool have_next;
+        {
+            const WfDev& wfv = karg<WfDev, KA_WF>();  // (the kernel's arguments are re-read where they are used: karg)
+            have_next = feed_next(feed, wfv, nxt.slot, nxt.valid);
+            if (have_next) load_miss_in<EAGER>(wfv, nxt);
+        }
         RR_TICK(0)
         ItemRegs ir = cur.ir;
         if (cur.valid) {
@@ -984,14 +1023,14 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             const bool first = (cur.bd & 0xffffu) <= 1u;
             const V3 thr = first ? mk(1.0, 1.0, 1.0) : cur.thr;
             V3 light = mk(0.0, 0.0, 0.0);
-            if (!first && ir.has_light) light = EAGER ? cur.light : load_light(wf, cur.slot);
-            const V3 result = v_add(light, v_mul(thr, background(sc, cur.d)));  // lib.rs:555
+            if (!first && ir.has_light) light = EAGER ? cur.light : load_light(karg<WfDev, KA_WF>(), cur.slot);
+            const V3 result = v_add(light, v_mul(thr, background(karg<SceneDev, KA_SC>(), cur.d)));  // lib.rs:555
             ir.acc[0] += result.x;
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
         RR_TICK(1)
-        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, sc, cam, rp, wf, range, sn);
+        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, range, sn);
         RR_TICK(2)
         cur = nxt;
         have = have_next;
