@@ -238,7 +238,7 @@ void rayrs_scene_destroy(rayrs_scene* scene) {
 // Sizes the traversal workgroup's LDS from the tree and the scene's tuning, and asks the runtime how
 // many such workgroups fit a CU.  A workgroup's LDS: the first stack_lds entries of each lane's stack
 // (deeper entries overflow to HBM; on the 1M-triangle scene 99.4 % of visits happen with at most 7
-// pending), 4 KiB of window lists, and the hot_records largest wide records.  13 + 4 + 14 KiB lets
+// pending), 4 KiB of window lists, and the hot_records largest wide records.  13 + 4 + 14 KiB (the default walk's trees: 17 KiB with the lanes' leaf queues + 4 + 10) lets
 // five workgroups (the kernel's launch bound) share a CU's 160 KiB.
 static int scene_configure_traversal(rayrs_scene* s) {
     const FlatScene& f = s->flat;

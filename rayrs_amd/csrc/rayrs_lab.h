@@ -19,10 +19,12 @@ extern "C" {
 
 typedef struct {
     uint32_t refill_min;    /* traversal: refill a wave's idle lanes when fewer than this are traversing (52) */
-    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (24) */
+    uint32_t leaf_min;      /* traversal: run a leaf phase once this many lanes stand on a leaf (the fast walk: 24) / have a leaf
+                               group waiting (the default walk: 48) */
     uint32_t static_pct;    /* traversal: share of the pool's windows dealt round robin, 1..100 (50) */
-    uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12) */
-    uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth);
+    uint32_t stack_lds;     /* traversal: stack entries per lane kept in LDS, the rest in HBM (12; the default walk, whose
+                               stack holds interior records only: 8) */
+    uint32_t hot_records;   /* traversal: leading wide records copied to LDS, at most 256 (14 KiB worth; the default walk 10 KiB);
                                0xffffffff = none */
     uint32_t trav_blocks_per_cu; /* traversal workgroups per CU, at most what the occupancy query allows */
     uint32_t eager_light;   /* 1 = the hit and miss kernels request a path's entry of the light side array together

@@ -2,7 +2,8 @@
 // gfx950 kernels per round:
 //
 //   trav_kernel   persistent waves, one BVH query per lane, lanes refilled from the
-//                 pool as queries finish; per-lane stack in LDS   (bvh.rs:391-415)
+//                 pool as queries finish; per-lane stack (and, the default walk, a
+//                 queue of leaf groups set aside) in LDS          (bvh.rs:391-415)
 //   hit_kernel    Material::evaluate + emission + Russian roulette (lib.rs:528-547)
 //   miss_kernel   Scene::background                               (lib.rs:555)
 // When a path ends in the hit or miss kernel the same lane adds the sample to the
@@ -570,6 +571,13 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
 // lanes than refill_min the wave retires its finished queries and takes new rays
 // from its window list; a leaf phase runs once leaf_min lanes stand on a leaf (or
 // none is on an interior record).
+//
+// EXACT (the default walk: nothing is culled, so the order in which a ray's leaf groups are tested changes nothing): a lane
+// does not stand on a leaf -- it sets the group aside on a queue of its own in LDS and walks on (device_path.h
+// trav_interior_step_defer), so it takes part in interior phases while it has a record to visit AND in leaf phases while a
+// group waits.  A leaf phase runs once leaf_min lanes have a group waiting, once leaf_wait lanes can do nothing else, or
+// when no lane has a record to visit.  Interior phases at 0.77 of the lanes instead of 0.59, a quarter fewer of them
+// (profiles/r06_leaf_queue.txt; priced beforehand with scripts/sim/walk_sched_sim.py).
 
 // PRE (the default walk on a scene with a hot group, layout.h HotGroupDev): the rays come pre-tested by the kernel that
 // made them (finish_rays above) -- they are known to enter the root box and at least one slot of the tree's first record,

@@ -3,7 +3,7 @@ usage: python scripts/ubench/tune_sweep.py <config> <res> <spp> "k=v,k=v" "k=v" 
 Each setting is rendered twice in the order A B C ... C B A; prints trace / traversal ms per render.
 TILE_RANKS=n in the environment renders one rank's share of n (what one GPU of n does; TILE_RANK=r which, default 0,
 "all" = every rank in turn, slowest reported last); CHUNK=n another sample chunk; FAST=1 renders with
-rayrs_render_params.fast_traversal."""
+rayrs_render_params.fast_traversal; CAM=close the camera the mesh fills (scenes.MESH_CLOSE_CAM)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayrs_amd
@@ -12,6 +12,8 @@ from rayrs_amd import scenes, procedural
 cfg, res, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 settings = sys.argv[4:] or [""]
 cam_args, objs, heur, _, mb = scenes.config(cfg)
+if os.environ.get("CAM") == "close":  # the camera the mesh fills (bench.py's secondary line)
+    cam_args = scenes.MESH_CLOSE_CAM
 cam_args = scenes.camera_for_resolution(cam_args, res, res)
 scene = rayrs_amd.Scene(objs, 1e-6, 1e6, heur, procedural.make_hdri(1024, 512), device=0)
 cam = rayrs_amd.Camera(*cam_args)
