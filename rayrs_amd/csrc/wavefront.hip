@@ -243,23 +243,30 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfDev wf, uint32_t live) {
 // at the end of the lane's work.
 struct ItemRegs {
     double acc[3];
-    uint32_t item, s_cur, s_end, has_item, pix;
-    uint32_t has_light;  // the path's light is in the side array (else it is +0)
+    uint32_t item, s_end, pix;
+    // TailSlot::s_cur AS LOADED: sample cursor | SLOT_LIGHT_BIT | SLOT_ITEM_BIT.  The fields are taken apart where they are
+    // used (cursor / has_item / has_light below), not where the word is loaded: load_item runs for batch b + 1 while batch b
+    // is still to be computed, and three bit operations on the loaded word there made the wave wait for the requests it
+    // had just issued -- a full memory latency at the top of every batch, the look-ahead undone (hit kernel: s_waitcnt
+    // vmcnt(4) behind its eight slot requests; found in the ISA, round 6).
+    uint32_t word;
+    RR_DEV uint32_t cursor() const { return word & SLOT_SAMPLE_MASK; }
+    RR_DEV bool has_item() const { return (word >> 31) != 0u; }
+    RR_DEV bool has_light() const { return ((word >> 30) & 1u) != 0u; }  // the path's light is in the side array (else it is +0)
 };
 
 RR_DEV ItemRegs load_item(const WfDev& wf, uint32_t slot) {
     const TailSlot* t = tail_slot(wf, slot);
     ItemRegs r;
     r.acc[0] = t->acc[0], r.acc[1] = t->acc[1], r.acc[2] = t->acc[2];
-    const uint32_t w = t->s_cur;
-    r.item = t->item, r.s_cur = w & SLOT_SAMPLE_MASK, r.s_end = t->s_end, r.pix = t->pix;
-    r.has_item = w >> 31, r.has_light = (w >> 30) & 1u;
+    r.word = t->s_cur;
+    r.item = t->item, r.s_end = t->s_end, r.pix = t->pix;
     return r;
 }
 
 // The RNG key of the sample a slot has in flight: the item's pixel and the sample before its cursor.
 RR_DEV uint64_t sample_key(const RenderDev& rp, const CameraDev& cam, const ItemRegs& ir) {
-    return rr_path_key(rp.seed, (uint64_t)(ir.pix >> 16) * cam.W + (ir.pix & 0xffffu), (uint64_t)(ir.s_cur - 1u));
+    return rr_path_key(rp.seed, (uint64_t)(ir.pix >> 16) * cam.W + (ir.pix & 0xffffu), (uint64_t)(ir.cursor() - 1u));
 }
 
 // A wave's private range of reserved item ids [next, end).  Items are taken from the
@@ -274,10 +281,21 @@ struct ItemRange {
     unsigned long long next, end;
 };
 
+RR_DEV unsigned long long wave_uniform64(unsigned long long v) {  // a value every lane holds alike, into scalar registers
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// SCALAR (the hit kernel): the range in scalar registers.  Left in the vector registers the loads return it in, it makes
+// next_sample's item loop wait for every request in flight at each turn -- the hit kernel's look-ahead loads among them.
+// The miss kernel, whose look-ahead is requested at its loop's top and waited for at Scene::background's lookup anyway,
+// measured 13 ms SLOWER with the scalar range (230.8 against 243.9 ms a frame, profiles/r06_leaf_queue.txt (6)): it keeps the
+// vector one.
+template <bool SCALAR = false>
 RR_DEV ItemRange load_item_range(const WfDev& wf, uint32_t wave) {
     ItemRange r;
     r.next = wf.wave_items[2 * (size_t)wave];
     r.end = wf.wave_items[2 * (size_t)wave + 1];
+    if (SCALAR) r.next = wave_uniform64(r.next), r.end = wave_uniform64(r.end);
     return r;
 }
 RR_DEV void store_item_range(const WfDev& wf, uint32_t wave, const ItemRange& r) {
@@ -374,15 +392,24 @@ RR_DEV void finish_rays(bool got, bool enters, bool primary, uint32_t slot, V3 o
 // the loop below: the hit kernel has bandwidth to spare and no latency to spare; the miss kernel does this work anyway.
 // CARRY (the hit kernel): lanes whose path goes on bring their bounced ray (co, cd, cbd) along; it is written out at the
 // end together with the new samples' primary rays, so that the pre-test above runs once, on a full wave.
+// The rays a batch ends up with: next_sample makes them, emit_rays pre-tests and writes them.  The two are separate calls so
+// that a kernel can issue its look-ahead loads between them: emit_rays is several thousand cycles of arithmetic on scalar
+// operands without a call or a wait in it -- the one stretch of these kernels a request can be in flight behind.
+struct NewRays {
+    bool got, enters, carry;  // the lane holds a ray for its slot; it is known to enter the root box; it is a bounced ray
+    V3 o, d, inv;
+    uint32_t bd;
+};
+
 template <bool COMPACT, bool DEFER = false>
-RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, ItemRange& range,
-                        SampleCount& sn, bool carry = false, V3 co = V3{0.0, 0.0, 0.0}, V3 cd = V3{0.0, 0.0, 1.0},
-                        uint32_t cbd = 0u) {
+RR_DEV NewRays next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_dirty, ItemRange& range,
+                           SampleCount& sn, bool carry = false, V3 co = V3{0.0, 0.0, 0.0}, V3 cd = V3{0.0, 0.0, 1.0},
+                           uint32_t cbd = 0u) {
     // (the kernel's arguments: views made where a region needs them -- karg above)
     const bool pre = karg<SceneDev, KA_SC>().hot != nullptr;  // wave-uniform: the rays made here are pre-tested (finish_rays)
     bool todo = want;  // lanes still without a ray for their slot
-    bool has_item = want && ir.has_item != 0u;
-    uint32_t item = ir.item, s_cur = ir.s_cur, s_end = ir.s_end;
+    bool has_item = want && ir.has_item();
+    uint32_t item = ir.item, s_cur = ir.cursor(), s_end = ir.s_end;
     uint32_t row = ir.pix >> 16, col = ir.pix & 0xffffu;
     double acc0 = ir.acc[0], acc1 = ir.acc[1], acc2 = ir.acc[2];
     bool fresh = false;            // the slot's item record has to be written in full
@@ -483,7 +510,18 @@ RR_DEV void next_sample(bool want, uint32_t slot, const ItemRegs& ir, bool acc_d
         }
         if (__ballot(todo) == 0ull) break;
     }
-    // ---- the rays: bounced ones brought along (carry) and the new samples' primary rays
+    return NewRays{got, enters, carry, o, d, inv, bd};
+}
+
+// ---- the rays: bounced ones brought along (carry) and the new samples' primary rays
+template <bool DEFER>
+RR_DEV void emit_rays(uint32_t slot, const NewRays& nr, SampleCount& sn) {
+    const bool got = nr.got, carry = nr.carry;
+    bool enters = nr.enters;
+    const V3 o = nr.o, d = nr.d;
+    V3 inv = nr.inv;
+    const uint32_t bd = nr.bd;
+    const bool pre = karg<SceneDev, KA_SC>().hot != nullptr;  // wave-uniform: the rays are pre-tested (finish_rays)
     if (__ballot(got) == 0ull) return;
     const bool primary = got && !carry;
     if (pre) {
@@ -557,8 +595,9 @@ __global__ void __launch_bounds__(256) wf_gen_kernel(SceneDev sc, CameraDev cam,
             // ::test_two_different_frames_back_to_back_on_one_scene); the item starts from zeros made here
             ItemRegs ir;
             ir.acc[0] = ir.acc[1] = ir.acc[2] = 0.0;
-            ir.item = ir.s_cur = ir.s_end = ir.has_item = ir.pix = ir.has_light = 0u;
-            next_sample<COMPACT>(valid, slot, ir, false, range, sn);
+            ir.item = ir.s_end = ir.pix = ir.word = 0u;
+            const NewRays nr = next_sample<COMPACT>(valid, slot, ir, false, range, sn);
+            emit_rays<false>(slot, nr, sn);
         }
     }
     store_item_range(wf, wave, range);
@@ -840,7 +879,7 @@ RR_DEV void load_hit_in(const WfDev& wf, HitIn& h) {  // idle lanes read slot 0:
 
 // Built for two workgroups per CU: 256 registers, batch b + 1 requested while batch b is computed (below).
 template <bool COMPACT, bool EAGER>
-__global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
+__global__ void __launch_bounds__(256, 3) wf_hit_kernel(SceneDev sc, CameraDev cam, RenderDev rp, WfDev wf) {
     __shared__ uint32_t lists[4][FEED_LIST];
     // The surface row is the third dependent fetch of a hit (slot -> primitive -> surface);
     // scenes have a handful of rows, so the first HIT_SURFACES_LDS of them wait in LDS.
@@ -855,7 +894,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     SampleCount sn{0, 0, 0, 0, HotTally{0, 0, 0}, 0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) wf.ctl->next_window = 0;  // the traversal kernel's window cursor
-    ItemRange range = load_item_range(wf, wave);
+    ItemRange range = load_item_range<true>(wf, wave);
     BatchFeed feed;
     feed_init(feed, wf, wave, n_waves, WF_HIT, list);
     // Three fetches per hit depend on each other: slot -> primitive record -> surface row.  The slot records of
@@ -873,13 +912,6 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
     while (have) {
         HitIn nxt;
         bool have_next = false;
-        {
-            const WfDev& wfv = karg<WfDev, KA_WF>();  // (the kernel's arguments are re-read where they are used: karg)
-            have_next = feed_next(feed, wfv, nxt.slot, nxt.valid);
-            RR_TICK(5)
-            if (have_next) load_hit_in<EAGER>(wfv, nxt);
-        }
-        RR_TICK(0)
         PrimRec<COMPACT> rec_nxt;
         {
             const uint32_t slot = cur.slot;
@@ -901,7 +933,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 // loaded unconditionally, beside the ray, and ignored while bounce == 1 (lib.rs:522-523)
                 thr = bounce > 1u ? cur.thr : mk(1.0, 1.0, 1.0);
                 light = mk(0.0, 0.0, 0.0);
-                if (bounce > 1u && ir.has_light) light = EAGER ? cur.light : load_light(wf, slot);
+                if (bounce > 1u && ir.has_light()) light = EAGER ? cur.light : load_light(wf, slot);
                 Rng rng{sample_key(rp, karg<CameraDev, KA_CAM>(), ir), cur.bd >> 16};
                 // lib.rs:528-551
                 const PrimRec<COMPACT>& rec = rec_cur;
@@ -938,9 +970,21 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
             }
             RR_TICK(1)
-            // batch b + 1's slot records have arrived long ago: its primitive records, ahead of this batch's stores
-            if (have_next) rec_nxt = load_prim<COMPACT>(karg<SceneDev, KA_SC>().prims, nxt.valid ? nxt.prim : 0u);
-            RR_TICK(2)
+            // ---- batch b + 1's slot records are requested HERE, behind Material::evaluate: every call of an elementary function
+            // (and the dispatch on the material's kind) waits for all the wave's requests in flight, so a request made ahead of
+            // them -- where rounds 1-5 made it -- was waited for a few hundred instructions later: a memory latency at the top
+            // of every batch, the look-ahead undone.  What follows -- this batch's stores, next_sample, emit_rays -- is ten
+            // thousand cycles without a call in it.
+            {
+                const WfDev& wfv = karg<WfDev, KA_WF>();  // (the kernel's arguments are re-read where they are used: karg)
+                have_next = feed_next(feed, wfv, nxt.slot, nxt.valid);
+                if (!have_next) nxt.slot = 0u, nxt.valid = false;
+                RR_TICK(5)
+                // (unconditional -- behind a wave's last batch every lane reads slot 0 once: under `if (have_next)` the loaded
+                // registers are copied into the loop's own at the end of the conditional block, i.e. waited for at once)
+                load_hit_in<EAGER>(wfv, nxt);
+            }
+            RR_TICK(0)
             if (goes_on) {
                 const WfDev& wf = karg<WfDev, KA_WF>();
                 // (the bounced ray itself -- origin, direction, bounce | draw, state -- is written by next_sample below, together
@@ -954,7 +998,7 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
                 // (the cursor word changes only when the path gets or loses its light: mostly it is left alone, and with
                 // it the 32-byte sector it lies in -- stores cost these kernels more than anything they compute)
-                if (keep_light != (ir.has_light != 0u)) lt->s_cur = ir.s_cur | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
+                if (keep_light != ir.has_light()) lt->s_cur = ir.cursor() | (keep_light ? SLOT_LIGHT_BIT : 0u) | SLOT_ITEM_BIT;
             }
             if (karg<RenderDev, KA_RP>().count_work) {  // wave-uniform; what the queries found, per surface row (bench.py: ray shares)
                 const RenderDev& rp = karg<RenderDev, KA_RP>();
@@ -965,7 +1009,13 @@ __global__ void __launch_bounds__(256, 2) wf_hit_kernel(SceneDev sc, CameraDev c
                 }
             }
             RR_TICK(3)
-            next_sample<COMPACT, true>(ended, slot, ir, acc_changed, range, sn, goes_on, position, dir, bd_next);
+            const NewRays nr = next_sample<COMPACT, true>(ended, slot, ir, acc_changed, range, sn, goes_on, position, dir, bd_next);
+            RR_TICK(4)
+            // batch b + 1's slot records have had next_sample's time to arrive: its primitive records (the second of the three
+            // dependent fetches of a hit), which have emit_rays' time
+            rec_nxt = load_prim<COMPACT>(karg<SceneDev, KA_SC>().prims, nxt.valid ? nxt.prim : 0u);
+            RR_TICK(2)
+            emit_rays<true>(slot, nr, sn);
             RR_TICK(4)
         }
         cur = nxt;
@@ -1017,12 +1067,16 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
     if (have) load_miss_in<EAGER>(wf, cur);
     RR_TICKS_BEGIN(3);
     while (have) {
+        // The next batch's slot records are requested at the loop's top.  (Behind next_sample, where only emit_rays' call-free
+        // stretch follows -- the hit kernel's order -- this kernel lost 5 %: it is bound by its 1.0 TB of random lines, and
+        // what it needs is requests in flight for as long as possible, whoever waits for them.)
         MissIn nxt;
         bool have_next;
         {
             const WfDev& wfv = karg<WfDev, KA_WF>();  // (the kernel's arguments are re-read where they are used: karg)
             have_next = feed_next(feed, wfv, nxt.slot, nxt.valid);
-            if (have_next) load_miss_in<EAGER>(wfv, nxt);
+            if (!have_next) nxt.slot = 0u, nxt.valid = false;
+            load_miss_in<EAGER>(wfv, nxt);  // (unconditional: see the hit kernel)
         }
         RR_TICK(0)
         ItemRegs ir = cur.ir;
@@ -1031,14 +1085,15 @@ __global__ void __launch_bounds__(256, 3) wf_miss_kernel(SceneDev sc, CameraDev 
             const bool first = (cur.bd & 0xffffu) <= 1u;
             const V3 thr = first ? mk(1.0, 1.0, 1.0) : cur.thr;
             V3 light = mk(0.0, 0.0, 0.0);
-            if (!first && ir.has_light) light = EAGER ? cur.light : load_light(karg<WfDev, KA_WF>(), cur.slot);
+            if (!first && ir.has_light()) light = EAGER ? cur.light : load_light(karg<WfDev, KA_WF>(), cur.slot);
             const V3 result = v_add(light, v_mul(thr, background(karg<SceneDev, KA_SC>(), cur.d)));  // lib.rs:555
             ir.acc[0] += result.x;
             ir.acc[1] += result.y;
             ir.acc[2] += result.z;
         }
         RR_TICK(1)
-        next_sample<COMPACT>(cur.valid, cur.slot, ir, true, range, sn);
+        const NewRays nr = next_sample<COMPACT>(cur.valid, cur.slot, ir, true, range, sn);
+        emit_rays<false>(cur.slot, nr, sn);
         RR_TICK(2)
         cur = nxt;
         have = have_next;

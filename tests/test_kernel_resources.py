@@ -49,9 +49,11 @@ def test_streaming_kernels_keep_their_occupancy(tmp_path):
     # ... for pre-tested rays (PRE: scenes with a hot group): the same
     for name, (vgpr, scratch) in pick(res, "wf_trav_kernelILb", "ELb0ELb1ELb1EEE").items():
         assert vgpr <= 96 and scratch <= 32, (name, vgpr, scratch)
-    # hit: two waves per SIMD (its look-ahead batch fills the file), miss: three; no scratch in either
+    # hit: THREE waves per SIMD since the look-ahead batch no longer lives across Material::evaluate (its slot records are
+    # requested behind it: 241 -> 172 registers by itself; the launch bound takes the last four: 32 bytes of scratch,
+    # seven accesses in the whole kernel), miss: three and no scratch
     for name, (vgpr, scratch) in pick(res, "wf_hit_kernel").items():
-        assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
+        assert vgpr <= 168 and scratch <= 32, (name, vgpr, scratch)
     for name, (vgpr, scratch) in pick(res, "wf_miss_kernel").items():
         assert vgpr <= 168 and scratch == 0, (name, vgpr, scratch)
 
