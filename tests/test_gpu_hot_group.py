@@ -136,6 +136,35 @@ def test_how_the_frame_is_cut_up_changes_nothing(how):
     assert tot["rays"] == ost["rays"] and 0 < tot["pre_rays"] < tot["rays"]
 
 
+@pytest.mark.parametrize("lab", [dict(leaf_min=64, leaf_wait=64), dict(leaf_min=64, leaf_wait=64, refill_min=64, stack_lds=2),
+                                 dict(leaf_min=1, leaf_wait=1), dict(leaf_min=64, leaf_wait=1, refill_min=1)],
+                         ids=["queues_fill", "queues_fill_stack_in_hbm", "leaf_phase_at_once", "one_lane_waits"])
+def test_leaf_groups_set_aside_in_any_order_change_nothing(lab):
+    """The default walk's lanes set the leaf groups they reach aside and walk on (device_path.h trav_interior_step_defer): the
+    closest hit is the smallest accepted t, first primitive in depth-first order on ties, in ANY order of the groups.  With leaf
+    phases held back until nobody has a record to visit the lanes' queues fill (a lane whose queue could not take four more
+    groups sits out interior phases: the queue cannot overflow); with a leaf phase at every group nothing ever waits.  Same
+    frame, same counters -- on a mesh whose rays cross a dozen groups."""
+    scene, cam, osc, ocam, _ = make(5, 48, 36, area_light=True)
+    spp = 5
+    oref, ost = osc.render(ocam, spp, 50, traversal=0)
+    _, wst = osc.use_product_walk(scene).render(ocam, spp, 50, traversal=2)
+    scene.lab_set(**lab)
+    img, st = rayrs_amd.render(scene, cam, spp, 50, out_f64=True, count_work=True)
+    assert st["hot_group"] == 1
+    assert np.array_equal(bits(img), bits(oref))
+    for k in ("rays", "interior_visits", "tri_tests", "plane_tests", "escaped_paths"):
+        assert st[k] == wst[k], k
+    assert st["rays"] == ost["rays"]
+    # the same on the close camera, where most rays need a deep walk
+    cam2 = rayrs_amd.Camera(*scenes.camera_for_resolution(scenes.MESH_CLOSE_CAM, 40, 40))
+    ocam2 = _oracle.OracleCamera(*scenes.camera_for_resolution(scenes.MESH_CLOSE_CAM, 40, 40))
+    osc2 = osc.use_product_walk(scene)
+    oref2, ost2 = osc2.render(ocam2, 3, 50, traversal=0)
+    img2, st2 = rayrs_amd.render(scene, cam2, 3, 50, out_f64=True)
+    assert np.array_equal(bits(img2), bits(oref2)) and st2["rays"] == ost2["rays"]
+
+
 def test_a_group_of_spheres_and_a_rectangle_can_be_the_hot_group():
     """The phase tests whatever kinds the group holds: a floor that shares its bottom Node with spheres."""
     from rayrs_amd.api import Axis, BvhHeuristic, Emission, Material, Object
