@@ -29,7 +29,7 @@ constexpr uint32_t TRAV_HOT_BYTES = 14u * 1024u;
 // The trees the default walk reads: a lane's leaf groups wait in a queue of LEAFQ entries behind its stack
 // (device_path.h trav_interior_step_defer), so its stack holds interior records only -- 8 entries in LDS serve what 12
 // served with the leaves among them -- and the records kept in LDS give up the other 4 KiB of the queue's 8.
-constexpr uint32_t FLAT_BLOCKS_PER_CU = 8;  // the gen / hit / miss kernels' common grid (rayrs_lab_tuning.flat_blocks_per_cu)
+constexpr uint32_t FLAT_BLOCKS_PER_CU_MIN = 8, FLAT_BLOCKS_PER_CU_MAX = 24;  // the gen / hit / miss kernels' common grid (rayrs_lab_tuning.flat_blocks_per_cu)
 constexpr uint32_t TRAV_STACK_LDS_DEFER = 8;
 constexpr uint32_t TRAV_HOT_BYTES_DEFER = 10u * 1024u;
 }  // namespace
@@ -836,9 +836,18 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
         }
 
         // the gen, hit and miss kernels run with this one grid, so wave w means the same windows in all three: one
-        // wave per window, at most eight workgroups per CU
+        // wave per window, at most 8 ... 24 workgroups per CU (below)
         uint32_t fb = (n_windows + 3u) / 4u;
-        const uint32_t flat_cap = (uint32_t)scene->cu_count * (lab.flat_blocks_per_cu ? lab.flat_blocks_per_cu : FLAT_BLOCKS_PER_CU);
+        // (8 ... 24 workgroups per CU, so that a wave has about nine windows: with the hit kernel at three resident workgroups
+        // per CU a finer grid evens out the end of a launch -- hit 411 -> 404 ms on the headline's 218 k windows at 24 -- but
+        // a wave that gets three windows spends its time on its first and last batch: config 3's 87 k windows want 8 or 9
+        // (198 against 200.5 ms at 24); profiles/r06_leaf_queue.txt (9))
+        uint32_t per_cu = lab.flat_blocks_per_cu;
+        if (!per_cu) {
+            per_cu = n_windows / (36u * (uint32_t)scene->cu_count);
+            per_cu = per_cu < FLAT_BLOCKS_PER_CU_MIN ? FLAT_BLOCKS_PER_CU_MIN : per_cu > FLAT_BLOCKS_PER_CU_MAX ? FLAT_BLOCKS_PER_CU_MAX : per_cu;
+        }
+        const uint32_t flat_cap = (uint32_t)scene->cu_count * per_cu;
         if (fb > flat_cap) fb = flat_cap;
         flat_blocks = fb;
         wf.n_flat_waves = fb * 4u;

@@ -42,8 +42,8 @@ typedef struct {
                                kept for the same-box A/B */
     uint32_t leaf_wait;     /* traversal, default walk: run a leaf phase once this many lanes can do nothing but wait for one
                                (leaf groups queued, no record to visit) (16) */
-    uint32_t flat_blocks_per_cu; /* gen / hit / miss kernels: workgroups per CU of their common grid, 1..64 (6: a whole number
-                               of rounds for the hit kernel's two and the miss kernel's three resident workgroups per CU) */
+    uint32_t flat_blocks_per_cu; /* gen / hit / miss kernels: workgroups per CU of their common grid, 1..64 (default: 8 .. 24 by the
+                               pool's size, about nine windows a wave) */
 } rayrs_lab_tuning;
 
 /* Applies to the renders launched on this scene afterwards.  Waits for a render in flight. */
