@@ -451,7 +451,7 @@ def main():
         if cx.info["local_pool"]:
             pool_b, sums_b = 0, min(items, 1 << 27) * 24
         else:
-            slots = min(items, 7 << 24, max(local_tiles * 64 * spp // 12, 1 << 20))
+            slots = min(items, 1 << 28, max(local_tiles * 64 * spp // 12, 1 << 20))
             pool_b, sums_b = ((slots + 1023) & ~1023) * (128 + 32 + 1), items * 24
         cx.hbm_bytes = int(cx.info["device_bytes"] + cx.n_flights * (pool_b + sums_b))
         print(f"bench.py rank {rank}/{world} config {config}: about to hold scene {cx.info['device_bytes'] / 1e6:.0f} MB + {cx.n_flights} "

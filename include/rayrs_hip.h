@@ -373,7 +373,7 @@ int rayrs_render_multi(rayrs_scene* const* scenes, uint32_t n, const rayrs_camer
  * development knobs -- thresholds, LDS budgets, test switches -- are not part of this boundary: rayrs_amd/csrc/rayrs_lab.h.) */
 typedef struct {
     uint32_t pool_slots;    /* streaming route: paths in flight = slots of the pool in HBM, 128 + 33 bytes each
-                               (default: min(items, 112 Mi, samples / 12)); ignored on the local-pool route */
+                               (default: min(items, 256 Mi, samples / 12)); ignored on the local-pool route */
     uint32_t local_pool;    /* a scene whose gate tree is at most one record (gate_n_wide <= 1: the reference's sphere
                                scenes) is rendered by ONE launch that keeps every path in LDS from its first ray
                                to its last (local_pool.hip) instead of three launches per bounce over a pool in

@@ -780,10 +780,13 @@ int rayrs_render_launch(rayrs_scene* scene, const rayrs_camera* camera, const ra
     // 48 M 1497, 64 M 1467, 96 M 1468, 128 M 1481, 192 M 1498 (round 1, 192-byte slots: 32 M).
     // Swept again on round 3's kernels (the traversal kernel faster, its fixed cost per launch the same): 64 M 1369 ms,
     // 80 M 1372, 96 M 1368, 112 M 1353, 128 M 1356, 160 M 1353, 192 M 1350: 112 M slots (18 GB of the 288 GB), 84 rounds.
+    // And on round 6's (the hit kernel at three waves per SIMD, the cheap queries answered by the kernels that make the rays):
+    // 80 M 1298 ms, 96 M 1290, 112 M 1276, 128 M 1278, 144 M 1267, 160 M 1250, 192 M 1250, 224 M 1246, 256 M 1242, 320 M 1242
+    // (profiles/r06_leaf_queue.txt (12)): 256 M slots (43 GB), 52 rounds.
     // A frame should also last some tens of rounds, or filling and draining the pool is all it does: at most one
     // slot per 12 samples -- which is what a one-eighth tile share of the headline frame gets (44.7 M: 33.5 M 189 ms,
     // 48 M 184, 64 M 186).
-    constexpr uint64_t POOL_MAX_SLOTS = 7ull << 24;
+    constexpr uint64_t POOL_MAX_SLOTS = 1ull << 28;
     uint64_t np64 = rp.total_items;
     if (np64 > POOL_MAX_SLOTS) np64 = POOL_MAX_SLOTS;
     {
